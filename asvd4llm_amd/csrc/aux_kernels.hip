@@ -1,0 +1,462 @@
+// aux_kernels.hip — the HBM-bound kernels around the SVD: calibration-hook statistics (K1/K2), scale vector and
+// column scaling (K3), truncate/un-scale/fuse/split (K5/K6), Frobenius norm (K8) and the reconstruction-error
+// evidence kernel (K9).  Reference lines are cited at each entry point in include/asvd_hip.h.
+#include "common.h"
+#include <cmath>
+#include <cstring>
+
+namespace {
+
+// --------------------------------------------------------------------------------------------------
+// K1/K2  |x| column statistics.  A wave covers 64*VEC consecutive columns of one row with 16-B loads per lane
+// (1 KiB per wave-instruction); the 4 waves of a workgroup interleave rows; row range split over blockIdx.y.
+template <int DT> struct vec_of;  // VEC elements per 16-byte load
+template <> struct vec_of<ASVD_F32> { static constexpr int VEC = 4; };
+template <> struct vec_of<ASVD_F16> { static constexpr int VEC = 8; };
+template <> struct vec_of<ASVD_BF16> { static constexpr int VEC = 8; };
+
+template <int DT, int MODE>
+__global__ __launch_bounds__(256) void absstat_partial_kernel(const void* __restrict__ x, int64_t rows, int64_t cols, int64_t ld,
+                                                              int64_t rows_per_split, float* __restrict__ part,
+                                                              int* __restrict__ nanflag) {
+    constexpr int VEC = vec_of<DT>::VEC;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t c0 = ((int64_t)blockIdx.x * 64 + lane) * VEC;
+    const int split = blockIdx.y;
+    const int64_t rb = split * rows_per_split;
+    const int64_t re = (rb + rows_per_split < rows) ? rb + rows_per_split : rows;
+    float acc[VEC];
+    int seen_nan = 0;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v] = 0.0f;
+    const bool full = (c0 + VEC <= cols) && ((ld % VEC) == 0) && ((((uintptr_t)x) & 15) == 0);
+    for (int64_t r = rb + w; r < re; r += 4) {
+        float vals[VEC];
+        if (full) {
+            if (DT == ASVD_F32) {
+                const f32x4 t = *(const f32x4*)((const float*)x + r * ld + c0);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) vals[v] = t[v % 4];
+            } else {
+                const uint4 t = *(const uint4*)((const uint16_t*)x + r * ld + c0);
+                const uint32_t wds[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    const uint16_t bits = (uint16_t)(wds[(v >> 1) & 3] >> (16 * (v & 1)));
+                    vals[v] = (DT == ASVD_F16) ? f16_bits_to_f32(bits) : bf16_bits_to_f32(bits);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) vals[v] = (c0 + v < cols) ? elem<DT>::ld(x, r * ld + c0 + v) : 0.0f;
+        }
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            const float a = fabsf(vals[v]);
+            if (MODE == ASVD_STAT_ABS_MEAN) acc[v] += a;
+            else {
+                if (a != a) seen_nan |= (1 << v);
+                else acc[v] = fmaxf(acc[v], a);
+            }
+        }
+    }
+    __shared__ float red[4][64 * VEC];
+    __shared__ int rnan[4][64];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) red[w][v * 64 + lane] = acc[v];
+    rnan[w][lane] = seen_nan;
+    __syncthreads();
+    if (w == 0) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            float s = red[0][v * 64 + lane];
+            if (MODE == ASVD_STAT_ABS_MEAN) s = ((s + red[1][v * 64 + lane]) + red[2][v * 64 + lane]) + red[3][v * 64 + lane];
+            else s = fmaxf(fmaxf(s, red[1][v * 64 + lane]), fmaxf(red[2][v * 64 + lane], red[3][v * 64 + lane]));
+            if (c0 + v < cols) part[(int64_t)split * cols + c0 + v] = s;
+        }
+        if (MODE == ASVD_STAT_ABS_MAX) {
+            const int nn = rnan[0][lane] | rnan[1][lane] | rnan[2][lane] | rnan[3][lane];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v)
+                if (c0 + v < cols) nanflag[(int64_t)split * cols + c0 + v] = (nn >> v) & 1;
+        }
+    }
+}
+
+template <int AT, int MODE>
+__global__ void absstat_final_kernel(const float* __restrict__ part, const int* __restrict__ nanflag, int nsplit, int64_t rows,
+                                     int64_t cols, void* __restrict__ acc) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    const float old = elem<AT>::ld(acc, c);
+    if (MODE == ASVD_STAT_ABS_MEAN) {
+        float s = 0.0f;
+        for (int k = 0; k < nsplit; ++k) s += part[(int64_t)k * cols + c];
+        const float mean = elem<AT>::rnd(s / (float)rows);  // .mean() result in the activation dtype
+        elem<AT>::st(acc, c, old + mean);                   // `+=` in that dtype (one rounding)
+    } else {
+        float mx = 0.0f;
+        int nn = 0;
+        for (int k = 0; k < nsplit; ++k) {
+            mx = fmaxf(mx, part[(int64_t)k * cols + c]);
+            nn |= nanflag[(int64_t)k * cols + c];
+        }
+        // torch.where(abs_max > acc, abs_max, acc): a NaN abs_max never wins
+        if (!nn && mx > old) elem<AT>::st(acc, c, mx);
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
+// K3a  s = (scaling**alpha [* fisher**alpha]) + eps, each op rounded to the statistics dtype
+__device__ __forceinline__ float pow_alpha(float x, float alpha) {
+    if (alpha == 0.5f) return sqrtf(x);
+    if (alpha == 1.0f) return x;
+    if (alpha == 2.0f) return x * x;
+    return powf(x, alpha);
+}
+template <int DT>
+__global__ void make_scale_kernel(const void* __restrict__ scaling, const void* __restrict__ fisher, int64_t n, float alpha,
+                                  float eps, void* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float p = elem<DT>::rnd(pow_alpha(elem<DT>::ld(scaling, i), alpha));
+    if (fisher) {
+        const float f = elem<DT>::rnd(pow_alpha(elem<DT>::ld(fisher, i), alpha));
+        p = elem<DT>::rnd(p * f);
+    }
+    elem<DT>::st(out, i, p + eps);
+}
+
+// K3b  out = float(w) * float(s)
+template <int DT, int ST>
+__global__ __launch_bounds__(256) void scale_cols_kernel(const void* __restrict__ w, int64_t m, int64_t n, int64_t ldw,
+                                                         const void* __restrict__ s, int has_scale, float* __restrict__ out,
+                                                         int64_t ldo) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const float sc = has_scale ? elem<ST>::ld(s, j) : 1.0f;
+    const int64_t r0 = (int64_t)blockIdx.y * 32;
+    const int64_t r1 = (r0 + 32 < m) ? r0 + 32 : m;
+    for (int64_t r = r0; r < r1; ++r) out[r * ldo + j] = elem<DT>::ld(w, r * ldw + j) * sc;
+}
+
+// --------------------------------------------------------------------------------------------------
+// K5/K6  A = U[:, :r] * f(S) ; B = ((V[:, :r] / s[:,None]).T) * g(S)[:,None] ; NaN flags
+template <int OT>
+__global__ __launch_bounds__(256) void split_a_kernel(const float* __restrict__ U, int64_t ldu, const float* __restrict__ S,
+                                                      int64_t m, int64_t r, int fuse, void* __restrict__ A,
+                                                      int* __restrict__ nan_flags) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= r) return;
+    const float sv = S[j];
+    const float f = (fuse == ASVD_FUSE_UV) ? sqrtf(sv) : (fuse == ASVD_FUSE_U ? sv : 1.0f);
+    int bad_u = 0;
+    const int64_t i0 = (int64_t)blockIdx.y * 32;
+    const int64_t i1 = (i0 + 32 < m) ? i0 + 32 : m;
+    for (int64_t i = i0; i < i1; ++i) {
+        const float u = U[i * ldu + j];
+        bad_u |= (u != u);
+        elem<OT>::st(A, i * r + j, (fuse == ASVD_FUSE_V) ? u : u * f);
+    }
+    if (nan_flags) {
+        if (blockIdx.y == 0 && sv != sv) atomicOr(&nan_flags[0], 1);
+        if (bad_u) atomicOr(&nan_flags[1], 1);
+    }
+}
+
+template <int OT, int ST>
+__global__ __launch_bounds__(256) void split_b_kernel(const float* __restrict__ V, int64_t ldv, const float* __restrict__ S,
+                                                      const void* __restrict__ s, int has_scale, int64_t n, int64_t r,
+                                                      int fuse, void* __restrict__ B, int* __restrict__ nan_flags) {
+    // 32 (i: rows of V) x 32 (j: rank index) tile, transposed through LDS: B[j][i]
+    __shared__ float tile[32][33];
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+    const int64_t i0 = (int64_t)blockIdx.x * 32, j0 = (int64_t)blockIdx.y * 32;
+    int bad = 0;
+    for (int a = ly; a < 32; a += 8) {
+        const int64_t i = i0 + a, j = j0 + lx;
+        float v = 0.0f;
+        if (i < n && j < r) {
+            v = V[i * ldv + j];
+            if (has_scale) v = v / elem<ST>::ld(s, i);
+            bad |= (v != v);
+        }
+        tile[a][lx] = v;
+    }
+    __syncthreads();
+    for (int a = ly; a < 32; a += 8) {
+        const int64_t j = j0 + a, i = i0 + lx;
+        if (i < n && j < r) {
+            const float sv = S[j];
+            const float g = (fuse == ASVD_FUSE_UV) ? sqrtf(sv) : (fuse == ASVD_FUSE_V ? sv : 1.0f);
+            const float v = tile[lx][a];
+            elem<OT>::st(B, j * n + i, (fuse == ASVD_FUSE_U) ? v : v * g);
+        }
+    }
+    if (nan_flags && bad) atomicOr(&nan_flags[2], 1);
+}
+
+// --------------------------------------------------------------------------------------------------
+// K8  sum of squares, fp32, fixed order: per-block partials then a single-thread-block ordered sum
+template <int DT>
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const void* __restrict__ w, int64_t m, int64_t n, int64_t ldw,
+                                                            float* __restrict__ part) {
+    // block handles 8 rows; thread strides over columns
+    const int64_t r0 = (int64_t)blockIdx.x * 8;
+    float acc = 0.0f;
+    for (int64_t r = r0; r < r0 + 8 && r < m; ++r)
+        for (int64_t j = threadIdx.x; j < n; j += 256) {
+            const float v = elem<DT>::ld(w, r * ldw + j);
+            acc += v * v;
+        }
+    __shared__ float red[256];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+__global__ __launch_bounds__(256) void ordered_sum_f32_kernel(const float* __restrict__ part, int64_t np, float* __restrict__ out) {
+    __shared__ float red[256];
+    float acc = 0.0f;
+    for (int64_t i = threadIdx.x; i < np; i += 256) acc += part[i];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0];
+}
+
+// --------------------------------------------------------------------------------------------------
+// K9  |W - A*B|_F^2 and |W|_F^2.  One wave per 32x32 output tile, fp32 MFMA (exact products of the stored factors).
+template <int WT, int ABT>
+__global__ __launch_bounds__(256) void recon_err_kernel(const void* __restrict__ W, int64_t ldw, const void* __restrict__ A,
+                                                        const void* __restrict__ B, int64_t m, int64_t n, int64_t r,
+                                                        double* __restrict__ part) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int h = lane >> 5, c = lane & 31;
+    const int64_t r0 = (int64_t)blockIdx.y * 64 + (w >> 1) * 32;
+    const int64_t c0 = (int64_t)blockIdx.x * 64 + (w & 1) * 32;
+    f32x16 acc = {0};
+    const int64_t row = r0 + c;  // A-operand row of this lane
+    const int64_t col = c0 + c;  // B-operand column of this lane
+    for (int64_t k0 = 0; k0 < r; k0 += 16) {
+        float a[8], b[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int64_t k = k0 + h * 8 + t;
+            a[t] = (row < m && k < r) ? elem<ABT>::ld(A, row * r + k) : 0.0f;
+            b[t] = (col < n && k < r) ? elem<ABT>::ld(B, k * n + col) : 0.0f;
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[t], acc, 0, 0, 0);
+    }
+    double e2 = 0.0, w2 = 0.0;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int64_t i = r0 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        const int64_t j = c0 + c;
+        if (i < m && j < n) {
+            const float wv = elem<WT>::ld(W, i * ldw + j);
+            const double d = (double)wv - (double)acc[reg];
+            e2 += d * d;
+            w2 += (double)wv * (double)wv;
+        }
+    }
+    e2 = wave_reduce_sum_d(e2);
+    w2 = wave_reduce_sum_d(w2);
+    __shared__ double red[4][2];
+    if (lane == 0) { red[w][0] = e2; red[w][1] = w2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int64_t bid = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+        part[2 * bid + 0] = ((red[0][0] + red[1][0]) + red[2][0]) + red[3][0];
+        part[2 * bid + 1] = ((red[0][1] + red[1][1]) + red[2][1]) + red[3][1];
+    }
+}
+__global__ __launch_bounds__(256) void ordered_sum_d2_kernel(const double* __restrict__ part, int64_t np, double* __restrict__ out) {
+    __shared__ double red[256][2];
+    double a = 0.0, b = 0.0;
+    for (int64_t i = threadIdx.x; i < np; i += 256) { a += part[2 * i]; b += part[2 * i + 1]; }
+    red[threadIdx.x][0] = a;
+    red[threadIdx.x][1] = b;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { red[threadIdx.x][0] += red[threadIdx.x + o][0]; red[threadIdx.x][1] += red[threadIdx.x + o][1]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[0] = red[0][0]; out[1] = red[0][1]; }
+}
+
+int absstat_nsplit(int64_t rows, int64_t cols) {
+    // enough workgroups to fill 256 CUs, at least 32 rows per split
+    const int64_t colblocks = ceil_div64(cols, 64 * 4);
+    int64_t ns = ceil_div64(1024, colblocks);
+    const int64_t maxs = rows / 32 > 0 ? rows / 32 : 1;
+    if (ns > maxs) ns = maxs;
+    if (ns < 1) ns = 1;
+    if (ns > 256) ns = 256;
+    return (int)ns;
+}
+
+}  // namespace
+
+extern "C" {
+
+int asvd_version(void) { return 100; }
+
+const char* asvd_status_string(int status) {
+    switch (status) {
+        case ASVD_OK: return "ok";
+        case ASVD_E_BADARG: return "bad argument";
+        case ASVD_E_WORKSPACE: return "workspace too small";
+        case ASVD_E_HIP: return "HIP runtime error";
+        case ASVD_E_NODEVICE: return "no gfx950 device";
+        case ASVD_N_NOCONV: return "Jacobi SVD did not converge within max_sweeps";
+        case ASVD_N_NAN: return "NaN/Inf encountered";
+        default: return "unknown status";
+    }
+}
+
+int asvd_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    int ok = 0;
+    for (int d = 0; d < n; ++d) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, d) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) == 0) ++ok;
+    }
+    return ok;
+}
+
+int asvd_absstat_worksize(int64_t rows, int64_t cols, size_t* bytes) {
+    if (!bytes || rows < 1 || cols < 1) return ASVD_E_BADARG;
+    const int ns = absstat_nsplit(rows, cols);
+    *bytes = (size_t)ns * cols * (sizeof(float) + sizeof(int));
+    return ASVD_OK;
+}
+
+int asvd_absstat_accum(const void* x, int x_dtype, int64_t rows, int64_t cols, int64_t ld, void* acc, int acc_dtype, int mode,
+                       void* work, size_t work_bytes, void* stream) {
+    if (!x || !acc || !work || rows < 1 || cols < 1 || ld < cols || !dtype_ok(x_dtype) || !dtype_ok(acc_dtype)) return ASVD_E_BADARG;
+    if (mode != ASVD_STAT_ABS_MEAN && mode != ASVD_STAT_ABS_MAX) return ASVD_E_BADARG;
+    const int ns = absstat_nsplit(rows, cols);
+    if (work_bytes < (size_t)ns * cols * (sizeof(float) + sizeof(int))) return ASVD_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float* part = (float*)work;
+    int* nanflag = (int*)(part + (int64_t)ns * cols);
+    const int64_t rps = ceil_div64(rows, ns);
+    const int vec = (x_dtype == ASVD_F32) ? 4 : 8;
+    dim3 grid((unsigned)ceil_div64(cols, 64 * vec), (unsigned)ns);
+    ASVD_DISPATCH_DTYPE(x_dtype, XT, {
+        if (mode == ASVD_STAT_ABS_MEAN) absstat_partial_kernel<XT, ASVD_STAT_ABS_MEAN><<<grid, 256, 0, st>>>(x, rows, cols, ld, rps, part, nanflag);
+        else absstat_partial_kernel<XT, ASVD_STAT_ABS_MAX><<<grid, 256, 0, st>>>(x, rows, cols, ld, rps, part, nanflag);
+    });
+    const unsigned fg = (unsigned)ceil_div64(cols, 256);
+    ASVD_DISPATCH_DTYPE(acc_dtype, AT, {
+        if (mode == ASVD_STAT_ABS_MEAN) absstat_final_kernel<AT, ASVD_STAT_ABS_MEAN><<<fg, 256, 0, st>>>(part, nanflag, ns, rows, cols, acc);
+        else absstat_final_kernel<AT, ASVD_STAT_ABS_MAX><<<fg, 256, 0, st>>>(part, nanflag, ns, rows, cols, acc);
+    });
+    ASVD_HIP_CHECK(hipGetLastError());
+    return ASVD_OK;
+}
+
+int asvd_make_scale(const void* scaling, const void* fisher, int dtype, int64_t n, float alpha, float eps, void* out, void* stream) {
+    if (!scaling || !out || n < 1 || !dtype_ok(dtype)) return ASVD_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned g = (unsigned)ceil_div64(n, 256);
+    ASVD_DISPATCH_DTYPE(dtype, DT, { make_scale_kernel<DT><<<g, 256, 0, st>>>(scaling, fisher, n, alpha, eps, out); });
+    ASVD_HIP_CHECK(hipGetLastError());
+    return ASVD_OK;
+}
+
+int asvd_scale_cols(const void* w, int w_dtype, int64_t m, int64_t n, int64_t ldw, const void* s, int s_dtype, float* out,
+                    int64_t ldo, void* stream) {
+    if (!w || !out || m < 1 || n < 1 || ldw < n || ldo < n || !dtype_ok(w_dtype)) return ASVD_E_BADARG;
+    if (s && !dtype_ok(s_dtype)) return ASVD_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)ceil_div64(n, 256), (unsigned)ceil_div64(m, 32));
+    const int has = s ? 1 : 0;
+    const int sdt = s ? s_dtype : ASVD_F32;
+    ASVD_DISPATCH_DTYPE(w_dtype, WT, {
+        switch (sdt) {
+            case ASVD_F32: scale_cols_kernel<WT, ASVD_F32><<<grid, 256, 0, st>>>(w, m, n, ldw, s, has, out, ldo); break;
+            case ASVD_F16: scale_cols_kernel<WT, ASVD_F16><<<grid, 256, 0, st>>>(w, m, n, ldw, s, has, out, ldo); break;
+            default: scale_cols_kernel<WT, ASVD_BF16><<<grid, 256, 0, st>>>(w, m, n, ldw, s, has, out, ldo); break;
+        }
+    });
+    ASVD_HIP_CHECK(hipGetLastError());
+    return ASVD_OK;
+}
+
+int asvd_truncate_split(const float* U, int64_t ldu, const float* S, const float* V, int64_t ldv, const void* s, int s_dtype,
+                        int64_t m, int64_t n, int64_t r, int sigma_fuse, void* A, void* B, int out_dtype, int* nan_flags,
+                        void* stream) {
+    if (!U || !S || !V || !A || !B || m < 1 || n < 1 || r < 1 || ldu < r || ldv < r || !dtype_ok(out_dtype)) return ASVD_E_BADARG;
+    if (sigma_fuse < 0 || sigma_fuse > 2) return ASVD_E_BADARG;
+    if (s && !dtype_ok(s_dtype)) return ASVD_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int has = s ? 1 : 0;
+    const int sdt = s ? s_dtype : ASVD_F32;
+    dim3 ga((unsigned)ceil_div64(r, 256), (unsigned)ceil_div64(m, 32));
+    dim3 gb((unsigned)ceil_div64(n, 32), (unsigned)ceil_div64(r, 32));
+    ASVD_DISPATCH_DTYPE(out_dtype, OT, {
+        split_a_kernel<OT><<<ga, 256, 0, st>>>(U, ldu, S, m, r, sigma_fuse, A, nan_flags);
+        switch (sdt) {
+            case ASVD_F32: split_b_kernel<OT, ASVD_F32><<<gb, 256, 0, st>>>(V, ldv, S, s, has, n, r, sigma_fuse, B, nan_flags); break;
+            case ASVD_F16: split_b_kernel<OT, ASVD_F16><<<gb, 256, 0, st>>>(V, ldv, S, s, has, n, r, sigma_fuse, B, nan_flags); break;
+            default: split_b_kernel<OT, ASVD_BF16><<<gb, 256, 0, st>>>(V, ldv, S, s, has, n, r, sigma_fuse, B, nan_flags); break;
+        }
+    });
+    ASVD_HIP_CHECK(hipGetLastError());
+    return ASVD_OK;
+}
+
+int asvd_fro_worksize(int64_t m, int64_t n, size_t* bytes) {
+    if (!bytes || m < 1 || n < 1) return ASVD_E_BADARG;
+    *bytes = (size_t)ceil_div64(m, 8) * sizeof(float);
+    return ASVD_OK;
+}
+
+int asvd_fro_norm_sq(const void* w, int w_dtype, int64_t m, int64_t n, int64_t ldw, float* out, void* work, size_t work_bytes,
+                     void* stream) {
+    if (!w || !out || !work || m < 1 || n < 1 || ldw < n || !dtype_ok(w_dtype)) return ASVD_E_BADARG;
+    const int64_t np = ceil_div64(m, 8);
+    if (work_bytes < (size_t)np * sizeof(float)) return ASVD_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    ASVD_DISPATCH_DTYPE(w_dtype, WT, { sumsq_partial_kernel<WT><<<(unsigned)np, 256, 0, st>>>(w, m, n, ldw, (float*)work); });
+    ordered_sum_f32_kernel<<<1, 256, 0, st>>>((const float*)work, np, out);
+    ASVD_HIP_CHECK(hipGetLastError());
+    return ASVD_OK;
+}
+
+int asvd_reconstruct_worksize(int64_t m, int64_t n, size_t* bytes) {
+    if (!bytes || m < 1 || n < 1) return ASVD_E_BADARG;
+    *bytes = (size_t)(ceil_div64(m, 64) * ceil_div64(n, 64)) * 2 * sizeof(double);
+    return ASVD_OK;
+}
+
+int asvd_reconstruct_err(const void* W, int w_dtype, int64_t ldw, const void* A, const void* B, int ab_dtype, int64_t m, int64_t n,
+                         int64_t r, double* out, void* work, size_t work_bytes, void* stream) {
+    if (!W || !A || !B || !out || !work || m < 1 || n < 1 || r < 1 || ldw < n || !dtype_ok(w_dtype) || !dtype_ok(ab_dtype)) return ASVD_E_BADARG;
+    const int64_t gx = ceil_div64(n, 64), gy = ceil_div64(m, 64);
+    if (work_bytes < (size_t)(gx * gy) * 2 * sizeof(double)) return ASVD_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)gx, (unsigned)gy);
+    ASVD_DISPATCH_DTYPE(w_dtype, WT, {
+        switch (ab_dtype) {
+            case ASVD_F32: recon_err_kernel<WT, ASVD_F32><<<grid, 256, 0, st>>>(W, ldw, A, B, m, n, r, (double*)work); break;
+            case ASVD_F16: recon_err_kernel<WT, ASVD_F16><<<grid, 256, 0, st>>>(W, ldw, A, B, m, n, r, (double*)work); break;
+            default: recon_err_kernel<WT, ASVD_BF16><<<grid, 256, 0, st>>>(W, ldw, A, B, m, n, r, (double*)work); break;
+        }
+    });
+    ordered_sum_d2_kernel<<<1, 256, 0, st>>>((const double*)work, gx * gy, out);
+    ASVD_HIP_CHECK(hipGetLastError());
+    return ASVD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,746 @@
+// svd_jacobi.hip — K4: batched economy SVD in fp32 by one-sided block Jacobi, written for gfx950.
+//
+// Replaces the factorisation at modules/svd_linear.py:65 (oracle: torch.linalg.svd, BASELINE.json) and the
+// values-only torch.svd at sensitivity.py:101.  See DESIGN.md §"K4" for the algorithm and roofline.
+//
+// Data layout in HBM (per problem): the oriented matrix (rows >= cols) is stored as nb = ncols_pad/32
+// column panels.  Panel I is a dense [R][32] fp32 array (row stride 128 B = one cache line), so a wave
+// reads two consecutive rows of a panel with ONE fully coalesced 256-B load, and a panel pair is two
+// contiguous streams.  Rows [0, m_pad) hold A (times the column scale), rows [m_pad, m_pad + n_pad) hold
+// the accumulated right factor V (identity at start) so that one update kernel rotates both.
+//
+// Per round-robin step (nb/2 disjoint panel pairs) three launches:
+//   gram_kernel    G = [A_I A_J]^T [A_I A_J]  (64x64; blocks II, IJ, JJ) — v_mfma_f32_32x32x2_f32, K = rows
+//   evd_kernel     two-sided Jacobi on G in LDS (fp32), eigenvalues sorted descending -> Q (64x64)
+//   update_kernel  [X_I X_J] <- [X_I X_J] * Q  over all R rows — v_mfma_f32_32x32x2_f32, K = 64
+#include "common.h"
+#include <vector>
+#include <cmath>
+#include <cstring>
+
+namespace {
+
+constexpr int PB = 32;       // panel width
+constexpr int PW = 2 * PB;   // pair width
+constexpr int GLD = PW + 1;  // LDS leading dimension of the 64x64 matrices in evd_kernel
+
+// round-robin tournament: nb (even) players, nb-1 steps, pair k in [0, nb/2).
+__device__ __host__ __forceinline__ void rr_pair(int nb, int step, int k, int& I, int& J) {
+    const int a = (k == 0) ? 0 : 1 + (k - 1 + step) % (nb - 1);
+    const int pb = nb - 1 - k;
+    const int b = 1 + (pb - 1 + step) % (nb - 1);
+    I = a < b ? a : b;
+    J = a < b ? b : a;
+}
+
+// --------------------------------------------------------------------------------------------------
+// pack: oriented, scaled, fp32 copy of the input into panel layout.  X must be zero-filled before.
+//   transposed == 0:  X[blk][r][c] = float(src[r][blk*32+c]) * float(s[blk*32+c])      r < rows, col < cols
+//   transposed == 1:  X[blk][r][c] = float(src[blk*32+c][r]) * float(s[r])             (oriented = src^T)
+// The product is the reference's `w.float() * s.view(1,-1)` (fp32 * upcast(s)), svd_linear.py:47,60.
+template <int DT, int ST>
+__global__ __launch_bounds__(256) void pack_kernel(const void* __restrict__ src, int64_t ld, const void* __restrict__ s,
+                                                   int has_scale, int transposed, int rows, int cols, int R,
+                                                   float* __restrict__ X) {
+    // block: 32 oriented rows x 256 oriented columns (8 panels)
+    const int tx = threadIdx.x;
+    const int r0 = blockIdx.x * 32;
+    const int c0 = blockIdx.y * 256;
+    if (!transposed) {
+        const int col = c0 + tx;
+        if (col >= cols) return;
+        const float sc = has_scale ? elem<ST>::ld(s, col) : 1.0f;
+        float* dst = X + ((int64_t)(col >> 5) * R) * PB + (col & 31);
+        for (int i = 0; i < 32; ++i) {
+            const int r = r0 + i;
+            if (r >= rows) break;
+            dst[(int64_t)r * PB] = elem<DT>::ld(src, (int64_t)r * ld + col) * sc;
+        }
+    } else {
+        // tile transpose through LDS: read src[c][r] coalesced along r, write X[.][r][c] coalesced along c
+        __shared__ float tile[32][33];
+        const int lx = tx & 31, ly = tx >> 5;  // 32 x 8
+        for (int p = 0; p < 8; ++p) {          // 8 panels of 32 oriented columns
+            const int cb = c0 + p * 32;
+            if (cb >= cols) break;             // uniform per block
+            for (int j = ly; j < 32; j += 8) {
+                const int c = cb + j, r = r0 + lx;
+                float v = 0.0f;
+                if (c < cols && r < rows) {
+                    const float sc = has_scale ? elem<ST>::ld(s, r) : 1.0f;
+                    v = elem<DT>::ld(src, (int64_t)c * ld + r) * sc;
+                }
+                tile[j][lx] = v;
+            }
+            __syncthreads();
+            float* dst = X + ((int64_t)(cb >> 5) * R) * PB;
+            for (int i = ly; i < 32; i += 8) {
+                const int r = r0 + i;
+                if (r < rows && cb + lx < cols) dst[(int64_t)r * PB + lx] = tile[lx][i];
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// V part: identity on the real columns
+__global__ void vinit_kernel(float* __restrict__ X, int cols, int R, int m_pad) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < cols) X[((int64_t)(j >> 5) * R + m_pad + j) * PB + (j & 31)] = 1.0f;
+}
+
+// --------------------------------------------------------------------------------------------------
+// gram: per (row split, pair, problem) partial 64x64 Gram matrix, three 32x32 blocks II, IJ, JJ.
+// MFMA 32x32x2 f32: lane l supplies A[i=l&31][k=l>>5] and B[k=l>>5][j=l&31]; with A = panel^T the wave's
+// operand for rows (r, r+1) is simply panel[r*32 + l] — one coalesced 256-B load per panel per MFMA step.
+__global__ __launch_bounds__(256) void gram_kernel(const float* __restrict__ X, int64_t panel_stride, int64_t batch_stride,
+                                                   int nb, int step, int m_pad, int rows_per_split,
+                                                   float* __restrict__ Gpart, const int* __restrict__ done) {
+    const int split = blockIdx.x, pair = blockIdx.y, b = blockIdx.z;
+    const int nsplit = gridDim.x, npairs = gridDim.y;
+    if (done[b]) return;
+    int I, J;
+    rr_pair(nb, step, pair, I, J);
+    const float* __restrict__ XI = X + (int64_t)b * batch_stride + (int64_t)I * panel_stride;
+    const float* __restrict__ XJ = X + (int64_t)b * batch_stride + (int64_t)J * panel_stride;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r_begin = split * rows_per_split;
+    const int r_end = min(r_begin + rows_per_split, m_pad);
+    const int nsteps = (r_end - r_begin) >> 1;  // row pairs in this split
+
+    f32x16 aii = {0}, aij = {0}, ajj = {0};
+    const float* pi = XI + (int64_t)r_begin * PB + lane;
+    const float* pj = XJ + (int64_t)r_begin * PB + lane;
+    int s = w;
+    for (; s + 28 < nsteps; s += 32) {
+        float a[8], c[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t off = (int64_t)(s + 4 * u) * (2 * PB);
+            a[u] = pi[off];
+            c[u] = pj[off];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            aii = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], a[u], aii, 0, 0, 0);
+            aij = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], c[u], aij, 0, 0, 0);
+            ajj = __builtin_amdgcn_mfma_f32_32x32x2f32(c[u], c[u], ajj, 0, 0, 0);
+        }
+    }
+    for (; s < nsteps; s += 4) {
+        const int64_t off = (int64_t)s * (2 * PB);
+        const float a = pi[off], c = pj[off];
+        aii = __builtin_amdgcn_mfma_f32_32x32x2f32(a, a, aii, 0, 0, 0);
+        aij = __builtin_amdgcn_mfma_f32_32x32x2f32(a, c, aij, 0, 0, 0);
+        ajj = __builtin_amdgcn_mfma_f32_32x32x2f32(c, c, ajj, 0, 0, 0);
+    }
+
+    // cross-wave reduction in fixed order (deterministic), then natural [t][i][j] layout to global
+    __shared__ float red[4 * 3 * 16 * 64];
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        red[((w * 3 + 0) * 16 + reg) * 64 + lane] = aii[reg];
+        red[((w * 3 + 1) * 16 + reg) * 64 + lane] = aij[reg];
+        red[((w * 3 + 2) * 16 + reg) * 64 + lane] = ajj[reg];
+    }
+    __syncthreads();
+    float* out = Gpart + (((int64_t)b * npairs + pair) * nsplit + split) * 3072;
+    for (int o = threadIdx.x; o < 3072; o += 256) {
+        const int t = o >> 10, i = (o & 1023) >> 5, j = o & 31;
+        const int ls = j + 32 * ((i >> 2) & 1);
+        const int reg = (i & 3) + 4 * (i >> 3);
+        float v = red[((0 * 3 + t) * 16 + reg) * 64 + ls];
+        v += red[((1 * 3 + t) * 16 + reg) * 64 + ls];
+        v += red[((2 * 3 + t) * 16 + reg) * 64 + ls];
+        v += red[((3 * 3 + t) * 16 + reg) * 64 + ls];
+        out[o] = v;
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
+// evd: one workgroup (1024 threads = 32 x 32 two-by-two blocks) per pair.  Two-sided Jacobi with the
+// parallel round-robin ordering: 63 steps per sweep, 32 disjoint rotations per step.
+__global__ __launch_bounds__(1024) void evd_kernel(const float* __restrict__ Gpart, int nsplit, float* __restrict__ Qbuf,
+                                                    int* __restrict__ active, unsigned* __restrict__ maxoff_bits,
+                                                    int* __restrict__ nrot, const int* __restrict__ done, float tol,
+                                                    int inner_sweeps) {
+    __shared__ float G[PW * GLD];
+    __shared__ float Q[PW * GLD];
+    __shared__ float cs[32 * 4];
+    __shared__ float redmax[16];
+    __shared__ float lam[PW];
+    __shared__ int rnk[PW];
+
+    const int pair = blockIdx.x, b = blockIdx.y, npairs = gridDim.x;
+    if (done[b]) return;
+    const int tid = threadIdx.x;
+    const float* gp = Gpart + ((int64_t)b * npairs + pair) * nsplit * 3072;
+
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = tid + 1024 * q;
+        const int i = e >> 6, j = e & 63;
+        int t, ii, jj;
+        if (i < 32 && j < 32) { t = 0; ii = i; jj = j; }
+        else if (i < 32) { t = 1; ii = i; jj = j - 32; }
+        else if (j < 32) { t = 1; ii = j; jj = i - 32; }
+        else { t = 2; ii = i - 32; jj = j - 32; }
+        const float* p = gp + t * 1024 + ii * 32 + jj;
+        float v = 0.0f;
+        for (int s = 0; s < nsplit; ++s) v += p[(int64_t)s * 3072];
+        G[i * GLD + j] = v;
+        Q[i * GLD + j] = (i == j) ? 1.0f : 0.0f;
+    }
+    __syncthreads();
+
+    // scaled off-diagonal measure: max |g_ij| / sqrt(g_ii g_jj)
+    float loc = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = tid + 1024 * q;
+        const int i = e >> 6, j = e & 63;
+        if (i != j) {
+            const float dd = G[i * GLD + i] * G[j * GLD + j];
+            const float g = G[i * GLD + j];
+            float v = (dd > 0.0f) ? fabsf(g) * rsqrtf(dd) : 0.0f;
+            if (g != g) v = g;  // propagate NaN
+            loc = (v != v) ? v : ((loc != loc) ? loc : fmaxf(loc, v));
+        }
+    }
+    {
+        // NaN-propagating max over the block
+        float v = loc;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float u = __shfl_xor(v, o, 64);
+            v = (u != u) ? u : ((v != v) ? v : fmaxf(v, u));
+        }
+        if ((tid & 63) == 0) redmax[tid >> 6] = v;
+    }
+    __syncthreads();
+    float off0 = redmax[0];
+    for (int i = 1; i < 16; ++i) {
+        const float u = redmax[i];
+        off0 = (u != u) ? u : ((off0 != off0) ? off0 : fmaxf(off0, u));
+    }
+    const bool is_nan = (off0 != off0);
+    if (tid == 0) {
+        atomicMax(&maxoff_bits[b], is_nan ? 0x7fc00000u : __float_as_uint(off0));
+    }
+    if (is_nan || off0 < tol) {
+        if (tid == 0) active[b * npairs + pair] = 0;
+        return;
+    }
+    if (tid == 0) {
+        active[b * npairs + pair] = 1;
+        atomicAdd(&nrot[b], 1);
+    }
+
+    const int k1 = tid >> 5, k2 = tid & 31;  // row-pair index, column-pair index of this thread's 2x2 block
+    for (int sw = 0; sw < inner_sweeps; ++sw) {
+        for (int st = 0; st < PW - 1; ++st) {
+            int p1, q1, p2, q2;
+            rr_pair(PW, st, k1, p1, q1);
+            rr_pair(PW, st, k2, p2, q2);
+            if (k1 == k2) {
+                const float a = G[p1 * GLD + p1], d = G[q1 * GLD + q1], bb = G[p1 * GLD + q1];
+                float c = 1.0f, s = 0.0f, t = 0.0f;
+                if (fabsf(bb) > 1e-8f * sqrtf(fabsf(a) * fabsf(d)) && bb != 0.0f) {
+                    const float zeta = (d - a) / (2.0f * bb);
+                    t = copysignf(1.0f, zeta) / (fabsf(zeta) + sqrtf(1.0f + zeta * zeta));
+                    if (zeta == 0.0f) t = 1.0f;
+                    c = 1.0f / sqrtf(1.0f + t * t);
+                    s = t * c;
+                }
+                cs[k1 * 4 + 0] = c;
+                cs[k1 * 4 + 1] = s;
+                cs[k1 * 4 + 2] = t;
+            }
+            __syncthreads();
+            const float c1 = cs[k1 * 4 + 0], s1 = cs[k1 * 4 + 1];
+            const float c2 = cs[k2 * 4 + 0], s2 = cs[k2 * 4 + 1];
+            const float x00 = G[p1 * GLD + p2], x01 = G[p1 * GLD + q2];
+            const float x10 = G[q1 * GLD + p2], x11 = G[q1 * GLD + q2];
+            // left: rows (p1,q1) <- R1^T rows ; right: cols (p2,q2) <- cols R2,   R = [[c, s], [-s, c]]
+            const float y00 = c1 * x00 - s1 * x10, y01 = c1 * x01 - s1 * x11;
+            const float y10 = s1 * x00 + c1 * x10, y11 = s1 * x01 + c1 * x11;
+            float z00 = c2 * y00 - s2 * y01, z01 = s2 * y00 + c2 * y01;
+            float z10 = c2 * y10 - s2 * y11, z11 = s2 * y10 + c2 * y11;
+            if (k1 == k2) {
+                const float t = cs[k1 * 4 + 2];
+                z00 = x00 - t * x01;
+                z11 = x11 + t * x01;
+                z01 = 0.0f;
+                z10 = 0.0f;
+            }
+            G[p1 * GLD + p2] = z00;
+            G[p1 * GLD + q2] = z01;
+            G[q1 * GLD + p2] = z10;
+            G[q1 * GLD + q2] = z11;
+            // eigenvector accumulation: columns (p2,q2) of rows 2*k1, 2*k1+1
+            {
+                const int r0 = 2 * k1, r1 = 2 * k1 + 1;
+                const float u0 = Q[r0 * GLD + p2], v0 = Q[r0 * GLD + q2];
+                const float u1 = Q[r1 * GLD + p2], v1 = Q[r1 * GLD + q2];
+                Q[r0 * GLD + p2] = c2 * u0 - s2 * v0;
+                Q[r0 * GLD + q2] = s2 * u0 + c2 * v0;
+                Q[r1 * GLD + p2] = c2 * u1 - s2 * v1;
+                Q[r1 * GLD + q2] = s2 * u1 + c2 * v1;
+            }
+            __syncthreads();
+        }
+    }
+
+    // sort eigenvalues descending (ties by index): column c of Q goes to position rnk[c]
+    if (tid < PW) lam[tid] = G[tid * GLD + tid];
+    __syncthreads();
+    if (tid < PW) {
+        const float me = lam[tid];
+        int cnt = 0;
+        for (int i = 0; i < PW; ++i) {
+            const float o = lam[i];
+            cnt += (o > me || (o == me && i < tid)) ? 1 : 0;
+        }
+        rnk[tid] = cnt;
+    }
+    __syncthreads();
+    float* qo = Qbuf + ((int64_t)b * npairs + pair) * (PW * PW);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = tid + 1024 * q;
+        const int r = e >> 6, c = e & 63;
+        qo[r * PW + rnk[c]] = Q[r * GLD + c];
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
+// update: [X_I X_J] <- [X_I X_J] * Q for the rows of this chunk.  Each wave owns 32-row tiles: the tile is
+// staged through a private padded LDS image (coalesced 1-KB global loads in, conflict-free ds_read_b128
+// row-per-lane out), multiplied by Q held in 64 VGPRs, and stored as full 128-B row segments.
+constexpr int TLD = PW + 4;  // LDS row stride in floats (272 B, multiple of 16 B; bank-conflict-free b128 reads)
+
+__global__ __launch_bounds__(256) void update_kernel(float* __restrict__ X, int64_t panel_stride, int64_t batch_stride,
+                                                     int nb, int step, int R, int rows_per_wg,
+                                                     const float* __restrict__ Qbuf, const int* __restrict__ active,
+                                                     const int* __restrict__ done) {
+    const int chunk = blockIdx.x, pair = blockIdx.y, b = blockIdx.z, npairs = gridDim.y;
+    if (done[b] || !active[b * npairs + pair]) return;
+    int I, J;
+    rr_pair(nb, step, pair, I, J);
+    float* __restrict__ XI = X + (int64_t)b * batch_stride + (int64_t)I * panel_stride;
+    float* __restrict__ XJ = X + (int64_t)b * batch_stride + (int64_t)J * panel_stride;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int h = lane >> 5, c = lane & 31;
+
+    const float* __restrict__ Qp = Qbuf + ((int64_t)b * npairs + pair) * (PW * PW);
+    float q0[32], q1[32];
+#pragma unroll
+    for (int t = 0; t < 32; ++t) {
+        q0[t] = Qp[(h * 32 + t) * PW + c];
+        q1[t] = Qp[(h * 32 + t) * PW + 32 + c];
+    }
+
+    __shared__ __attribute__((aligned(16))) float tile[4][32 * TLD];
+    float* my = tile[w];
+    const int r_begin = chunk * rows_per_wg;
+    const int r_end = min(r_begin + rows_per_wg, R);
+    for (int base = r_begin; base < r_end; base += 128) {
+        const int r0 = base + w * 32;
+        const bool valid = r0 < r_end;  // R and rows_per_wg are multiples of 32
+        if (valid) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int idx = it * 256 + lane * 4;
+                const int row = idx >> 5, col = idx & 31;
+                const f32x4 vi = *(const f32x4*)(XI + (int64_t)r0 * PB + idx);
+                const f32x4 vj = *(const f32x4*)(XJ + (int64_t)r0 * PB + idx);
+                *(f32x4*)(my + row * TLD + col) = vi;
+                *(f32x4*)(my + row * TLD + 32 + col) = vj;
+            }
+        }
+        __syncthreads();
+        if (valid) {
+            float a[32];
+#pragma unroll
+            for (int t4 = 0; t4 < 8; ++t4) {
+                const f32x4 v = *(const f32x4*)(my + c * TLD + h * 32 + t4 * 4);
+                a[4 * t4 + 0] = v[0];
+                a[4 * t4 + 1] = v[1];
+                a[4 * t4 + 2] = v[2];
+                a[4 * t4 + 3] = v[3];
+            }
+            f32x16 acc0 = {0}, acc1 = {0};
+#pragma unroll
+            for (int t = 0; t < 32; ++t) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], q0[t], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], q1[t], acc1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int i = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                XI[(int64_t)(r0 + i) * PB + c] = acc0[reg];
+                XJ[(int64_t)(r0 + i) * PB + c] = acc1[reg];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
+// finalize 1: column norms (double accumulation), sigma_j = |a_j| / |v_j| (drift-corrected) or |a_j|
+__global__ __launch_bounds__(256) void colnorm_kernel(const float* __restrict__ X, int64_t panel_stride, int64_t batch_stride,
+                                                      int m_pad, int R, int n_pad, float* __restrict__ sig,
+                                                      float* __restrict__ inv_na, float* __restrict__ inv_nv) {
+    const int blk = blockIdx.x, b = blockIdx.y;
+    const float* P = X + (int64_t)b * batch_stride + (int64_t)blk * panel_stride;
+    const int c = threadIdx.x & 31, g = threadIdx.x >> 5;  // 8 row groups
+    double sa = 0.0, sv = 0.0;
+    for (int r = g; r < m_pad; r += 8) {
+        const double v = P[(int64_t)r * PB + c];
+        sa += v * v;
+    }
+    for (int r = m_pad + g; r < R; r += 8) {
+        const double v = P[(int64_t)r * PB + c];
+        sv += v * v;
+    }
+    __shared__ double ra[8][32], rv[8][32];
+    ra[g][c] = sa;
+    rv[g][c] = sv;
+    __syncthreads();
+    if (g == 0) {
+        for (int i = 1; i < 8; ++i) { sa += ra[i][c]; sv += rv[i][c]; }
+        const double na = sqrt(sa), nv = sqrt(sv);
+        const bool has_v = (R > m_pad);
+        const int j = blk * PB + c;
+        double s = na;
+        if (has_v) s = (nv > 0.0) ? na / nv : 0.0;
+        sig[(int64_t)b * n_pad + j] = (float)s;
+        inv_na[(int64_t)b * n_pad + j] = (na > 0.0) ? (float)(1.0 / na) : 0.0f;
+        inv_nv[(int64_t)b * n_pad + j] = (nv > 0.0) ? (float)(1.0 / nv) : 0.0f;
+    }
+}
+
+// finalize 2: rank by counting (descending, ties by index, NaN first) -> perm[rank] = j
+__global__ __launch_bounds__(256) void rank_kernel(const float* __restrict__ sig, int n_pad, int* __restrict__ perm) {
+    const int b = blockIdx.y;
+    const float* s = sig + (int64_t)b * n_pad;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    __shared__ float buf[256];
+    float me = (j < n_pad) ? s[j] : 0.0f;
+    if (me != me) me = INFINITY;
+    int cnt = 0;
+    for (int base = 0; base < n_pad; base += 256) {
+        float v = (base + threadIdx.x < n_pad) ? s[base + threadIdx.x] : -INFINITY;
+        if (v != v) v = INFINITY;
+        buf[threadIdx.x] = v;
+        __syncthreads();
+        const int lim = min(256, n_pad - base);
+        for (int i = 0; i < lim; ++i) {
+            const float o = buf[i];
+            cnt += (o > me || (o == me && base + i < j)) ? 1 : 0;
+        }
+        __syncthreads();
+    }
+    if (j < n_pad) perm[(int64_t)b * n_pad + cnt] = j;
+}
+
+// finalize 3: gather the leading k columns, normalised, into row-major outputs.
+//   part A rows [0, rowsA)  -> outA [rowsA, k]   (normalised a_j: left vectors of the oriented matrix)
+//   part V rows [0, rowsV)  -> outV [rowsV, k]   (normalised v_j: right vectors)
+__global__ __launch_bounds__(256) void gather_kernel(const float* __restrict__ X, int64_t panel_stride, int m_pad, int R,
+                                                     const float* __restrict__ sig, const float* __restrict__ inv_na,
+                                                     const float* __restrict__ inv_nv, const int* __restrict__ perm,
+                                                     int rowsA, int rowsV, int k, float* __restrict__ outA,
+                                                     float* __restrict__ outV, float* __restrict__ outS) {
+    const int jj = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rl = threadIdx.x >> 6;  // 4 row lanes
+    if (jj >= k) return;
+    const int j = perm[jj];
+    const float* P = X + (int64_t)(j >> 5) * panel_stride + (j & 31);
+    const int rtot = rowsA + rowsV;
+    const int rb = blockIdx.y * 64;
+    if (blockIdx.y == 0 && rl == 0 && outS) outS[jj] = sig[j];
+    const float ia = inv_na[j], iv = inv_nv[j];
+    for (int r = rb + rl; r < min(rb + 64, rtot); r += 4) {
+        if (r < rowsA) {
+            if (outA) outA[(int64_t)r * k + jj] = P[(int64_t)r * PB] * ia;
+        } else {
+            const int i = r - rowsA;
+            if (outV) outV[(int64_t)i * k + jj] = P[(int64_t)(m_pad + i) * PB] * iv;
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
+struct Plan {
+    int batch;
+    int64_t m, n;         // as given
+    int transposed;       // oriented = A^T when m < n
+    int rows, cols;       // oriented dims, rows >= cols
+    int m_pad, n_pad, nb, npairs, R, want_v;
+    int nsplit, rows_per_split, rows_per_wg, nchunks;
+    int64_t panel_stride, batch_stride;
+    // workspace offsets in bytes
+    size_t off_x, off_gpart, off_q, off_active, off_sig, off_ina, off_inv, off_perm, off_flags, total;
+};
+
+int make_plan(int batch, int64_t m, int64_t n, int want_v, Plan& p) {
+    if (batch < 1 || m < 1 || n < 1 || m > (1 << 24) || n > (1 << 24)) return ASVD_E_BADARG;
+    p.batch = batch;
+    p.m = m;
+    p.n = n;
+    p.transposed = (m < n) ? 1 : 0;
+    p.rows = (int)(p.transposed ? n : m);
+    p.cols = (int)(p.transposed ? m : n);
+    p.m_pad = (int)round_up64(p.rows, 32);
+    p.n_pad = (int)round_up64(p.cols, PW);
+    p.nb = p.n_pad / PB;
+    p.npairs = p.nb / 2;
+    p.want_v = want_v ? 1 : 0;
+    p.R = p.m_pad + (p.want_v ? p.n_pad : 0);
+    // gram: aim for >= 1024 workgroups, >= 64 rows per workgroup
+    int64_t want = ceil_div64(1024, (int64_t)p.npairs * batch);
+    int64_t maxsplit = p.m_pad / 64 > 0 ? p.m_pad / 64 : 1;
+    int64_t ns = want < 1 ? 1 : (want > maxsplit ? maxsplit : want);
+    if (ns > 64) ns = 64;
+    p.rows_per_split = (int)round_up64(ceil_div64(p.m_pad, ns), 8);
+    p.nsplit = (int)ceil_div64(p.m_pad, p.rows_per_split);
+    // update: 128-row iterations; aim for >= 1024 workgroups but >= 2 iterations per workgroup when possible
+    int64_t wantc = ceil_div64(1024, (int64_t)p.npairs * batch);
+    int64_t iters_total = ceil_div64(p.R, 128);
+    int64_t nc = wantc < 1 ? 1 : (wantc > iters_total ? iters_total : wantc);
+    p.rows_per_wg = (int)(ceil_div64(iters_total, nc) * 128);
+    p.nchunks = (int)ceil_div64(p.R, p.rows_per_wg);
+    p.panel_stride = (int64_t)p.R * PB;
+    p.batch_stride = p.panel_stride * p.nb;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    p.off_x = take((size_t)p.batch_stride * batch * sizeof(float));
+    p.off_gpart = take((size_t)batch * p.npairs * p.nsplit * 3072 * sizeof(float));
+    p.off_q = take((size_t)batch * p.npairs * PW * PW * sizeof(float));
+    p.off_active = take((size_t)batch * p.npairs * sizeof(int));
+    p.off_sig = take((size_t)batch * p.n_pad * sizeof(float));
+    p.off_ina = take((size_t)batch * p.n_pad * sizeof(float));
+    p.off_inv = take((size_t)batch * p.n_pad * sizeof(float));
+    p.off_perm = take((size_t)batch * p.n_pad * sizeof(int));
+    p.off_flags = take((size_t)batch * 4 * sizeof(int));  // [maxoff bits | nrot | done | pad] x batch (SoA)
+    p.total = off;
+    return ASVD_OK;
+}
+
+// ---- optional per-class timing with HIP events on the call's stream ------------------------------
+bool g_prof_enabled = false;
+float g_prof_ms[5] = {0, 0, 0, 0, 0};
+int g_prof_launches[5] = {0, 0, 0, 0, 0};
+struct ProfRec { int cls; hipEvent_t a, b; };
+std::vector<ProfRec> g_prof_recs;
+
+struct ProfScope {
+    int cls; hipStream_t st; hipEvent_t a = nullptr, b = nullptr; bool on;
+    ProfScope(int c, hipStream_t s) : cls(c), st(s), on(g_prof_enabled) {
+        if (on) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, st); }
+    }
+    ~ProfScope() {
+        if (on) { (void)hipEventRecord(b, st); g_prof_recs.push_back({cls, a, b}); }
+    }
+};
+void prof_begin() {
+    for (int i = 0; i < 5; ++i) { g_prof_ms[i] = 0; g_prof_launches[i] = 0; }
+    g_prof_recs.clear();
+}
+void prof_end() {
+    for (auto& r : g_prof_recs) {
+        float ms = 0;
+        (void)hipEventSynchronize(r.b);
+        (void)hipEventElapsedTime(&ms, r.a, r.b);
+        g_prof_ms[r.cls] += ms;
+        g_prof_launches[r.cls] += 1;
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    g_prof_recs.clear();
+}
+
+template <int DT>
+int launch_pack(const void* src, int64_t ld, const void* s, int cs_dtype, const Plan& p, float* Xb, hipStream_t st) {
+    dim3 grid((unsigned)ceil_div64(p.rows, 32), (unsigned)ceil_div64(p.cols, 256));
+    const int has = s ? 1 : 0;
+    switch (cs_dtype) {
+        case ASVD_F32: pack_kernel<DT, ASVD_F32><<<grid, 256, 0, st>>>(src, ld, s, has, p.transposed, p.rows, p.cols, p.R, Xb); break;
+        case ASVD_F16: pack_kernel<DT, ASVD_F16><<<grid, 256, 0, st>>>(src, ld, s, has, p.transposed, p.rows, p.cols, p.R, Xb); break;
+        case ASVD_BF16: pack_kernel<DT, ASVD_BF16><<<grid, 256, 0, st>>>(src, ld, s, has, p.transposed, p.rows, p.cols, p.R, Xb); break;
+        default: return ASVD_E_BADARG;
+    }
+    return ASVD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void asvd_svd_set_profiling(int enabled) { g_prof_enabled = enabled != 0; }
+int asvd_svd_get_profile(float* ms_host, int* launches_host) {
+    if (!ms_host || !launches_host) return ASVD_E_BADARG;
+    for (int i = 0; i < 5; ++i) { ms_host[i] = g_prof_ms[i]; launches_host[i] = g_prof_launches[i]; }
+    return ASVD_OK;
+}
+
+int asvd_svd_worksize(int batch, int64_t m, int64_t n, int want_vectors, size_t* bytes) {
+    if (!bytes) return ASVD_E_BADARG;
+    Plan p;
+    int rc = make_plan(batch, m, n, want_vectors, p);
+    if (rc) return rc;
+    *bytes = p.total;
+    return ASVD_OK;
+}
+
+int asvd_svd_batched(int batch, const void* const* a_host, int a_dtype, int64_t m, int64_t n, int64_t lda,
+                     const void* const* cs_host, int cs_dtype, float* const* U_host, float* const* S_host,
+                     float* const* V_host, int64_t k, int max_sweeps, float tol, void* work, size_t work_bytes,
+                     int* info_host, void* stream) {
+    if (!a_host || !S_host || !work || !dtype_ok(a_dtype) || lda < n) return ASVD_E_BADARG;
+    if (cs_host && !dtype_ok(cs_dtype)) return ASVD_E_BADARG;
+    const int want_v = (U_host != nullptr || V_host != nullptr) ? 1 : 0;
+    Plan p;
+    int rc = make_plan(batch, m, n, want_v, p);
+    if (rc) return rc;
+    if (k < 1 || k > p.cols) return ASVD_E_BADARG;
+    if (work_bytes < p.total) return ASVD_E_WORKSPACE;
+    for (int b = 0; b < batch; ++b)
+        if (!a_host[b] || !S_host[b]) return ASVD_E_BADARG;
+    if (max_sweeps <= 0) max_sweeps = 16;
+    if (!(tol > 0.0f)) tol = 1e-6f;
+    hipStream_t st = (hipStream_t)stream;
+
+    char* wb = (char*)work;
+    float* X = (float*)(wb + p.off_x);
+    float* Gpart = (float*)(wb + p.off_gpart);
+    float* Qbuf = (float*)(wb + p.off_q);
+    int* active = (int*)(wb + p.off_active);
+    float* sig = (float*)(wb + p.off_sig);
+    float* ina = (float*)(wb + p.off_ina);
+    float* inv = (float*)(wb + p.off_inv);
+    int* perm = (int*)(wb + p.off_perm);
+    unsigned* maxoff = (unsigned*)(wb + p.off_flags);
+    int* nrot = (int*)(wb + p.off_flags) + batch;
+    int* done = (int*)(wb + p.off_flags) + 2 * batch;
+
+    if (g_prof_enabled) prof_begin();
+
+    // ---- pack ----
+    {
+        ProfScope ps(0, st);
+        ASVD_HIP_CHECK(hipMemsetAsync(X, 0, (size_t)p.batch_stride * batch * sizeof(float), st));
+        ASVD_HIP_CHECK(hipMemsetAsync(wb + p.off_flags, 0, (size_t)batch * 4 * sizeof(int), st));
+        for (int b = 0; b < batch; ++b) {
+            float* Xb = X + (int64_t)b * p.batch_stride;
+            const void* s = cs_host ? cs_host[b] : nullptr;
+            int prc;
+            switch (a_dtype) {
+                case ASVD_F32: prc = launch_pack<ASVD_F32>(a_host[b], lda, s, cs_dtype, p, Xb, st); break;
+                case ASVD_F16: prc = launch_pack<ASVD_F16>(a_host[b], lda, s, cs_dtype, p, Xb, st); break;
+                default: prc = launch_pack<ASVD_BF16>(a_host[b], lda, s, cs_dtype, p, Xb, st); break;
+            }
+            if (prc) return prc;
+            if (p.want_v) vinit_kernel<<<(unsigned)ceil_div64(p.cols, 256), 256, 0, st>>>(Xb, p.cols, p.R, p.m_pad);
+        }
+    }
+
+    // ---- sweeps ----
+    std::vector<int> flags((size_t)batch * 4, 0);
+    std::vector<int> sweeps_done(batch, 0), last_rot(batch, 0), status(batch, ASVD_N_NOCONV);
+    std::vector<int> host_done(batch, 0);
+    const int nsteps = p.nb - 1;
+    const int inner_sweeps = 2;
+    int sweep = 0;
+    for (; sweep < max_sweeps; ++sweep) {
+        ASVD_HIP_CHECK(hipMemsetAsync(wb + p.off_flags, 0, (size_t)batch * 2 * sizeof(int), st));  // maxoff, nrot
+        for (int step = 0; step < nsteps; ++step) {
+            {
+                ProfScope ps(1, st);
+                gram_kernel<<<dim3(p.nsplit, p.npairs, batch), 256, 0, st>>>(X, p.panel_stride, p.batch_stride, p.nb, step,
+                                                                             p.m_pad, p.rows_per_split, Gpart, done);
+            }
+            {
+                ProfScope ps(2, st);
+                evd_kernel<<<dim3(p.npairs, batch), 1024, 0, st>>>(Gpart, p.nsplit, Qbuf, active, maxoff, nrot, done, tol,
+                                                                   inner_sweeps);
+            }
+            {
+                ProfScope ps(3, st);
+                update_kernel<<<dim3(p.nchunks, p.npairs, batch), 256, 0, st>>>(X, p.panel_stride, p.batch_stride, p.nb, step,
+                                                                                p.R, p.rows_per_wg, Qbuf, active, done);
+            }
+        }
+        ASVD_HIP_CHECK(hipMemcpyAsync(flags.data(), wb + p.off_flags, (size_t)batch * 4 * sizeof(int), hipMemcpyDeviceToHost, st));
+        ASVD_HIP_CHECK(hipStreamSynchronize(st));
+        bool all_done = true;
+        bool changed = false;
+        for (int b = 0; b < batch; ++b) {
+            if (host_done[b]) continue;
+            float mo;
+            unsigned bits = (unsigned)flags[b];
+            std::memcpy(&mo, &bits, sizeof(float));
+            sweeps_done[b] = sweep + 1;
+            last_rot[b] = flags[batch + b];
+            if (mo != mo) { status[b] = ASVD_N_NAN; host_done[b] = 1; changed = true; }
+            else if (mo < tol) { status[b] = ASVD_OK; host_done[b] = 1; changed = true; }
+            else all_done = false;
+        }
+        if (all_done) { ++sweep; break; }
+        if (changed) {
+            ASVD_HIP_CHECK(hipMemcpyAsync(done, host_done.data(), (size_t)batch * sizeof(int), hipMemcpyHostToDevice, st));
+            ASVD_HIP_CHECK(hipStreamSynchronize(st));  // host_done may be modified next sweep
+        }
+    }
+
+    // ---- finalize ----
+    {
+        ProfScope ps(4, st);
+        colnorm_kernel<<<dim3(p.nb, batch), 256, 0, st>>>(X, p.panel_stride, p.batch_stride, p.m_pad, p.R, p.n_pad, sig, ina, inv);
+        rank_kernel<<<dim3((unsigned)ceil_div64(p.n_pad, 256), batch), 256, 0, st>>>(sig, p.n_pad, perm);
+        for (int b = 0; b < batch; ++b) {
+            float* Uo = U_host ? U_host[b] : nullptr;
+            float* Vo = V_host ? V_host[b] : nullptr;
+            // oriented left vectors (A part) are U of A when not transposed, V of A when transposed
+            float* outA = p.transposed ? Vo : Uo;
+            float* outV = p.transposed ? Uo : Vo;
+            const int rowsA = p.rows;
+            const int rowsV = p.want_v ? p.cols : 0;
+            dim3 grid((unsigned)ceil_div64(k, 64), (unsigned)ceil_div64(rowsA + rowsV > 0 ? rowsA + rowsV : 1, 64));
+            gather_kernel<<<grid, 256, 0, st>>>(X + (int64_t)b * p.batch_stride, p.panel_stride, p.m_pad, p.R,
+                                                sig + (int64_t)b * p.n_pad, ina + (int64_t)b * p.n_pad,
+                                                inv + (int64_t)b * p.n_pad, perm + (int64_t)b * p.n_pad, rowsA, rowsV,
+                                                (int)k, outA, outV, S_host[b]);
+        }
+    }
+    ASVD_HIP_CHECK(hipStreamSynchronize(st));
+    ASVD_HIP_CHECK(hipGetLastError());
+    if (g_prof_enabled) prof_end();
+
+    int worst = ASVD_OK;
+    for (int b = 0; b < batch; ++b) {
+        if (info_host) {
+            info_host[4 * b + 0] = status[b];
+            info_host[4 * b + 1] = sweeps_done[b];
+            info_host[4 * b + 2] = last_rot[b];
+            info_host[4 * b + 3] = 0;
+        }
+        if (status[b] > worst) worst = status[b];
+    }
+    return worst;
+}
+
+int asvd_svd(const void* a, int a_dtype, int64_t m, int64_t n, int64_t lda, const void* col_scale, int cs_dtype, float* U,
+             float* S, float* V, int64_t k, int max_sweeps, float tol, void* work, size_t work_bytes, int* info_host,
+             void* stream) {
+    const void* ap[1] = {a};
+    const void* cp[1] = {col_scale};
+    float* up[1] = {U};
+    float* sp[1] = {S};
+    float* vp[1] = {V};
+    return asvd_svd_batched(1, ap, a_dtype, m, n, lda, col_scale ? cp : nullptr, cs_dtype, (U ? up : nullptr), sp,
+                            (V ? vp : nullptr), k, max_sweeps, tol, work, work_bytes, info_host, stream);
+}
+
+}  // extern "C"

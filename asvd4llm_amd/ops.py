@@ -1,0 +1,195 @@
+"""torch-tensor front end of the C ABI (include/asvd_hip.h).  torch is used for device memory and streams only —
+every arithmetic step below runs in libasvd_hip.so.  Tensors must live on a gfx950 device; nothing falls back to CPU."""
+import ctypes
+
+import torch
+
+from . import _lib as L
+
+_DT = {torch.float32: L.F32, torch.float16: L.F16, torch.bfloat16: L.BF16}
+
+
+def _dt(t):
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def _dev(t, name):
+    if not t.is_cuda:
+        raise L.AsvdHipError(f"{name} must be a device tensor (got {t.device}); the ASVD hot path has no CPU fallback")
+    return t
+
+
+def _stream(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _work(nbytes, device):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def absstat_accum(x2d, acc, method):
+    """acc (in place) <- hook update with |x| column statistic over rows of x2d [rows, cols] (act_aware_utils.py:64-74)"""
+    lib = L.load(True)
+    _dev(x2d, "x"), _dev(acc, "acc")
+    assert x2d.dim() == 2 and x2d.stride(1) == 1 and acc.is_contiguous() and acc.numel() == x2d.shape[1]
+    rows, cols = x2d.shape
+    mode = L.STAT_ABS_MEAN if "abs_mean" in method else L.STAT_ABS_MAX
+    nb = ctypes.c_size_t()
+    L.check(lib.asvd_absstat_worksize(rows, cols, ctypes.byref(nb)), "asvd_absstat_worksize")
+    work = _work(nb.value, x2d.device)
+    with torch.cuda.device(x2d.device):
+        L.check(lib.asvd_absstat_accum(_ptr(x2d), _dt(x2d), rows, cols, x2d.stride(0), _ptr(acc), _dt(acc), mode, _ptr(work),
+                                       work.numel(), _stream(x2d)), "asvd_absstat_accum")
+    return acc
+
+
+def make_scale(scaling, fisher=None, alpha=1.0, eps=1e-6):
+    """s = scaling**alpha [* fisher**alpha] + eps in the dtype of `scaling` (svd_linear.py:48-59)"""
+    lib = L.load(True)
+    _dev(scaling, "scaling")
+    scaling = scaling.contiguous()
+    if fisher is not None:
+        fisher = fisher.to(scaling.dtype).contiguous()
+    out = torch.empty_like(scaling)
+    with torch.cuda.device(scaling.device):
+        L.check(lib.asvd_make_scale(_ptr(scaling), _ptr(fisher), _dt(scaling), scaling.numel(), float(alpha), float(eps), _ptr(out),
+                                    _stream(scaling)), "asvd_make_scale")
+    return out
+
+
+def scale_cols(w, s=None):
+    """fp32 w * s[None, :] (svd_linear.py:47,60)"""
+    lib = L.load(True)
+    _dev(w, "w")
+    assert w.dim() == 2 and w.stride(1) == 1
+    m, n = w.shape
+    out = torch.empty((m, n), dtype=torch.float32, device=w.device)
+    with torch.cuda.device(w.device):
+        L.check(lib.asvd_scale_cols(_ptr(w), _dt(w), m, n, w.stride(0), _ptr(s), _dt(s) if s is not None else 0, _ptr(out), n,
+                                    _stream(w)), "asvd_scale_cols")
+    return out
+
+
+class SvdInfo:
+    def __init__(self, status, sweeps, last_rot):
+        self.status, self.sweeps, self.last_rotated_pairs = status, sweeps, last_rot
+
+    def __repr__(self):
+        return f"SvdInfo(status={self.status}, sweeps={self.sweeps}, last_rotated_pairs={self.last_rotated_pairs})"
+
+
+def svd_batched(mats, col_scales=None, k=None, want_vectors=True, max_sweeps=0, tol=0.0):
+    """Economy SVD of a list of same-shape device matrices: mats[b] * diag(col_scales[b]) = U S V^T.
+    Returns (U list [m,k], S list [k], V list [n,k], infos).  U/V lists are None when want_vectors is False."""
+    lib = L.load(True)
+    B = len(mats)
+    assert B >= 1
+    m, n = mats[0].shape
+    dev = mats[0].device
+    for a in mats:
+        _dev(a, "matrix")
+        assert a.shape == (m, n) and a.dtype == mats[0].dtype and a.stride(1) == 1 and a.stride(0) == mats[0].stride(0)
+    kmax = min(m, n)
+    k = kmax if k is None else int(k)
+    assert 1 <= k <= kmax
+    nb = ctypes.c_size_t()
+    L.check(lib.asvd_svd_worksize(B, m, n, 1 if want_vectors else 0, ctypes.byref(nb)), "asvd_svd_worksize")
+    work = _work(nb.value, dev)
+    S = [torch.empty(k, dtype=torch.float32, device=dev) for _ in range(B)]
+    U = [torch.empty((m, k), dtype=torch.float32, device=dev) for _ in range(B)] if want_vectors else None
+    V = [torch.empty((n, k), dtype=torch.float32, device=dev) for _ in range(B)] if want_vectors else None
+    arr = ctypes.c_void_p * B
+    a_p = arr(*[a.data_ptr() for a in mats])
+    s_p = arr(*[s.data_ptr() for s in S])
+    u_p = arr(*[u.data_ptr() for u in U]) if want_vectors else None
+    v_p = arr(*[v.data_ptr() for v in V]) if want_vectors else None
+    if col_scales is not None:
+        for s in col_scales:
+            _dev(s, "col_scale")
+            assert s.numel() == n and s.is_contiguous() and s.dtype == col_scales[0].dtype
+        c_p = arr(*[s.data_ptr() for s in col_scales])
+        cdt = _dt(col_scales[0])
+    else:
+        c_p, cdt = None, 0
+    info = (ctypes.c_int * (4 * B))()
+    with torch.cuda.device(dev):
+        rc = lib.asvd_svd_batched(B, a_p, _dt(mats[0]), m, n, mats[0].stride(0), c_p, cdt, u_p, s_p, v_p, k, int(max_sweeps),
+                                  float(tol), _ptr(work), work.numel(), info, _stream(mats[0]))
+    L.check(rc, "asvd_svd_batched")
+    infos = [SvdInfo(info[4 * b], info[4 * b + 1], info[4 * b + 2]) for b in range(B)]
+    return U, S, V, infos
+
+
+def svd(a, col_scale=None, k=None, want_vectors=True, max_sweeps=0, tol=0.0):
+    U, S, V, infos = svd_batched([a], None if col_scale is None else [col_scale], k, want_vectors, max_sweeps, tol)
+    if want_vectors:
+        return U[0], S[0], V[0], infos[0]
+    return None, S[0], None, infos[0]
+
+
+def truncate_split(U, S, V, s, r, sigma_fuse, out_dtype):
+    """(A [m,r], B [r,n], nan_flags[3]) per SVDLinear.__init__ + un-scaling (svd_linear.py:69-70,16-24,102)"""
+    lib = L.load(True)
+    _dev(U, "U")
+    m, n = U.shape[0], V.shape[0]
+    assert U.stride(1) == 1 and V.stride(1) == 1 and U.shape[1] >= r and V.shape[1] >= r and S.numel() >= r
+    A = torch.empty((m, r), dtype=out_dtype, device=U.device)
+    Bm = torch.empty((r, n), dtype=out_dtype, device=U.device)
+    flags = torch.zeros(3, dtype=torch.int32, device=U.device)
+    with torch.cuda.device(U.device):
+        L.check(lib.asvd_truncate_split(_ptr(U), U.stride(0), _ptr(S), _ptr(V), V.stride(0), _ptr(s), _dt(s) if s is not None else 0,
+                                        m, n, r, L.FUSE[sigma_fuse], _ptr(A), _ptr(Bm), _DT[out_dtype], _ptr(flags), _stream(U)),
+                "asvd_truncate_split")
+    return A, Bm, flags
+
+
+def fro_norm_sq(w):
+    lib = L.load(True)
+    _dev(w, "w")
+    assert w.dim() == 2 and w.stride(1) == 1
+    m, n = w.shape
+    nb = ctypes.c_size_t()
+    L.check(lib.asvd_fro_worksize(m, n, ctypes.byref(nb)), "asvd_fro_worksize")
+    work = _work(nb.value, w.device)
+    out = torch.empty(1, dtype=torch.float32, device=w.device)
+    with torch.cuda.device(w.device):
+        L.check(lib.asvd_fro_norm_sq(_ptr(w), _dt(w), m, n, w.stride(0), _ptr(out), _ptr(work), work.numel(), _stream(w)),
+                "asvd_fro_norm_sq")
+    return out
+
+
+def reconstruct_err(W, A, B):
+    """(|W - A B|_F^2, |W|_F^2) as a device double[2] tensor"""
+    lib = L.load(True)
+    _dev(W, "W")
+    m, n = W.shape
+    r = A.shape[1]
+    assert A.shape == (m, r) and B.shape == (r, n) and A.is_contiguous() and B.is_contiguous() and A.dtype == B.dtype
+    nb = ctypes.c_size_t()
+    L.check(lib.asvd_reconstruct_worksize(m, n, ctypes.byref(nb)), "asvd_reconstruct_worksize")
+    work = _work(nb.value, W.device)
+    out = torch.empty(2, dtype=torch.float64, device=W.device)
+    with torch.cuda.device(W.device):
+        L.check(lib.asvd_reconstruct_err(_ptr(W), _dt(W), W.stride(0), _ptr(A), _ptr(B), _dt(A), m, n, r, _ptr(out), _ptr(work),
+                                         work.numel(), _stream(W)), "asvd_reconstruct_err")
+    return out
+
+
+def svd_profile(enable=None):
+    """enable/disable HIP-event timing of the SVD kernel classes, or read the last call's totals"""
+    lib = L.load(False)
+    if enable is not None:
+        lib.asvd_svd_set_profiling(1 if enable else 0)
+        return None
+    ms = (ctypes.c_float * 5)()
+    n = (ctypes.c_int * 5)()
+    lib.asvd_svd_get_profile(ms, n)
+    names = ["pack", "gram", "evd", "update", "finalize"]
+    return {names[i]: {"ms": ms[i], "launches": n[i]} for i in range(5)}

@@ -1,0 +1,163 @@
+/*
+ * asvd_hip.h — C ABI of libasvd_hip.so: the MI355X (gfx950) kernels behind the activation-aware SVD
+ * compression path of ASVD4LLM.
+ *
+ * The reference (hahnyuan/ASVD4LLM) is pure Python and has no FFI layer; its arithmetic for this path
+ * lives in eager torch ops.  Every entry point below replaces one group of those torch ops; the
+ * reference lines are cited per function (paths relative to the reference tree).  A maintainer of the
+ * reference binds these with ctypes from inside the same Python functions.
+ *
+ * Conventions
+ *   - plain pointers + sizes; no torch types.  All data pointers are DEVICE pointers unless the name
+ *     ends in `_host`.  The caller owns every buffer; the library never frees or retains them.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Kernels are enqueued on it.
+ *     Functions documented "host-synchronous" call hipStreamSynchronize(stream) internally because
+ *     they return host scalars (sweep counts / NaN flags) or steer iteration on device results.
+ *   - return value: 0 = OK; negative = bad argument / runtime error (ASVD_E_*); positive = numerical
+ *     condition (ASVD_N_*).  asvd_status_string() gives text.
+ *   - matrices are row-major; `ld*` are leading dimensions in ELEMENTS.
+ */
+#ifndef ASVD_HIP_H
+#define ASVD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* element types */
+#define ASVD_F32 0
+#define ASVD_F16 1
+#define ASVD_BF16 2
+
+/* status codes */
+#define ASVD_OK 0
+#define ASVD_E_BADARG (-1)
+#define ASVD_E_WORKSPACE (-2)   /* workspace too small */
+#define ASVD_E_HIP (-3)         /* a HIP runtime call failed */
+#define ASVD_E_NODEVICE (-4)    /* no gfx950 device visible */
+#define ASVD_N_NOCONV 1         /* Jacobi did not reach tol within max_sweeps (results still usable) */
+#define ASVD_N_NAN 2            /* NaN/Inf seen in outputs */
+
+/* sigma_fuse modes of SVDLinear.__init__ (modules/svd_linear.py:16-24) */
+#define ASVD_FUSE_UV 0
+#define ASVD_FUSE_U 1
+#define ASVD_FUSE_V 2
+
+/* activation-statistic modes of the calibration hook (act_aware_utils.py:64-74) */
+#define ASVD_STAT_ABS_MEAN 0
+#define ASVD_STAT_ABS_MAX 1
+
+int asvd_version(void);
+const char* asvd_status_string(int status);
+/* number of visible HIP devices with arch gfx950; <=0 means the library cannot run */
+int asvd_device_count(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * K1/K2  calibration hook accumulator.
+ * Replaces act_aware_utils.py:66-67 (abs_mean: `input[0].abs().mean(dim=-2).view(-1)`; `acc += ...`)
+ * and :69-74 (abs_max: `.abs().amax(dim=-2)`; `torch.where(abs_max > acc, abs_max, acc)`).
+ *   x   [rows, cols] row-major with leading dimension ld (the [1,T,C] / [T,C] hook input flattened)
+ *   acc [cols] in acc_dtype (the reference keeps the activation dtype); caller zero-initialises it,
+ *       which reproduces the reference's python-int 0 start exactly (0 + x == x; max(x,0) == x).
+ * abs_mean: column sums accumulate in fp32, are divided by rows, rounded to acc_dtype, then added to
+ *           acc in acc_dtype arithmetic (one rounding), i.e. the reference's two-op sequence.
+ * abs_max : NaN in x never replaces acc (torch.where(nan > acc) is false).
+ * work: asvd_absstat_worksize bytes (fp32 partial sums). Asynchronous on `stream`.
+ */
+int asvd_absstat_worksize(int64_t rows, int64_t cols, size_t* bytes);
+int asvd_absstat_accum(const void* x, int x_dtype, int64_t rows, int64_t cols, int64_t ld,
+                       void* acc, int acc_dtype, int mode, void* work, size_t work_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K3a  scale vector.  Replaces svd_linear.py:48-59:
+ *   s = 1 * scaling_diag_matrix**alpha [* fisher_info**alpha]; s += 1e-6
+ * evaluated in the dtype of the statistics (fp16 for an fp16 model: pow, product and +eps each round
+ * to that dtype, as torch does).  fisher may be NULL.  out has the same dtype.  Asynchronous.
+ */
+int asvd_make_scale(const void* scaling, const void* fisher, int dtype, int64_t n, float alpha, float eps,
+                    void* out, void* stream);
+
+/* K3b  w_scaled[i][j] = float(w[i][j]) * float(s[j]).  Replaces svd_linear.py:47,60
+ * (`w = linear.weight.data.float(); w = w * scaling_diag_matrix.view(1,-1)`).  s may be NULL (plain
+ * upcast).  Stand-alone form used by parity tests; asvd_svd fuses the same arithmetic into its pack
+ * kernel.  Asynchronous. */
+int asvd_scale_cols(const void* w, int w_dtype, int64_t m, int64_t n, int64_t ldw,
+                    const void* s, int s_dtype, float* out, int64_t ldo, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K4  economy SVD in fp32:   A * diag(col_scale) = U diag(S) V^T .
+ * Replaces the factorisation call at svd_linear.py:65 (`torch.svd_lowrank(w, q=rank)`; the parity
+ * oracle named by BASELINE.json is the exact `torch.linalg.svd(w, full_matrices=False)`), and, with
+ * U = V = NULL, the values-only `torch.svd(w.float(), compute_uv=False)` at sensitivity.py:101.
+ *
+ * Algorithm: one-sided block Jacobi (Hestenes) on 32-column panels.  Per round-robin step and panel
+ * pair: 64x64 Gram matrix by fp32 MFMA, 64x64 symmetric eigen-solve by two-sided Jacobi in LDS,
+ * panel <- panel * Q by fp32 MFMA; V is accumulated by the same update; sigma_j = |a_j| / |v_j|.
+ *
+ *   batch       number of same-shape problems solved concurrently (fills the 256 CUs)
+ *   a_host      host array [batch] of device pointers to A_b  [m, n] row-major, leading dim lda
+ *   cs_host     host array [batch] of device pointers to column scales s_b [n] (or NULL / NULL entries)
+ *   U_host      host array [batch] of device pointers to U_b [m, k] row-major (NULL: no vectors)
+ *   S_host      host array [batch] of device pointers to S_b [k] descending
+ *   V_host      host array [batch] of device pointers to V_b [n, k] row-major (NULL: no vectors)
+ *   k           number of leading singular triplets to write, 1 <= k <= min(m, n)
+ *   max_sweeps  <=0: default (16);  tol <=0: default (1e-6) on max |cos(a_i, a_j)|
+ *   info_host   optional host int[4*batch]: {status, sweeps, rotated pairs in last sweep, reserved}
+ * Host-synchronous (one stream sync per sweep).  Returns worst status over the batch.
+ */
+int asvd_svd_worksize(int batch, int64_t m, int64_t n, int want_vectors, size_t* bytes);
+int asvd_svd_batched(int batch, const void* const* a_host, int a_dtype, int64_t m, int64_t n, int64_t lda,
+                     const void* const* cs_host, int cs_dtype,
+                     float* const* U_host, float* const* S_host, float* const* V_host, int64_t k,
+                     int max_sweeps, float tol, void* work, size_t work_bytes, int* info_host, void* stream);
+/* single-problem convenience wrapper (batch = 1) */
+int asvd_svd(const void* a, int a_dtype, int64_t m, int64_t n, int64_t lda, const void* col_scale, int cs_dtype,
+             float* U, float* S, float* V, int64_t k, int max_sweeps, float tol,
+             void* work, size_t work_bytes, int* info_host, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K5/K6  truncate to rank r, un-scale V, fuse sigma, transpose V, down-cast, NaN flag.
+ * Replaces svd_linear.py:69-70 (`V = V / s.view(-1,1)`), :81-98 (NaN checks) and SVDLinear.__init__
+ * :16-24 + the `.to(dtype)` at :102:
+ *   UV: A = U[:, :r] * sqrt(S[:r])           B = (V[:, :r] / s[:,None]).T * sqrt(S[:r])[:,None]
+ *   U : A = U[:, :r] * S[:r]                 B = (V[:, :r] / s[:,None]).T
+ *   V : A = U[:, :r]                         B = (V[:, :r] / s[:,None]).T * S[:r][:,None]
+ * all in fp32, then rounded once (RNE) to out_dtype.
+ *   U [m, ldu>=r], S [>=r], V [n, ldv>=r] fp32;  s [n] in s_dtype or NULL;
+ *   A [m, r] (ALinear.weight), B [r, n] (BLinear.weight) contiguous in out_dtype;
+ *   nan_flags: device int[3] OR-ed with 1 where S / U / V hold a NaN within the first r columns
+ *              (caller zero-initialises; NULL to skip).  Asynchronous.
+ */
+int asvd_truncate_split(const float* U, int64_t ldu, const float* S, const float* V, int64_t ldv,
+                        const void* s, int s_dtype, int64_t m, int64_t n, int64_t r, int sigma_fuse,
+                        void* A, void* B, int out_dtype, int* nan_flags, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K8  squared Frobenius norm (sensitivity.py:100 `torch.norm(w, p="fro") ** 2`), fp32 accumulate in
+ * fixed order, result written to *out (device float).  work: asvd_fro_worksize bytes.  Asynchronous. */
+int asvd_fro_worksize(int64_t m, int64_t n, size_t* bytes);
+int asvd_fro_norm_sq(const void* w, int w_dtype, int64_t m, int64_t n, int64_t ldw, float* out,
+                     void* work, size_t work_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K9  parity evidence (new; no reference counterpart):  err2 = |W - A*B|_F^2 , w2 = |W|_F^2
+ *   W [m, n] in w_dtype (ldw), A [m, r], B [r, n] contiguous in ab_dtype (F16/BF16/F32).
+ *   out: device double[2] = {err2, w2}.  work: asvd_reconstruct_worksize bytes.  Asynchronous. */
+int asvd_reconstruct_worksize(int64_t m, int64_t n, size_t* bytes);
+int asvd_reconstruct_err(const void* W, int w_dtype, int64_t ldw, const void* A, const void* B, int ab_dtype,
+                         int64_t m, int64_t n, int64_t r, double* out, void* work, size_t work_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Instrumentation: per-kernel-class wall time of the last asvd_svd_batched call, measured with HIP
+ * events on the call's stream when enabled.  classes: 0 pack, 1 gram, 2 evd, 3 update, 4 finalize.
+ * ms_host: float[5] total milliseconds; launches_host: int[5].  */
+void asvd_svd_set_profiling(int enabled);
+int asvd_svd_get_profile(float* ms_host, int* launches_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ASVD_HIP_H */
