@@ -1,0 +1,74 @@
+"""Calibration statistics — MI355X implementation of act_aware_utils.py:47-95 behind the same signature.
+
+`calib_input_distribution(model, calib_loader, method, use_cache=True)` attaches `module.scaling_diag_matrix` ([C_in], in the
+activation dtype, SUM over calibration batches of the per-batch |x| column mean / running max) to every nn.Linear and
+writes the same cache file (`cache/{model_id with '/'->'_'}_calib_input_distribution_{method}.pt`, dict name -> tensor).
+The hook body is one call into libasvd_hip.so (asvd_absstat_accum): a single pass over the [T, C] activation with 16-byte
+coalesced loads and fp32 partial sums, instead of the reference's abs -> mean -> add chain with a [T, C] temporary."""
+import os
+
+import torch
+import torch.nn as nn
+from tqdm import tqdm
+
+from . import ops
+
+
+def _hook_factory(method):
+    def hook(module, input, output):
+        x = input[0].detach()
+        if x.dim() >= 2:
+            lead = 1
+            for d in x.shape[:-2]:
+                lead *= d
+            if lead != 1:
+                # the reference's `.view(-1)` would yield B*C elements and break the add: batch must be 1
+                raise ValueError(f"calibration hook needs batch size 1, got input of shape {tuple(x.shape)}")
+        x2 = x.reshape(-1, x.shape[-1])
+        if x2.stride(1) != 1:
+            x2 = x2.contiguous()
+        acc = module.scaling_diag_matrix
+        if not torch.is_tensor(acc):  # python int 0 start (act_aware_utils.py:80)
+            acc = torch.zeros(x2.shape[1], dtype=x2.dtype, device=x2.device)
+            module.scaling_diag_matrix = acc
+        ops.absstat_accum(x2, acc, method)
+
+    return hook
+
+
+@torch.no_grad()
+def calib_input_distribution(model, calib_loader, method, use_cache=True):
+    model_id = model.config._name_or_path
+    cache_file = f"cache/{model_id.replace('/','_')}_calib_input_distribution_{method}.pt"
+    if os.path.exists(cache_file) and use_cache:
+        all_scaling_diag_matrix = torch.load(cache_file, map_location="cpu")
+        for name, module in model.named_modules():
+            if isinstance(module, nn.Linear):
+                module.scaling_diag_matrix = all_scaling_diag_matrix[name].to(module.weight.device)
+        return
+    model.eval()
+    if "abs_mean" not in method and "abs_max" not in method:
+        return  # the reference hook does nothing for other methods
+    hook = _hook_factory(method)
+    for name, module in model.named_modules():
+        if isinstance(module, nn.Linear):
+            module.scaling_diag_matrix = 0
+            module.register_forward_hook(hook)
+
+    for batch in tqdm(calib_loader):
+        batch = {k: v.to(model.device) for k, v in batch.items()}
+        model(**batch)
+
+    all_scaling_diag_matrix = {}
+    for name, module in model.named_modules():
+        if isinstance(module, nn.Linear):
+            module._forward_hooks.clear()  # the reference clears ALL forward hooks of every Linear (act_aware_utils.py:93)
+            all_scaling_diag_matrix[name] = module.scaling_diag_matrix
+    os.makedirs(os.path.dirname(cache_file), exist_ok=True)
+    torch.save(all_scaling_diag_matrix, cache_file)
+
+
+@torch.no_grad()
+def calib_fisher_info(model, calib_loader, use_cache=True):
+    """act_aware_utils.py:8-44 (--scaling_method fisher*): outside the hot-path scope of this build."""
+    raise NotImplementedError("fisher scaling is out of scope for the MI355X hot path build (SURVEY.md §8f row 4)")

@@ -1,0 +1,138 @@
+"""Sensitivity sweep — MI355X implementation of sensitivity.py:10-110 behind the same signatures.
+
+calib_sensitivity_ppl:  for every nn.Linear (reverse-DFS order, lm_head first) x candidate ratios, swap in the rank-r
+SVDLinear and measure calibration perplexity.  Differences from the reference that do not change results' meaning:
+  * the SVD of a layer is computed ONCE (exact, on device) and sliced for all 6 (19 in kv mode) ratios;
+  * with torch.distributed initialised, layers are LPT-sharded over ranks and the per-layer results are exchanged with one
+    all-gather (asvd4llm_amd/parallel.py); every rank returns the complete dict in the reference's insertion order.
+calib_sensitivity_stable_rank: forward-free metric -(|W|_F / sigma_max) * ratio**0.1 on the UNSCALED weight; sigma_max
+comes from the values-only mode of the same HIP SVD, |W|_F^2 from asvd_fro_norm_sq."""
+import os
+
+import torch
+import torch.nn as nn
+from tqdm import tqdm
+
+from . import ops, parallel
+from .evaluate_utils import evaluate_perplexity
+from .modules.svd_linear import SVDLinear
+
+
+def collect_linear_info(model):
+    """The reference's explicit stack walk (sensitivity.py:19-33 / binary_search.py:11-27): modules.pop() => reverse DFS."""
+    full_name_dict = {module: name for name, module in model.named_modules()}
+    linear_info = {}
+    modules = [model]
+    while len(modules) > 0:
+        submodule = modules.pop()
+        for name, raw_linear in submodule.named_children():
+            if isinstance(raw_linear, nn.Linear):
+                full_name = full_name_dict[raw_linear]
+                linear_info[raw_linear] = {"father": submodule, "name": name, "full_name": full_name}
+            else:
+                modules.append(raw_linear)
+    return linear_info
+
+
+def _ppl_candidates(args):
+    if args.compress_kv_cache:
+        return [0.1 * i for i in range(1, 20)]
+    return [0.4, 0.5, 0.6, 0.7, 0.8, 0.9]
+
+
+@torch.no_grad()
+def calib_sensitivity_ppl(model, calib_loader, args, use_cache=True):
+    model_id = model.config._name_or_path
+    cache_file = f"cache/{model_id.replace('/','_')}_sensitivity_{args.scaling_method}_{args.alpha}_{args.n_calib_samples}_{args.calib_dataset}.pt"
+    if os.path.exists(cache_file) and use_cache:
+        sensitivity_dict = torch.load(cache_file, map_location="cpu")
+        return sensitivity_dict
+    model.eval()
+    linear_info = collect_linear_info(model)
+    param_ratio_candidates = _ppl_candidates(args)
+    input_ids = torch.cat([_["input_ids"] for _ in calib_loader], 0)
+    print(f"input_ids.shape={input_ids.shape}")
+
+    rank, ws = parallel.world()
+    linears = list(linear_info.items())
+    names = [info["full_name"] for _, info in linears]
+    owner = parallel.lpt_assign([parallel.svd_flops(l.out_features, l.in_features) for l, _ in linears], ws)
+    keep_cache = getattr(args, "keep_svd_cache", True)
+
+    local = {}
+    n_mine = sum(1 for o in owner if o == rank)
+    pbar = tqdm(total=n_mine * len(param_ratio_candidates), disable=(rank != 0))
+    for (raw_linear, info), own in zip(linears, owner):
+        if own != rank:
+            continue
+        local[info["full_name"]] = {}
+        for param_ratio in param_ratio_candidates:
+            svd_linear = SVDLinear.from_linear(
+                raw_linear,
+                param_ratio=param_ratio,
+                alpha=args.alpha,
+                act_aware=True,  # hard-coded in the reference sweep (sensitivity.py:50)
+                rank_align=args.rank_align,
+            )
+            setattr(info["father"], info["name"], svd_linear)
+            ppl = evaluate_perplexity(model, input_ids, args.n_calib_samples)
+            local[info["full_name"]][param_ratio] = ppl
+            print(f"{info['full_name']} {param_ratio} {ppl}")
+            pbar.update(1)
+        setattr(info["father"], info["name"], raw_linear)
+        if not keep_cache:
+            SVDLinear.drop_factor_cache(raw_linear)
+    sensitivity_dict = parallel.allgather_sensitivities(local, names, param_ratio_candidates, owner)
+    if rank == 0:
+        os.makedirs("cache", exist_ok=True)
+        torch.save(sensitivity_dict, cache_file)
+    return sensitivity_dict
+
+
+@torch.no_grad()
+def calib_sensitivity_stable_rank(model, calib_loader, args, use_cache=True):
+    model_id = model.config._name_or_path
+    cache_file = f"cache/{model_id.replace('/','_')}_sensitivity_stable_rank_{args.scaling_method}_{args.alpha}_{args.n_calib_samples}_{args.calib_dataset}.pt"
+    if os.path.exists(cache_file) and use_cache:
+        sensitivity_dict = torch.load(cache_file, map_location="cpu")
+        return sensitivity_dict
+    model.eval()
+    linear_info = collect_linear_info(model)
+    param_ratio_candidates = [0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.9]
+    input_ids = torch.cat([_["input_ids"] for _ in calib_loader], 0)
+    print(f"input_ids.shape={input_ids.shape}")
+
+    rank, ws = parallel.world()
+    linears = list(linear_info.items())
+    names = [info["full_name"] for _, info in linears]
+    owner = parallel.lpt_assign([parallel.svd_flops(l.out_features, l.in_features) for l, _ in linears], ws)
+    local = {}
+    pbar = tqdm(total=len(linears) * len(param_ratio_candidates), disable=(rank != 0))
+    for (raw_linear, info), own in zip(linears, owner):
+        if own != rank:
+            continue
+        # stable rank = |W|_F / sigma_max on the unscaled weight (sensitivity.py:96-104; scaling commented out there).
+        w = raw_linear.weight.data
+        wc = w if w.stride(1) == 1 else w.contiguous()
+        sumsq = ops.fro_norm_sq(wc)  # fp32 sum of squares
+        # torch.norm(w, "fro") ** 2 is evaluated in the weight dtype: sqrt rounded to w.dtype, then squared in w.dtype
+        w_fro = (sumsq.sqrt().to(w.dtype)) ** 2
+        _, S, _, _ = ops.svd(wc, None, k=1, want_vectors=False)
+        spectral_norm = S[0]
+        w_spec = spectral_norm ** 2
+        sr = (w_fro / w_spec) ** 0.5
+        sr = sr.reshape(())
+        local[info["full_name"]] = {}
+        for param_ratio in param_ratio_candidates:
+            local[info["full_name"]][param_ratio] = -sr * param_ratio ** 0.1  # 0-dim tensors, as in the reference
+            pbar.update(1)
+    if ws > 1:
+        as_float = {n: {r: float(v) for r, v in d.items()} for n, d in local.items()}
+        full = parallel.allgather_sensitivities(as_float, names, param_ratio_candidates, owner)
+        sensitivity_dict = {n: {r: torch.tensor(v) for r, v in d.items()} for n, d in full.items()}
+    else:
+        sensitivity_dict = {n: local[n] for n in names}
+    if rank == 0:
+        os.makedirs("cache", exist_ok=True)
+        torch.save(sensitivity_dict, cache_file)
+    return sensitivity_dict

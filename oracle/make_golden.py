@@ -1,0 +1,314 @@
+"""Generate tests/golden/* by IMPORTING the reference (/root/reference, read-only) in the build container.
+
+Run once here (`python oracle/make_golden.py`); the reference never travels to the GPU box, only these vectors do.
+Fixtures are data (inputs + outputs of the reference's own functions), no reference source text.
+`lm_eval` is absent in this image: the three modules that import it at top level get an empty stub — the hot path only
+uses evaluate_utils.evaluate_perplexity, which has no lm_eval dependency."""
+import contextlib
+import io
+import json
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+for name in ("lm_eval", "lm_eval.base", "lm_eval.evaluator", "lm_eval.tasks"):
+    sys.modules.setdefault(name, types.ModuleType(name))
+sys.modules["lm_eval.base"].BaseLM = object
+sys.modules["lm_eval"].evaluator = sys.modules["lm_eval.evaluator"]
+sys.modules["lm_eval"].tasks = sys.modules["lm_eval.tasks"]
+sys.modules["lm_eval"].base = sys.modules["lm_eval.base"]
+sys.path.insert(0, REF)
+
+from modules.svd_linear import SVDLinear  # noqa: E402
+import act_aware_utils  # noqa: E402
+import sensitivity as ref_sensitivity  # noqa: E402
+import binary_search as ref_binary_search  # noqa: E402
+import evaluate_utils as ref_eval  # noqa: E402
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+# ---- F-rank ---------------------------------------------------------------------------------------------------
+def gen_rank():
+    shapes = [(768, 768), (3072, 768), (768, 3072), (50272, 768), (4096, 4096), (11008, 4096), (4096, 11008), (32000, 4096),
+              (5120, 5120), (13824, 5120), (5120, 13824), (32000, 5120), (64, 64), (176, 64), (64, 176)]
+    ratios = [0.4, 0.5, 0.6, 0.7, 0.8, 0.9, 0.25] + [0.1 * i for i in range(1, 20)]
+    rows = []
+    for (o, i) in shapes:
+        for ratio in ratios:
+            for align in (1, 128):
+                lin = types.SimpleNamespace()
+                # run the reference arithmetic through from_linear on a meta-free tiny proxy is too heavy for 50272x768;
+                # the rank lines (svd_linear.py:39-44) are reproduced by calling from_linear only on small shapes below and
+                # evaluated here with the identical expressions for the big ones (checked equal on the small ones).
+                n_params = o * i
+                compressed = int(n_params * ratio)
+                rank = compressed // (i + o)
+                rank = int(np.ceil(rank / align) * align)
+                rows.append([o, i, ratio, align, rank])
+    # cross-check the expressions against the reference object on small shapes
+    for (o, i) in [(64, 64), (176, 64), (64, 176)]:
+        for ratio in ratios:
+            lin = nn.Linear(i, o)
+            with contextlib.redirect_stdout(io.StringIO()):
+                m = SVDLinear.from_linear(lin, ratio)
+            if isinstance(m, SVDLinear):
+                exp = [r for r in rows if r[0] == o and r[1] == i and r[2] == ratio and r[3] == 1][0][4]
+                assert m.truncation_rank == min(exp, min(o, i)) or m.truncation_rank == exp, (o, i, ratio, m.truncation_rank, exp)
+    json.dump({"columns": ["out", "in", "ratio", "align", "rank"], "rows": rows}, open(os.path.join(OUT, "rank_table.json"), "w"))
+
+
+# ---- F-hook ---------------------------------------------------------------------------------------------------
+class OneLinear(nn.Module):
+    def __init__(self, c, dtype):
+        super().__init__()
+        self.config = types.SimpleNamespace(_name_or_path="golden/one_linear")
+        self.lin = nn.Linear(c, 8, bias=False).to(dtype)
+        self.device = torch.device("cpu")
+
+    def forward(self, x):
+        return self.lin(x)
+
+
+def gen_hook():
+    out = {}
+    cases = [("a", (1, 64, 64), torch.float16), ("b", (64, 176), torch.float32), ("c", (1, 512, 200), torch.float16),
+             ("d", (1, 2048, 768), torch.float16)]
+    g = torch.Generator().manual_seed(233)
+    cwd = os.getcwd()
+    for tag, shape, dt in cases:
+        xs = [(torch.randn(shape, generator=g) * (1 + 3 * torch.rand(shape[-1], generator=g))).to(dt) for _ in range(4)]
+        if tag == "c":
+            xs[1][..., 5, 7] = float("nan")  # NaN handling of abs_max / abs_mean
+        for method in ("abs_mean", "abs_max"):
+            accs = []
+            for nb in range(1, 5):
+                model = OneLinear(shape[-1], dt)
+                with tempfile.TemporaryDirectory() as td:
+                    os.chdir(td)
+                    os.makedirs("cache")
+                    with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+                        act_aware_utils.calib_input_distribution(model, [{"x": x} for x in xs[:nb]], method, use_cache=False)
+                    os.chdir(cwd)
+                accs.append(npy(model.lin.scaling_diag_matrix))
+            out[f"{tag}_{method}_acc"] = np.stack(accs)
+        if tag != "d":
+            out[f"{tag}_x"] = np.stack([npy(x) for x in xs])
+        else:
+            out["d_seed_note"] = np.array([233])
+            out["d_x"] = np.stack([npy(x) for x in xs])[:, :, ::8, :]  # subsample rows for size; stats below are for d_x
+    # for case d regenerate accumulators on the stored (subsampled) input so the fixture is self-contained
+    xs = [torch.from_numpy(a) for a in out["d_x"]]
+    for method in ("abs_mean", "abs_max"):
+        accs = []
+        for nb in range(1, 5):
+            model = OneLinear(768, torch.float16)
+            with tempfile.TemporaryDirectory() as td:
+                os.chdir(td)
+                os.makedirs("cache")
+                with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+                    act_aware_utils.calib_input_distribution(model, [{"x": x} for x in xs[:nb]], method, use_cache=False)
+                os.chdir(cwd)
+            accs.append(npy(model.lin.scaling_diag_matrix))
+        out[f"d_{method}_acc"] = np.stack(accs)
+    np.savez_compressed(os.path.join(OUT, "hook.npz"), **out)
+
+
+# ---- F-svd ----------------------------------------------------------------------------------------------------
+def exact_lowrank(w, q=6, niter=2, M=None):
+    U, S, Vh = torch.linalg.svd(w, full_matrices=False)
+    return U[:, :q], S[:q], Vh[:q].transpose(0, 1)
+
+
+def gen_svd():
+    out = {}
+    meta = []
+    g = torch.Generator().manual_seed(233)
+    cases = []
+    for (o, i) in [(64, 64), (176, 64), (64, 176), (256, 128)]:
+        for dist in ("gauss", "outlier"):
+            for dt in (torch.float16, torch.float32):
+                cases.append((o, i, dist, dt))
+    stock = torch.svd_lowrank
+    for ci, (o, i, dist, dt) in enumerate(cases):
+        W = torch.randn(o, i, generator=g) * 0.02
+        scal = 4 * torch.randn(i, generator=g).abs()
+        if dist == "outlier":
+            W[:, torch.randperm(i, generator=g)[: max(1, i // 50)]] *= 20
+            scal[torch.randperm(i, generator=g)[: max(1, i // 50)]] *= 30
+            scal[0] = 0.0  # dead channel -> s = 1e-6 (fp16: 1.0133e-6)
+        lin = nn.Linear(i, o, bias=(ci % 2 == 0)).to(dt)
+        lin.weight.data = W.to(dt)
+        lin.scaling_diag_matrix = scal.to(dt)
+        for fuse in ("UV", "U", "V"):
+            for ratio, alpha in ((0.5, 0.5), (0.9, 1.0)):
+                torch.svd_lowrank = exact_lowrank
+                with contextlib.redirect_stdout(io.StringIO()):
+                    m = SVDLinear.from_linear(lin, ratio, act_aware=True, alpha=alpha, sigma_fuse=fuse)
+                torch.svd_lowrank = stock
+                assert isinstance(m, SVDLinear)
+                key = f"c{ci}_{fuse}_{ratio}_{alpha}"
+                out[key + "_A"] = npy(m.ALinear.weight.data)
+                out[key + "_B"] = npy(m.BLinear.weight.data)
+                # stock (randomized) reference: truncation error in the scaled norm, for the one-sided Eckart-Young check
+                torch.manual_seed(233)
+                with contextlib.redirect_stdout(io.StringIO()):
+                    ms = SVDLinear.from_linear(lin, ratio, act_aware=True, alpha=alpha, sigma_fuse=fuse)
+                s = (lin.scaling_diag_matrix ** alpha + 1e-6).float()
+                Ws = lin.weight.data.float() * s.view(1, -1)
+                rec = (ms.ALinear.weight.data.float() @ ms.BLinear.weight.data.float()) * s.view(1, -1)
+                stock_err = float((Ws - rec).norm() / Ws.norm())
+                meta.append({"key": key, "case": ci, "out": o, "in": i, "dist": dist, "dtype": str(dt).split(".")[-1], "fuse": fuse,
+                             "ratio": ratio, "alpha": alpha, "rank": int(m.truncation_rank), "has_bias": lin.bias is not None,
+                             "stock_scaled_trunc_err": stock_err})
+        out[f"c{ci}_W"] = npy(lin.weight.data)
+        out[f"c{ci}_scal"] = npy(lin.scaling_diag_matrix)
+    np.savez_compressed(os.path.join(OUT, "svd_linear.npz"), **out)
+    json.dump(meta, open(os.path.join(OUT, "svd_linear_meta.json"), "w"), indent=0)
+
+
+# ---- tiny model for order / search / stable-rank / ppl ---------------------------------------------------------
+class Attn(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.q_proj, self.k_proj, self.v_proj, self.o_proj = (nn.Linear(d, d, bias=False) for _ in range(4))
+
+
+class Mlp(nn.Module):
+    def __init__(self, d, f):
+        super().__init__()
+        self.gate_proj, self.up_proj, self.down_proj = nn.Linear(d, f, bias=False), nn.Linear(d, f, bias=False), nn.Linear(f, d, bias=False)
+
+
+class Layer(nn.Module):
+    def __init__(self, d, f):
+        super().__init__()
+        self.self_attn, self.mlp = Attn(d), Mlp(d, f)
+
+
+class TinyLM(nn.Module):
+    """Llama-shaped module tree (names only matter); forward returns fixed pseudo-logits so evaluate_perplexity runs."""
+
+    def __init__(self, d=32, f=80, n_layers=2, vocab=50, seed=0):
+        super().__init__()
+        torch.manual_seed(seed)
+        self.config = types.SimpleNamespace(_name_or_path="golden/tiny_lm")
+        self.model = nn.Module()
+        self.model.embed_tokens = nn.Embedding(vocab, d)
+        self.model.layers = nn.ModuleList([Layer(d, f) for _ in range(n_layers)])
+        self.lm_head = nn.Linear(d, vocab, bias=False)
+        self.device = torch.device("cpu")
+
+    def forward(self, input_ids=None, **kw):
+        h = self.model.embed_tokens(input_ids)
+        for l in self.model.layers:
+            a = l.self_attn
+            h = h + a.o_proj(torch.tanh(a.q_proj(h)) * torch.sigmoid(a.k_proj(h)) + a.v_proj(h))
+            m = l.mlp
+            h = h + m.down_proj(torch.nn.functional.silu(m.gate_proj(h)) * m.up_proj(h))
+        return (self.lm_head(h),)
+
+
+def tiny_state(model):
+    return {k: npy(v) for k, v in model.state_dict().items()}
+
+
+def gen_search():
+    out = {}
+    model = TinyLM()
+    args = types.SimpleNamespace(scaling_method="abs_mean", alpha=0.5, n_calib_samples=3, calib_dataset="wikitext2", compress_kv_cache=False,
+                                 rank_align=1, act_aware=True, sigma_fuse="UV", ppl_target=-1, param_ratio_target=0.8, kv_cache_ratio_target=-1)
+    g = torch.Generator().manual_seed(5)
+    calib = [{"input_ids": torch.randint(0, 50, (1, 16), generator=g)} for _ in range(3)]
+    cwd = os.getcwd()
+    stock = torch.svd_lowrank
+    with tempfile.TemporaryDirectory() as td:
+        os.chdir(td)
+        os.makedirs("cache")
+        with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+            act_aware_utils.calib_input_distribution(model, calib, "abs_mean", use_cache=False)
+        scal = {n: npy(m.scaling_diag_matrix) for n, m in model.named_modules() if isinstance(m, nn.Linear)}
+        torch.svd_lowrank = exact_lowrank
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf), contextlib.redirect_stderr(io.StringIO()):
+            sens = ref_sensitivity.calib_sensitivity_ppl(model, calib, args, use_cache=False)
+        sweep_log = [l for l in buf.getvalue().splitlines() if l and not l.startswith("input_ids")]
+        with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+            sens_sr = ref_sensitivity.calib_sensitivity_stable_rank(model, calib, args, use_cache=False)
+        # ppl of the raw tiny model
+        ids = torch.cat([c["input_ids"] for c in calib], 0)
+        ppl_raw = ref_eval.evaluate_perplexity(model, ids, 3)
+        results = {}
+        for tag, kw in (("ratio0.8", dict(param_ratio_target=0.8)), ("ratio0.6", dict(param_ratio_target=0.6)),
+                        ("kv0.5", dict(compress_kv_cache=True, kv_cache_ratio_target=0.5))):
+            m2 = TinyLM()
+            for n, mod in m2.named_modules():
+                if isinstance(mod, nn.Linear):
+                    mod.scaling_diag_matrix = torch.from_numpy(scal[n])
+            a2 = types.SimpleNamespace(**{**vars(args), **kw})
+            if a2.compress_kv_cache:
+                sd = {k: {0.1 * i: float(100 - 3 * i + (hash(k) % 7)) for i in range(1, 20)} for k in sens}
+            else:
+                sd = sens
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf), contextlib.redirect_stderr(io.StringIO()):
+                ref_binary_search.binary_search_truncation_rank(m2, sd, calib, a2)
+            trace = [l for l in buf.getvalue().splitlines() if l.startswith("low=") or l.startswith("===")]
+            ranks = {n: (int(mod.truncation_rank) if isinstance(mod, SVDLinear) else -1) for n, mod in m2.named_modules()
+                     if isinstance(mod, (SVDLinear,)) or (isinstance(mod, nn.Linear) and not n.endswith("ALinear") and not n.endswith("BLinear"))}
+            ppl = ref_eval.evaluate_perplexity(m2, ids, 3)
+            results[tag] = {"trace": trace, "ranks": ranks, "ppl_after": ppl, "sens": {k: {str(r): float(v) for r, v in d.items()} for k, d in sd.items()}}
+        torch.svd_lowrank = stock
+        os.chdir(cwd)
+    order = list(sens.keys())
+    json.dump({"order": order, "sweep_log": sweep_log, "sensitivity_ppl": {k: {str(r): float(v) for r, v in d.items()} for k, d in sens.items()},
+               "sensitivity_stable_rank": {k: {str(r): float(v) for r, v in d.items()} for k, d in sens_sr.items()},
+               "ppl_raw": ppl_raw, "search": results, "calib_ids": [c["input_ids"].tolist() for c in calib],
+               "model": {"d": 32, "f": 80, "n_layers": 2, "vocab": 50, "seed": 0}},
+              open(os.path.join(OUT, "tiny_lm.json"), "w"), indent=0)
+    np.savez_compressed(os.path.join(OUT, "tiny_lm_state.npz"), **tiny_state(TinyLM()), **{"scal::" + k: v for k, v in scal.items()})
+
+
+def gen_order_hf():
+    """reverse-DFS Linear order of real HF module trees (tiny random Llama / OPT)"""
+    from transformers import LlamaConfig, LlamaForCausalLM, OPTConfig, OPTForCausalLM
+    res = {}
+    for tag, model in (("llama", LlamaForCausalLM(LlamaConfig(hidden_size=32, intermediate_size=64, num_hidden_layers=2, num_attention_heads=2,
+                                                              num_key_value_heads=2, vocab_size=64))),
+                       ("opt", OPTForCausalLM(OPTConfig(hidden_size=32, ffn_dim=64, num_hidden_layers=2, num_attention_heads=2, vocab_size=64,
+                                                        word_embed_proj_dim=32, max_position_embeddings=64)))):
+        full = {m: n for n, m in model.named_modules()}
+        order = []
+        modules = [model]
+        # the reference walk (sensitivity.py:19-33) executed through its own function would need a forward; the order only
+        # depends on named_children(), so replay the identical stack discipline on the reference's data structure
+        while modules:
+            sub = modules.pop()
+            for name, child in sub.named_children():
+                if isinstance(child, nn.Linear):
+                    order.append(full[child])
+                else:
+                    modules.append(child)
+        res[tag] = order
+    json.dump(res, open(os.path.join(OUT, "linear_order_hf.json"), "w"), indent=0)
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    gen_rank()
+    gen_hook()
+    gen_svd()
+    gen_search()
+    gen_order_hf()
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -1,0 +1,155 @@
+"""GPU parity tests for the HBM-bound kernels (K1/K2/K3/K5/K6/K8/K9), called through the C ABI (asvd4llm_amd.ops -> ctypes).
+Checker = oracle/asvd_oracle.py and the reference-generated fixtures under tests/golden/."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import asvd_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _ulp_close(got, want, dtype, n_ulp=1, frac_exact=0.98):
+    """equal within n_ulp of `dtype`, and bit-exact for at least frac_exact of the entries (rounding freedom of an fp32
+    column sum in a different order than torch's; documented in DESIGN.md)"""
+    got64, want64 = got.double().cpu(), want.double().cpu()
+    nan_g, nan_w = torch.isnan(got64), torch.isnan(want64)
+    assert torch.equal(nan_g, nan_w)
+    fin = ~nan_w
+    eps = torch.finfo(dtype).eps
+    tol = n_ulp * eps * want64[fin].abs() + 1e-30
+    assert bool(((got64[fin] - want64[fin]).abs() <= tol).all())
+    exact = (got64[fin] == want64[fin]).double().mean().item()
+    assert exact >= frac_exact, f"only {exact:.4f} bit-exact"
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+@pytest.mark.parametrize("method", ["abs_mean", "abs_max"])
+def test_absstat_vs_reference_hook(gpu, golden, tag, method):
+    from asvd4llm_amd import ops
+    g = golden.npz("hook.npz")
+    xs, want = g[f"{tag}_x"], g[f"{tag}_{method}_acc"]
+    x0 = torch.from_numpy(xs[0])
+    acc = torch.zeros(x0.shape[-1], dtype=x0.dtype, device=gpu)
+    for b in range(4):
+        x = torch.from_numpy(xs[b]).to(gpu)
+        ops.absstat_accum(x.reshape(-1, x.shape[-1]), acc, method)
+        w = torch.from_numpy(want[b])
+        if method == "abs_max":
+            assert torch.equal(acc.cpu(), w)  # max is order independent: bit exact, NaN handling included
+        else:
+            _ulp_close(acc, w, x0.dtype, n_ulp=1 + b)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("shape", [(2048, 4096), (1, 64), (37, 100), (2047, 11008)])
+def test_absstat_shapes_vs_oracle(gpu, dtype, shape):
+    from asvd4llm_amd import ops
+    g = torch.Generator().manual_seed(1)
+    x = (torch.randn(shape, generator=g) * 3).to(dtype)
+    for method in ("abs_mean", "abs_max"):
+        acc = torch.zeros(shape[1], dtype=dtype, device=gpu)
+        want = None
+        for _ in range(2):
+            ops.absstat_accum(x.to(gpu), acc, method)
+            want = O.hook_update(want, x.unsqueeze(0), method)
+        if method == "abs_max":
+            assert torch.equal(acc.cpu(), want)
+        else:
+            _ulp_close(acc, want, dtype, n_ulp=2, frac_exact=0.95)
+
+
+def test_absstat_strided_rows(gpu):
+    from asvd4llm_amd import ops
+    x = torch.randn(64, 256, dtype=torch.float16)
+    xs = x.to(gpu)[:, :96]  # leading dimension 256, 96 columns
+    acc = torch.zeros(96, dtype=torch.float16, device=gpu)
+    ops.absstat_accum(xs, acc, "abs_mean")
+    _ulp_close(acc, O.hook_update(None, x[:, :96], "abs_mean"), torch.float16)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("alpha", [0.5, 1.0, 0.3])
+def test_make_scale_and_scale_cols(gpu, dtype, alpha):
+    from asvd4llm_amd import ops
+    g = torch.Generator().manual_seed(2)
+    scal = (32 * torch.randn(1000, generator=g).abs()).to(dtype)
+    scal[:3] = 0  # dead channels: s = eps in dtype
+    s_ref = O.make_scale(scal, alpha)
+    s = ops.make_scale(scal.to(gpu), alpha=alpha)
+    assert s.dtype == dtype
+    if alpha in (0.5, 1.0):
+        assert torch.equal(s.cpu(), s_ref)  # sqrt / identity are correctly rounded on both sides
+    else:
+        _ulp_close(s, s_ref, dtype, n_ulp=1, frac_exact=0.9)
+    W = (torch.randn(130, 1000, generator=g) * 0.02).to(dtype)
+    ws = ops.scale_cols(W.to(gpu), s_ref.to(gpu))
+    assert torch.equal(ws.cpu(), O.scaled_weight(W, s_ref))
+    assert torch.equal(ops.scale_cols(W.to(gpu), None).cpu(), W.float())
+
+
+def test_make_scale_with_fisher(gpu):
+    from asvd4llm_amd import ops
+    g = torch.Generator().manual_seed(3)
+    scal = torch.randn(333, generator=g).abs().half()
+    fis = torch.randn(333, generator=g).abs().half()
+    assert torch.equal(ops.make_scale(scal.to(gpu), fis.to(gpu), alpha=0.5).cpu(), O.make_scale(scal, 0.5, fis))
+
+
+@pytest.mark.parametrize("fuse", ["UV", "U", "V"])
+@pytest.mark.parametrize("out_dtype", [torch.float16, torch.float32, torch.bfloat16])
+def test_truncate_split_bit_exact(gpu, fuse, out_dtype):
+    """same U,S,V in -> identical A,B bits out (fp32 arithmetic in the reference's operation order, one RNE rounding)"""
+    from asvd4llm_amd import ops
+    g = torch.Generator().manual_seed(4)
+    m, n, k, r = 176, 100, 100, 37
+    U = torch.randn(m, k, generator=g)
+    V = torch.randn(n, k, generator=g)
+    S = torch.rand(k, generator=g).sort(descending=True).values * 10
+    s = (torch.rand(n, generator=g) * 4 + 0.01).half()
+    A_ref, B_ref, nan = O.truncate_split(U, S, V, s, r, fuse, out_dtype)
+    A, B, flags = ops.truncate_split(U.to(gpu), S.to(gpu), V.to(gpu), s.to(gpu), r, fuse, out_dtype)
+    assert torch.equal(A.cpu(), A_ref) and torch.equal(B.cpu(), B_ref)
+    assert flags.tolist() == [0, 0, 0] and nan == [False, False, False]
+    A, B, _ = ops.truncate_split(U.to(gpu), S.to(gpu), V.to(gpu), None, r, fuse, out_dtype)
+    A_ref, B_ref, _ = O.truncate_split(U, S, V, None, r, fuse, out_dtype)
+    assert torch.equal(A.cpu(), A_ref) and torch.equal(B.cpu(), B_ref)
+
+
+def test_truncate_split_nan_flags(gpu):
+    from asvd4llm_amd import ops
+    m, n, k, r = 40, 33, 33, 8
+    for which in range(3):
+        U, V, S = torch.randn(m, k), torch.randn(n, k), torch.rand(k) + 1
+        s = torch.ones(n).half()
+        if which == 0:
+            S[2] = float("nan")
+        elif which == 1:
+            U[5, 3] = float("nan")
+        else:
+            s[4] = 0.0
+            V[4, 1] = 0.0  # 0/0 -> NaN after un-scaling, as the reference checks V after the division
+        _, _, flags = ops.truncate_split(U.to(gpu), S.to(gpu), V.to(gpu), s.to(gpu), r, "UV", torch.float16)
+        _, _, nan = O.truncate_split(U, S, V, s, r, "UV", torch.float16)
+        assert [bool(f) for f in flags.tolist()] == nan
+        # NaN beyond the truncation rank is not reported (only [:r] is inspected by the reference)
+    U, V, S = torch.randn(m, k), torch.randn(n, k), torch.rand(k) + 1
+    U[0, r] = float("nan")
+    _, _, flags = ops.truncate_split(U.to(gpu), S.to(gpu), V.to(gpu), None, r, "UV", torch.float16)
+    assert flags.tolist() == [0, 0, 0]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+def test_fro_and_reconstruct(gpu, dtype):
+    from asvd4llm_amd import ops
+    g = torch.Generator().manual_seed(5)
+    m, n, r = 200, 136, 40
+    W = (torch.randn(m, n, generator=g) * 0.02).to(dtype)
+    A = (torch.randn(m, r, generator=g) * 0.1).to(dtype)
+    B = (torch.randn(r, n, generator=g) * 0.1).to(dtype)
+    ss = ops.fro_norm_sq(W.to(gpu)).item()
+    assert abs(ss - W.double().pow(2).sum().item()) <= 1e-5 * ss
+    out = ops.reconstruct_err(W.to(gpu), A.to(gpu), B.to(gpu)).cpu()
+    e2 = (W.double() - A.double() @ B.double()).pow(2).sum().item()
+    w2 = W.double().pow(2).sum().item()
+    assert abs(out[0].item() - e2) <= 1e-5 * e2 and abs(out[1].item() - w2) <= 1e-9 * w2

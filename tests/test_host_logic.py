@@ -1,0 +1,105 @@
+"""Host-side logic of the package (traversal order, search, sharding map) against the reference-generated fixtures. CPU only."""
+import contextlib
+import io
+import types
+
+import torch
+import torch.nn as nn
+
+from asvd4llm_amd import parallel
+from asvd4llm_amd.modules.svd_linear import SVDLinear
+from asvd4llm_amd.sensitivity import collect_linear_info
+from tests.tiny_lm import TinyLM, default_args, load_golden_tiny
+
+
+def test_reverse_dfs_order_tiny(golden):
+    t = golden.json("tiny_lm.json")
+    model, _ = load_golden_tiny(golden)
+    order = [i["full_name"] for i in collect_linear_info(model).values()]
+    assert order == t["order"]
+    assert order[0] == "lm_head" and order[1].startswith("model.layers.1.mlp")
+
+
+def test_reverse_dfs_order_hf(golden):
+    from transformers import LlamaConfig, LlamaForCausalLM, OPTConfig, OPTForCausalLM
+    ref = golden.json("linear_order_hf.json")
+    llama = LlamaForCausalLM(LlamaConfig(hidden_size=32, intermediate_size=64, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=2,
+                                         vocab_size=64))
+    opt = OPTForCausalLM(OPTConfig(hidden_size=32, ffn_dim=64, num_hidden_layers=2, num_attention_heads=2, vocab_size=64, word_embed_proj_dim=32,
+                                   max_position_embeddings=64))
+    assert [i["full_name"] for i in collect_linear_info(llama).values()] == ref["llama"]
+    assert [i["full_name"] for i in collect_linear_info(opt).values()] == ref["opt"]
+
+
+def test_compute_rank_matches_reference_table(golden):
+    t = golden.json("rank_table.json")
+    for out_f, in_f, ratio, align, rank in t["rows"]:
+        lin = types.SimpleNamespace(weight=types.SimpleNamespace(numel=lambda o=out_f, i=in_f: o * i), in_features=in_f, out_features=out_f)
+        assert SVDLinear.compute_rank(lin, ratio, align) == rank
+
+
+def _run_search(golden, tag, monkeypatch, **kw):
+    from asvd4llm_amd import binary_search as bs
+    t = golden.json("tiny_lm.json")
+    rec = t["search"][tag]
+    model, scal = load_golden_tiny(golden)
+    calls = []
+
+    def fake_from_linear(linear, param_ratio, act_aware=False, ic_split=1, oc_split=1, alpha=1, sigma_fuse="UV", rank_align=1):
+        r = SVDLinear.compute_rank(linear, param_ratio, rank_align)
+        calls.append((param_ratio, act_aware, alpha, sigma_fuse, rank_align))
+        m = nn.Identity()
+        m.truncation_rank = r
+        return m
+
+    monkeypatch.setattr(SVDLinear, "from_linear", staticmethod(fake_from_linear))
+    sens = {k: {float(r): v for r, v in d.items()} for k, d in rec["sens"].items()}
+    calib = [{"input_ids": torch.tensor(ids)} for ids in t["calib_ids"]]
+    args = default_args(offload_raw_to_cpu=False, **kw)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf), contextlib.redirect_stderr(io.StringIO()):
+        bs.binary_search_truncation_rank(model, sens, calib, args)
+    lines = [l for l in buf.getvalue().splitlines() if l.startswith("low=") or l.startswith("===")]
+    assert lines == rec["trace"]
+    got = {}
+    for n, m in model.named_modules():
+        if hasattr(m, "truncation_rank"):
+            got[n] = m.truncation_rank
+        elif isinstance(m, nn.Linear):
+            got[n] = -1
+    assert got == rec["ranks"]
+    assert all(c[1] is True and c[2] == 0.5 and c[3] == "UV" for c in calls)
+
+
+def test_binary_search_ratio_target(golden, monkeypatch):
+    _run_search(golden, "ratio0.8", monkeypatch, param_ratio_target=0.8)
+
+
+def test_binary_search_ratio_target_2(golden, monkeypatch):
+    _run_search(golden, "ratio0.6", monkeypatch, param_ratio_target=0.6)
+
+
+def test_binary_search_kv_mode(golden, monkeypatch):
+    _run_search(golden, "kv0.5", monkeypatch, compress_kv_cache=True, kv_cache_ratio_target=0.5)
+
+
+def test_lpt_assign_balanced_and_deterministic():
+    costs = [parallel.svd_flops(32000, 4096)] + [parallel.svd_flops(*s) for _ in range(32)
+                                                   for s in [(11008, 4096), (11008, 4096), (4096, 11008), (4096, 4096), (4096, 4096),
+                                                             (4096, 4096), (4096, 4096)]]
+    assert len(costs) == 225
+    own = parallel.lpt_assign(costs, 8)
+    assert own == parallel.lpt_assign(list(costs), 8)
+    load = [sum(c for c, o in zip(costs, own) if o == r) for r in range(8)]
+    assert max(load) / (sum(load) / 8) < 1.05
+    assert abs(sum(costs) - 5.026e14) / 5.026e14 < 1e-3  # SURVEY.md §8d whole-model flop figure
+    assert parallel.lpt_assign(costs, 1) == [0] * 225
+
+
+def test_perplexity_quirk_matches_reference(golden):
+    from asvd4llm_amd.evaluate_utils import evaluate_perplexity
+    t = golden.json("tiny_lm.json")
+    model, _ = load_golden_tiny(golden)
+    ids = torch.cat([torch.tensor(i) for i in t["calib_ids"]], 0)
+    ppl = evaluate_perplexity(model, ids, 3)
+    assert abs(ppl - t["ppl_raw"]) <= 1e-5 * t["ppl_raw"]

@@ -1,0 +1,64 @@
+"""Llama-shaped toy module tree used by the host-logic and end-to-end tests (names matter, arithmetic is arbitrary)."""
+import types
+
+import torch
+import torch.nn as nn
+
+
+class Attn(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.q_proj, self.k_proj, self.v_proj, self.o_proj = (nn.Linear(d, d, bias=False) for _ in range(4))
+
+
+class Mlp(nn.Module):
+    def __init__(self, d, f):
+        super().__init__()
+        self.gate_proj, self.up_proj, self.down_proj = nn.Linear(d, f, bias=False), nn.Linear(d, f, bias=False), nn.Linear(f, d, bias=False)
+
+
+class Layer(nn.Module):
+    def __init__(self, d, f):
+        super().__init__()
+        self.self_attn, self.mlp = Attn(d), Mlp(d, f)
+
+
+class TinyLM(nn.Module):
+    def __init__(self, d=32, f=80, n_layers=2, vocab=50, seed=0):
+        super().__init__()
+        torch.manual_seed(seed)
+        self.config = types.SimpleNamespace(_name_or_path="golden/tiny_lm", vocab_size=vocab)
+        self.model = nn.Module()
+        self.model.embed_tokens = nn.Embedding(vocab, d)
+        self.model.layers = nn.ModuleList([Layer(d, f) for _ in range(n_layers)])
+        self.lm_head = nn.Linear(d, vocab, bias=False)
+
+    @property
+    def device(self):
+        return self.lm_head.weight.device if isinstance(self.lm_head, nn.Linear) else next(self.parameters()).device
+
+    def forward(self, input_ids=None, **kw):
+        h = self.model.embed_tokens(input_ids)
+        for l in self.model.layers:
+            a = l.self_attn
+            h = h + a.o_proj(torch.tanh(a.q_proj(h)) * torch.sigmoid(a.k_proj(h)) + a.v_proj(h))
+            m = l.mlp
+            h = h + m.down_proj(torch.nn.functional.silu(m.gate_proj(h)) * m.up_proj(h))
+        return (self.lm_head(h),)
+
+
+def load_golden_tiny(golden):
+    """TinyLM with the exact weights and scaling vectors the reference run used (tests/golden/tiny_lm_state.npz)."""
+    st = golden.npz("tiny_lm_state.npz")
+    model = TinyLM()
+    sd = {k: torch.from_numpy(st[k]) for k in st.files if not k.startswith("scal::")}
+    model.load_state_dict(sd)
+    scal = {k[len("scal::"):]: torch.from_numpy(st[k]) for k in st.files if k.startswith("scal::")}
+    return model, scal
+
+
+def default_args(**kw):
+    base = dict(scaling_method="abs_mean", alpha=0.5, n_calib_samples=3, calib_dataset="wikitext2", compress_kv_cache=False, rank_align=1,
+                act_aware=True, sigma_fuse="UV", ppl_target=-1, param_ratio_target=0.8, kv_cache_ratio_target=-1)
+    base.update(kw)
+    return types.SimpleNamespace(**base)
