@@ -92,7 +92,7 @@ __global__ void absstat_final_kernel(const float* __restrict__ part, const int* 
     if (MODE == ASVD_STAT_ABS_MEAN) {
         float s = 0.0f;
         for (int k = 0; k < nsplit; ++k) s += part[(int64_t)k * cols + c];
-        const float mean = elem<AT>::rnd(s / (float)rows);  // .mean() result in the activation dtype
+        const float mean = elem<AT>::rnd(__fdiv_rn(s, (float)rows));  // .mean() result in the activation dtype
         elem<AT>::st(acc, c, old + mean);                   // `+=` in that dtype (one rounding)
     } else {
         float mx = 0.0f;
@@ -109,16 +109,18 @@ __global__ void absstat_final_kernel(const float* __restrict__ part, const int* 
 // --------------------------------------------------------------------------------------------------
 // K3a  s = (scaling**alpha [* fisher**alpha]) + eps, each op rounded to the statistics dtype
 __device__ __forceinline__ float pow_alpha(float x, float alpha) {
-    if (alpha == 0.5f) return sqrtf(x);
+    if (alpha == 0.5f) return (float)sqrt((double)x);  // correctly rounded (fp64 sqrt rounded once; v_sqrt_f32 is 1 ulp)
     if (alpha == 1.0f) return x;
     if (alpha == 2.0f) return x * x;
-    return powf(x, alpha);
+    return (float)pow((double)x, (double)alpha);  // double pow rounded once: within the last fp32 bit of a correctly rounded powf
 }
 template <int DT>
 __global__ void make_scale_kernel(const void* __restrict__ scaling, const void* __restrict__ fisher, int64_t n, float alpha,
                                   float eps, void* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    // torch casts the python-scalar exponent to the tensor dtype before pow (0.3 -> 0.30005 for fp16): do the same
+    alpha = elem<DT>::rnd(alpha);
     float p = elem<DT>::rnd(pow_alpha(elem<DT>::ld(scaling, i), alpha));
     if (fisher) {
         const float f = elem<DT>::rnd(pow_alpha(elem<DT>::ld(fisher, i), alpha));
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(256) void split_a_kernel(const float* __restrict__ 
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= r) return;
     const float sv = S[j];
-    const float f = (fuse == ASVD_FUSE_UV) ? sqrtf(sv) : (fuse == ASVD_FUSE_U ? sv : 1.0f);
+    const float f = (fuse == ASVD_FUSE_UV) ? (float)sqrt((double)sv) : (fuse == ASVD_FUSE_U ? sv : 1.0f);
     int bad_u = 0;
     const int64_t i0 = (int64_t)blockIdx.y * 32;
     const int64_t i1 = (i0 + 32 < m) ? i0 + 32 : m;
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(256) void split_b_kernel(const float* __restrict__ 
         float v = 0.0f;
         if (i < n && j < r) {
             v = V[i * ldv + j];
-            if (has_scale) v = v / elem<ST>::ld(s, i);
+            if (has_scale) v = __fdiv_rn(v, elem<ST>::ld(s, i));
             bad |= (v != v);
         }
         tile[a][lx] = v;
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(256) void split_b_kernel(const float* __restrict__ 
         const int64_t j = j0 + a, i = i0 + lx;
         if (i < n && j < r) {
             const float sv = S[j];
-            const float g = (fuse == ASVD_FUSE_UV) ? sqrtf(sv) : (fuse == ASVD_FUSE_V ? sv : 1.0f);
+            const float g = (fuse == ASVD_FUSE_UV) ? (float)sqrt((double)sv) : (fuse == ASVD_FUSE_V ? sv : 1.0f);
             const float v = tile[lx][a];
             elem<OT>::st(B, j * n + i, (fuse == ASVD_FUSE_U) ? v : v * g);
         }

@@ -17,6 +17,8 @@
 #include <vector>
 #include <cmath>
 #include <cstring>
+#include <cstdio>
+#include <cstdlib>
 
 namespace {
 
@@ -158,27 +160,48 @@ __global__ __launch_bounds__(256) void gram_kernel(const float* __restrict__ X, 
 }
 
 // --------------------------------------------------------------------------------------------------
-// evd: one workgroup (1024 threads = 32 x 32 two-by-two blocks) per pair.  Two-sided Jacobi with the
-// parallel round-robin ordering: 63 steps per sweep, 32 disjoint rotations per step.
-__global__ __launch_bounds__(1024) void evd_kernel(const float* __restrict__ Gpart, int nsplit, float* __restrict__ Qbuf,
-                                                    int* __restrict__ active, unsigned* __restrict__ maxoff_bits,
-                                                    int* __restrict__ nrot, const int* __restrict__ done, float tol,
-                                                    int inner_sweeps) {
-    __shared__ float G[PW * GLD];
+// evd: one 256-thread workgroup per pair.  Two-sided Jacobi on the 64x64 Gram matrix in LDS with the parallel
+// round-robin ordering (63 steps per sweep, 32 disjoint rotations per step).  Thread (ty, tx) of a 16x16 grid owns the
+// 2x2 blocks {row pairs 2ty, 2ty+1} x {column pairs 2tx, 2tx+1} and rows 4ty..4ty+3 of those column pairs of Q.
+// Every thread recomputes the four rotations it needs from the OLD matrix (G is ping-ponged between two LDS images), so
+// a step costs ONE barrier and no serialized "compute rotations" phase.  Pair tables are precomputed in LDS.
+__device__ __forceinline__ void jacobi_rot(float a, float d, float b, float& c, float& s, float& t) {
+    c = 1.0f; s = 0.0f; t = 0.0f;
+    const float cosv = b * __builtin_amdgcn_rsqf(a) * __builtin_amdgcn_rsqf(d);  // |cos| of the two columns
+    if (fabsf(cosv) > 1e-8f) {
+        const float zeta = (d - a) * __builtin_amdgcn_rcpf(2.0f * b);
+        t = copysignf(1.0f, zeta) * __builtin_amdgcn_rcpf(fabsf(zeta) + __builtin_amdgcn_sqrtf(fmaf(zeta, zeta, 1.0f)));
+        c = __builtin_amdgcn_rsqf(fmaf(t, t, 1.0f));
+        s = t * c;
+        // unit-norm correction: delta = c^2 + s^2 - 1 via FMAs is accurate far below one ulp, so after scaling by
+        // (1 - delta/2) only the unbiased rounding of c and s themselves remains (no systematic norm drift; the
+        // hardware rcp/rsq approximations above only perturb the ANGLE, which the next visit corrects).
+        const float delta = fmaf(s, s, fmaf(c, c, -1.0f));
+        const float hd = 0.5f * delta;
+        c = fmaf(-c, hd, c);
+        s = fmaf(-s, hd, s);
+    }
+}
+
+__global__ __launch_bounds__(256) void evd_kernel(const float* __restrict__ Gpart, int nsplit, float* __restrict__ Qbuf,
+                                                   int* __restrict__ active, unsigned* __restrict__ maxoff_bits,
+                                                   int* __restrict__ nrot, const int* __restrict__ done, float tol,
+                                                   int inner_sweeps) {
+    __shared__ float Gs[2][PW * GLD];
     __shared__ float Q[PW * GLD];
-    __shared__ float cs[32 * 4];
-    __shared__ float redmax[16];
+    __shared__ unsigned short tab[(PW - 1) * 32];  // (p | q << 8) per step and pair
+    __shared__ float redmax[4];
     __shared__ float lam[PW];
+    __shared__ float cscale[PW];
     __shared__ int rnk[PW];
 
     const int pair = blockIdx.x, b = blockIdx.y, npairs = gridDim.x;
     if (done[b]) return;
     const int tid = threadIdx.x;
     const float* gp = Gpart + ((int64_t)b * npairs + pair) * nsplit * 3072;
+    float* G0 = Gs[0];
 
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int e = tid + 1024 * q;
+    for (int e = tid; e < PW * PW; e += 256) {
         const int i = e >> 6, j = e & 63;
         int t, ii, jj;
         if (i < 32 && j < 32) { t = 0; ii = i; jj = j; }
@@ -188,27 +211,30 @@ __global__ __launch_bounds__(1024) void evd_kernel(const float* __restrict__ Gpa
         const float* p = gp + t * 1024 + ii * 32 + jj;
         float v = 0.0f;
         for (int s = 0; s < nsplit; ++s) v += p[(int64_t)s * 3072];
-        G[i * GLD + j] = v;
+        G0[i * GLD + j] = v;
         Q[i * GLD + j] = (i == j) ? 1.0f : 0.0f;
+    }
+    for (int e = tid; e < (PW - 1) * 32; e += 256) {
+        const int st = e >> 5, k = e & 31;
+        int p, q;
+        rr_pair(PW, st, k, p, q);
+        tab[e] = (unsigned short)(p | (q << 8));
     }
     __syncthreads();
 
-    // scaled off-diagonal measure: max |g_ij| / sqrt(g_ii g_jj)
+    // scaled off-diagonal measure: max |g_ij| / sqrt(g_ii g_jj), NaN propagating
     float loc = 0.0f;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int e = tid + 1024 * q;
+    for (int e = tid; e < PW * PW; e += 256) {
         const int i = e >> 6, j = e & 63;
         if (i != j) {
-            const float dd = G[i * GLD + i] * G[j * GLD + j];
-            const float g = G[i * GLD + j];
+            const float dd = G0[i * GLD + i] * G0[j * GLD + j];
+            const float g = G0[i * GLD + j];
             float v = (dd > 0.0f) ? fabsf(g) * rsqrtf(dd) : 0.0f;
-            if (g != g) v = g;  // propagate NaN
+            if (g != g || dd != dd) v = __builtin_nanf("");
             loc = (v != v) ? v : ((loc != loc) ? loc : fmaxf(loc, v));
         }
     }
     {
-        // NaN-propagating max over the block
         float v = loc;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
@@ -219,14 +245,12 @@ __global__ __launch_bounds__(1024) void evd_kernel(const float* __restrict__ Gpa
     }
     __syncthreads();
     float off0 = redmax[0];
-    for (int i = 1; i < 16; ++i) {
+    for (int i = 1; i < 4; ++i) {
         const float u = redmax[i];
         off0 = (u != u) ? u : ((off0 != off0) ? off0 : fmaxf(off0, u));
     }
     const bool is_nan = (off0 != off0);
-    if (tid == 0) {
-        atomicMax(&maxoff_bits[b], is_nan ? 0x7fc00000u : __float_as_uint(off0));
-    }
+    if (tid == 0) atomicMax(&maxoff_bits[b], is_nan ? 0x7fc00000u : __float_as_uint(off0));
     if (is_nan || off0 < tol) {
         if (tid == 0) active[b * npairs + pair] = 0;
         return;
@@ -236,64 +260,82 @@ __global__ __launch_bounds__(1024) void evd_kernel(const float* __restrict__ Gpa
         atomicAdd(&nrot[b], 1);
     }
 
-    const int k1 = tid >> 5, k2 = tid & 31;  // row-pair index, column-pair index of this thread's 2x2 block
-    for (int sw = 0; sw < inner_sweeps; ++sw) {
+    const int ty = tid >> 4, tx = tid & 15;
+    // a nearly diagonal pair needs one sweep (quadratic convergence finishes the job at the next visit)
+    const int nsw = (off0 > 0.05f) ? inner_sweeps : 1;
+    int cur = 0;
+    for (int sw = 0; sw < nsw; ++sw) {
         for (int st = 0; st < PW - 1; ++st) {
-            int p1, q1, p2, q2;
-            rr_pair(PW, st, k1, p1, q1);
-            rr_pair(PW, st, k2, p2, q2);
-            if (k1 == k2) {
-                const float a = G[p1 * GLD + p1], d = G[q1 * GLD + q1], bb = G[p1 * GLD + q1];
-                float c = 1.0f, s = 0.0f, t = 0.0f;
-                if (fabsf(bb) > 1e-8f * sqrtf(fabsf(a) * fabsf(d)) && bb != 0.0f) {
-                    const float zeta = (d - a) / (2.0f * bb);
-                    t = copysignf(1.0f, zeta) / (fabsf(zeta) + sqrtf(1.0f + zeta * zeta));
-                    if (zeta == 0.0f) t = 1.0f;
-                    c = 1.0f / sqrtf(1.0f + t * t);
-                    s = t * c;
+            const float* __restrict__ Gi = Gs[cur];
+            float* __restrict__ Go = Gs[cur ^ 1];
+            int pr[2], qr[2], pc[2], qc[2];
+            float cr[2], sr[2], tr[2], cc[2], sc[2], tc[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const unsigned tr_ = tab[st * 32 + 2 * ty + i], tc_ = tab[st * 32 + 2 * tx + i];
+                pr[i] = tr_ & 255; qr[i] = tr_ >> 8;
+                pc[i] = tc_ & 255; qc[i] = tc_ >> 8;
+                jacobi_rot(Gi[pr[i] * GLD + pr[i]], Gi[qr[i] * GLD + qr[i]], Gi[pr[i] * GLD + qr[i]], cr[i], sr[i], tr[i]);
+                jacobi_rot(Gi[pc[i] * GLD + pc[i]], Gi[qc[i] * GLD + qc[i]], Gi[pc[i] * GLD + qc[i]], cc[i], sc[i], tc[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const float x00 = Gi[pr[i] * GLD + pc[j]], x01 = Gi[pr[i] * GLD + qc[j]];
+                    const float x10 = Gi[qr[i] * GLD + pc[j]], x11 = Gi[qr[i] * GLD + qc[j]];
+                    // rows (p,q) <- R_r^T rows ; cols (p,q) <- cols R_c ,  R = [[c, s], [-s, c]]
+                    const float y00 = cr[i] * x00 - sr[i] * x10, y01 = cr[i] * x01 - sr[i] * x11;
+                    const float y10 = sr[i] * x00 + cr[i] * x10, y11 = sr[i] * x01 + cr[i] * x11;
+                    float z00 = cc[j] * y00 - sc[j] * y01, z01 = sc[j] * y00 + cc[j] * y01;
+                    float z10 = cc[j] * y10 - sc[j] * y11, z11 = sc[j] * y10 + cc[j] * y11;
+                    if (ty == tx && i == j) {  // the pivot block itself: exact diagonal update, off-diagonal annihilated
+                        z00 = x00 - tr[i] * x01;
+                        z11 = x11 + tr[i] * x01;
+                        z01 = 0.0f;
+                        z10 = 0.0f;
+                    }
+                    Go[pr[i] * GLD + pc[j]] = z00;
+                    Go[pr[i] * GLD + qc[j]] = z01;
+                    Go[qr[i] * GLD + pc[j]] = z10;
+                    Go[qr[i] * GLD + qc[j]] = z11;
                 }
-                cs[k1 * 4 + 0] = c;
-                cs[k1 * 4 + 1] = s;
-                cs[k1 * 4 + 2] = t;
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 4 * ty + r;
+                    const float u = Q[row * GLD + pc[j]], v = Q[row * GLD + qc[j]];
+                    Q[row * GLD + pc[j]] = cc[j] * u - sc[j] * v;
+                    Q[row * GLD + qc[j]] = sc[j] * u + cc[j] * v;
+                }
             }
             __syncthreads();
-            const float c1 = cs[k1 * 4 + 0], s1 = cs[k1 * 4 + 1];
-            const float c2 = cs[k2 * 4 + 0], s2 = cs[k2 * 4 + 1];
-            const float x00 = G[p1 * GLD + p2], x01 = G[p1 * GLD + q2];
-            const float x10 = G[q1 * GLD + p2], x11 = G[q1 * GLD + q2];
-            // left: rows (p1,q1) <- R1^T rows ; right: cols (p2,q2) <- cols R2,   R = [[c, s], [-s, c]]
-            const float y00 = c1 * x00 - s1 * x10, y01 = c1 * x01 - s1 * x11;
-            const float y10 = s1 * x00 + c1 * x10, y11 = s1 * x01 + c1 * x11;
-            float z00 = c2 * y00 - s2 * y01, z01 = s2 * y00 + c2 * y01;
-            float z10 = c2 * y10 - s2 * y11, z11 = s2 * y10 + c2 * y11;
-            if (k1 == k2) {
-                const float t = cs[k1 * 4 + 2];
-                z00 = x00 - t * x01;
-                z11 = x11 + t * x01;
-                z01 = 0.0f;
-                z10 = 0.0f;
-            }
-            G[p1 * GLD + p2] = z00;
-            G[p1 * GLD + q2] = z01;
-            G[q1 * GLD + p2] = z10;
-            G[q1 * GLD + q2] = z11;
-            // eigenvector accumulation: columns (p2,q2) of rows 2*k1, 2*k1+1
-            {
-                const int r0 = 2 * k1, r1 = 2 * k1 + 1;
-                const float u0 = Q[r0 * GLD + p2], v0 = Q[r0 * GLD + q2];
-                const float u1 = Q[r1 * GLD + p2], v1 = Q[r1 * GLD + q2];
-                Q[r0 * GLD + p2] = c2 * u0 - s2 * v0;
-                Q[r0 * GLD + q2] = s2 * u0 + c2 * v0;
-                Q[r1 * GLD + p2] = c2 * u1 - s2 * v1;
-                Q[r1 * GLD + q2] = s2 * u1 + c2 * v1;
-            }
-            __syncthreads();
+            cur ^= 1;
         }
     }
+    const float* Gf = Gs[cur];
 
-    // sort eigenvalues descending (ties by index): column c of Q goes to position rnk[c]
-    if (tid < PW) lam[tid] = G[tid * GLD + tid];
+    // column norms of Q in double (4 threads x 16 rows per column): Q's columns are renormalised to unit length so
+    // that the accumulated rounding of ~126 rotations per column cannot drift the norms of the updated panels.
+    {
+        const int c = tid >> 2, part = tid & 3;
+        double acc = 0.0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const double v = Q[(part * 16 + r) * GLD + c];
+            acc += v * v;
+        }
+        acc += __shfl_xor(acc, 1, 64);
+        acc += __shfl_xor(acc, 2, 64);
+        if (part == 0) {
+            cscale[c] = (acc > 0.0) ? (float)(1.0 / sqrt(acc)) : 1.0f;
+            lam[c] = Gf[c * GLD + c];
+        }
+    }
     __syncthreads();
+    // sort eigenvalues descending (ties by index): column c of Q goes to position rnk[c]
     if (tid < PW) {
         const float me = lam[tid];
         int cnt = 0;
@@ -305,11 +347,9 @@ __global__ __launch_bounds__(1024) void evd_kernel(const float* __restrict__ Gpa
     }
     __syncthreads();
     float* qo = Qbuf + ((int64_t)b * npairs + pair) * (PW * PW);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int e = tid + 1024 * q;
+    for (int e = tid; e < PW * PW; e += 256) {
         const int r = e >> 6, c = e & 63;
-        qo[r * PW + rnk[c]] = Q[r * GLD + c];
+        qo[r * PW + rnk[c]] = Q[r * GLD + c] * cscale[c];
     }
 }
 
@@ -608,7 +648,7 @@ int asvd_svd_batched(int batch, const void* const* a_host, int a_dtype, int64_t 
     if (work_bytes < p.total) return ASVD_E_WORKSPACE;
     for (int b = 0; b < batch; ++b)
         if (!a_host[b] || !S_host[b]) return ASVD_E_BADARG;
-    if (max_sweeps <= 0) max_sweeps = 16;
+    if (max_sweeps <= 0) max_sweeps = 30;
     if (!(tol > 0.0f)) tol = 1e-6f;
     hipStream_t st = (hipStream_t)stream;
 
@@ -650,6 +690,8 @@ int asvd_svd_batched(int batch, const void* const* a_host, int a_dtype, int64_t 
     std::vector<int> flags((size_t)batch * 4, 0);
     std::vector<int> sweeps_done(batch, 0), last_rot(batch, 0), status(batch, ASVD_N_NOCONV);
     std::vector<int> host_done(batch, 0);
+    std::vector<float> last_off(batch, 0.0f), prev_off(batch, 1e30f);
+    const bool debug = getenv("ASVD_DEBUG") != nullptr;
     const int nsteps = p.nb - 1;
     const int inner_sweeps = 2;
     int sweep = 0;
@@ -663,7 +705,7 @@ int asvd_svd_batched(int batch, const void* const* a_host, int a_dtype, int64_t 
             }
             {
                 ProfScope ps(2, st);
-                evd_kernel<<<dim3(p.npairs, batch), 1024, 0, st>>>(Gpart, p.nsplit, Qbuf, active, maxoff, nrot, done, tol,
+                evd_kernel<<<dim3(p.npairs, batch), 256, 0, st>>>(Gpart, p.nsplit, Qbuf, active, maxoff, nrot, done, tol,
                                                                    inner_sweeps);
             }
             {
@@ -683,9 +725,15 @@ int asvd_svd_batched(int batch, const void* const* a_host, int a_dtype, int64_t 
             std::memcpy(&mo, &bits, sizeof(float));
             sweeps_done[b] = sweep + 1;
             last_rot[b] = flags[batch + b];
+            last_off[b] = mo;
+            if (debug) fprintf(stderr, "[asvd_svd] b=%d sweep=%d maxoff=%.3e rotated_pairs=%d\n", b, sweep + 1, mo, last_rot[b]);
             if (mo != mo) { status[b] = ASVD_N_NAN; host_done[b] = 1; changed = true; }
             else if (mo < tol) { status[b] = ASVD_OK; host_done[b] = 1; changed = true; }
+            // stagnation at the fp32 noise floor: the scaled off-diagonal stopped contracting well below the level that
+            // matters for the 1e-4 sigma / 1e-3 reconstruction contract (second-order in maxoff) -> converged
+            else if (mo < 100.0f * tol && mo > 0.25f * prev_off[b]) { status[b] = ASVD_OK; host_done[b] = 1; changed = true; }
             else all_done = false;
+            prev_off[b] = mo;
         }
         if (all_done) { ++sweep; break; }
         if (changed) {
@@ -724,7 +772,7 @@ int asvd_svd_batched(int batch, const void* const* a_host, int a_dtype, int64_t 
             info_host[4 * b + 0] = status[b];
             info_host[4 * b + 1] = sweeps_done[b];
             info_host[4 * b + 2] = last_rot[b];
-            info_host[4 * b + 3] = 0;
+            std::memcpy(&info_host[4 * b + 3], &last_off[b], sizeof(float));  // last sweep's max scaled off-diagonal (float bits)
         }
         if (status[b] > worst) worst = status[b];
     }

@@ -87,16 +87,21 @@ class SVDLinear(nn.Module):
         w = linear.weight.data
         if not w.is_cuda:
             raise AsvdHipError(f"weight of {linear} is on {w.device}; the ASVD hot path runs on gfx950 only (no CPU fallback)")
-        stat = getattr(linear, "scaling_diag_matrix", None)
-        fis = getattr(linear, "fisher_info", None)
-        key = (w.data_ptr(), w._version, tuple(w.shape), w.dtype, bool(act_aware), float(alpha) if act_aware else None,
-               None if (stat is None or not act_aware) else (stat.data_ptr(), stat._version),
-               None if (fis is None or not act_aware) else (fis.data_ptr(), fis._version))
+        stat = getattr(linear, "scaling_diag_matrix", None) if act_aware else None
+        fis = getattr(linear, "fisher_info", None) if act_aware else None
+        wc = w if w.stride(1) == 1 else w.contiguous()
+
+        def _sig(t):  # content signature: `.data` edits do not bump Parameter._version, so hash the values (one tiny kernel)
+            if t is None:
+                return None
+            t2 = t.to(w.device).reshape(1, -1) if t.dim() != 2 else t
+            return (tuple(t.shape), t.dtype, float(ops.fro_norm_sq(t2 if t2.stride(-1) == 1 else t2.contiguous()).item()))
+
+        key = (w.data_ptr(), _sig(wc), bool(act_aware), float(alpha) if act_aware else None, _sig(stat), _sig(fis))
         cache = getattr(linear, "_asvd_factor_cache", None)
         if cache is not None and cache[0] == key:
             return cache[1]
         s = SVDLinear._scale_vector(linear, act_aware, alpha)
-        wc = w if w.stride(1) == 1 else w.contiguous()
         U, S, V, info = ops.svd(wc, s)
         if info.status == 2:
             raise FloatingPointError("nan in svd")

@@ -16,6 +16,10 @@ def _ulp_close(got, want, dtype, n_ulp=1, frac_exact=0.98):
     nan_g, nan_w = torch.isnan(got64), torch.isnan(want64)
     assert torch.equal(nan_g, nan_w)
     fin = ~nan_w
+    if dtype == torch.float32:
+        # fp32 statistics: the sum itself is rounded in fp32 in a different order than torch's -> a few fp32 ulps, no bit claim
+        assert bool(((got64[fin] - want64[fin]).abs() <= 2e-6 * want64[fin].abs() + 1e-30).all())
+        return
     eps = torch.finfo(dtype).eps
     tol = n_ulp * eps * want64[fin].abs() + 1e-30
     assert bool(((got64[fin] - want64[fin]).abs() <= tol).all())
@@ -78,8 +82,13 @@ def test_make_scale_and_scale_cols(gpu, dtype, alpha):
     s_ref = O.make_scale(scal, alpha)
     s = ops.make_scale(scal.to(gpu), alpha=alpha)
     assert s.dtype == dtype
-    if alpha in (0.5, 1.0):
-        assert torch.equal(s.cpu(), s_ref)  # sqrt / identity are correctly rounded on both sides
+    if alpha == 1.0 or (alpha == 0.5 and dtype != torch.float32):
+        assert torch.equal(s.cpu(), s_ref)  # identity / sqrt rounded to a 16-bit dtype: bit exact
+    elif alpha == 0.5:
+        # fp32 sqrt: the kernel's is correctly rounded (fp64 sqrt rounded once); torch-CPU's float sqrt goes through MKL VML
+        # (HA mode, < 1 ulp but NOT correctly rounded), so the oracle itself is only defined to 1 ulp here
+        assert bool(((s.cpu().double() - s_ref.double()).abs() <= 1.2e-7 * s_ref.double().abs()).all())
+        assert torch.equal(s.cpu(), (scal.double().sqrt().float() + 1e-6))
     else:
         _ulp_close(s, s_ref, dtype, n_ulp=1, frac_exact=0.9)
     W = (torch.randn(130, 1000, generator=g) * 0.02).to(dtype)
@@ -107,13 +116,25 @@ def test_truncate_split_bit_exact(gpu, fuse, out_dtype):
     V = torch.randn(n, k, generator=g)
     S = torch.rand(k, generator=g).sort(descending=True).values * 10
     s = (torch.rand(n, generator=g) * 4 + 0.01).half()
+    def same(x, y):
+        if fuse != "UV":
+            return torch.equal(x.cpu(), y)  # mul / div only: bit exact
+        # "UV" takes sqrt(S): torch-CPU's fp32 sqrt (MKL VML) is 1-ulp, the kernel's is correctly rounded -> compare against
+        # the oracle evaluated with a correctly rounded sqrt (bit exact) and bound the distance to torch's own result
+        d = (x.cpu().double() - y.double()).abs()
+        return bool((d <= 2.5 * torch.finfo(out_dtype).eps * y.double().abs() + 1e-30).all())
+
     A_ref, B_ref, nan = O.truncate_split(U, S, V, s, r, fuse, out_dtype)
     A, B, flags = ops.truncate_split(U.to(gpu), S.to(gpu), V.to(gpu), s.to(gpu), r, fuse, out_dtype)
-    assert torch.equal(A.cpu(), A_ref) and torch.equal(B.cpu(), B_ref)
+    assert same(A, A_ref) and same(B, B_ref)
     assert flags.tolist() == [0, 0, 0] and nan == [False, False, False]
+    if fuse == "UV":  # bit-exact form: same operation order with sqrt correctly rounded
+        rs = S[:r].double().sqrt().float()
+        assert torch.equal(A.cpu(), (U[:, :r] * rs).to(out_dtype))
+        assert torch.equal(B.cpu(), ((V[:, :r] / s.view(-1, 1)).t() * rs.view(-1, 1)).contiguous().to(out_dtype))
     A, B, _ = ops.truncate_split(U.to(gpu), S.to(gpu), V.to(gpu), None, r, fuse, out_dtype)
     A_ref, B_ref, _ = O.truncate_split(U, S, V, None, r, fuse, out_dtype)
-    assert torch.equal(A.cpu(), A_ref) and torch.equal(B.cpu(), B_ref)
+    assert same(A, A_ref) and same(B, B_ref)
 
 
 def test_truncate_split_nan_flags(gpu):

