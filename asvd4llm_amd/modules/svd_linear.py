@@ -82,8 +82,9 @@ class SVDLinear(nn.Module):
         return ops.make_scale(scaling, None if fisher is None else fisher.to(dev), alpha=alpha, eps=1e-6)
 
     @staticmethod
-    def factorize(linear, act_aware=False, alpha=1):
-        """One exact SVD of W*diag(s) on the device, cached on the module.  Returns (U, S, V, s)."""
+    def _cache_key(linear, act_aware, alpha):
+        """(key, contiguous weight).  Content signature: `.data` edits do not bump Parameter._version, so the values are hashed
+        (sum of squares by the K8 kernel) - one tiny launch + one host sync per call."""
         w = linear.weight.data
         if not w.is_cuda:
             raise AsvdHipError(f"weight of {linear} is on {w.device}; the ASVD hot path runs on gfx950 only (no CPU fallback)")
@@ -91,23 +92,61 @@ class SVDLinear(nn.Module):
         fis = getattr(linear, "fisher_info", None) if act_aware else None
         wc = w if w.stride(1) == 1 else w.contiguous()
 
-        def _sig(t):  # content signature: `.data` edits do not bump Parameter._version, so hash the values (one tiny kernel)
+        def _sig(t):
             if t is None:
                 return None
             t2 = t.to(w.device).reshape(1, -1) if t.dim() != 2 else t
             return (tuple(t.shape), t.dtype, float(ops.fro_norm_sq(t2 if t2.stride(-1) == 1 else t2.contiguous()).item()))
 
         key = (w.data_ptr(), _sig(wc), bool(act_aware), float(alpha) if act_aware else None, _sig(stat), _sig(fis))
+        return key, wc
+
+    @staticmethod
+    def factorize(linear, act_aware=False, alpha=1, k=None):
+        """One exact SVD of W*diag(s) on the device, cached on the module.  Returns (U, S, V, s).
+        k: number of leading triplets needed (None = all).  A cached factorisation is reused when it holds >= k columns."""
+        key, wc = SVDLinear._cache_key(linear, act_aware, alpha)
+        kmax = min(wc.shape)
+        k = kmax if k is None else max(1, min(int(k), kmax))
         cache = getattr(linear, "_asvd_factor_cache", None)
-        if cache is not None and cache[0] == key:
+        if cache is not None and cache[0] == key and cache[1][1].numel() >= k:
             return cache[1]
         s = SVDLinear._scale_vector(linear, act_aware, alpha)
-        U, S, V, info = ops.svd(wc, s)
+        U, S, V, info = ops.svd(wc, s, k=k)
         if info.status == 2:
             raise FloatingPointError("nan in svd")
         linear._asvd_factor_cache = (key, (U, S, V, s))
         linear._asvd_svd_info = info
         return U, S, V, s
+
+    @staticmethod
+    def prefactorize(linears, act_aware=False, alpha=1, ranks=None, max_batch=16):
+        """Factorise many Linears up front, same-shape ones CONCURRENTLY (asvd_svd_batched): independent matrices are what
+        fills the 256 CUs during the 64-workgroup eigen-solve phase, and 288 GB of HBM hold the factors of a whole 7B/13B
+        shard.  ranks: optional {linear: largest rank needed} (convergence is then only enforced for those leading triplets).
+        Fills the same per-module cache `from_linear` uses; already cached layers are skipped."""
+        groups = {}
+        for lin in linears:
+            key, wc = SVDLinear._cache_key(lin, act_aware, alpha)
+            kmax = min(wc.shape)
+            k = kmax if not ranks or not ranks.get(lin) else max(1, min(int(ranks[lin]), kmax))
+            cache = getattr(lin, "_asvd_factor_cache", None)
+            if cache is not None and cache[0] == key and cache[1][1].numel() >= k:
+                continue
+            s = SVDLinear._scale_vector(lin, act_aware, alpha)
+            gk = (tuple(wc.shape), wc.dtype, wc.stride(0), wc.device, None if s is None else s.dtype)
+            groups.setdefault(gk, []).append((lin, key, wc, s, k))
+        for gk, items in groups.items():
+            for i in range(0, len(items), max_batch):
+                chunk = items[i:i + max_batch]
+                k = max(it[4] for it in chunk)
+                scs = None if chunk[0][3] is None else [it[3] for it in chunk]
+                U, S, V, infos = ops.svd_batched([it[2] for it in chunk], scs, k=k)
+                for j, (lin, key, wc, s, _) in enumerate(chunk):
+                    if infos[j].status == 2:
+                        continue  # from_linear will hit the NaN path itself
+                    lin._asvd_factor_cache = (key, (U[j], S[j], V[j], s))
+                    lin._asvd_svd_info = infos[j]
 
     @staticmethod
     def drop_factor_cache(linear):
@@ -135,7 +174,8 @@ class SVDLinear(nn.Module):
         try:
             if rank < 1 or rank > min(linear.in_features, linear.out_features):
                 raise ValueError(f"rank {rank} outside [1, min(in, out)]")  # torch.svd_lowrank(q=rank) raises too
-            U, S, V, s = SVDLinear.factorize(linear, act_aware, alpha)
+            hint = getattr(linear, "_asvd_rank_hint", None)  # set by the sweep: the largest rank it will ask for
+            U, S, V, s = SVDLinear.factorize(linear, act_aware, alpha, k=max(rank, hint) if hint else None)
         except (AsvdHipError, AttributeError):
             raise
         except Exception:

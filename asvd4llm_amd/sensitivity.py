@@ -61,6 +61,14 @@ def calib_sensitivity_ppl(model, calib_loader, args, use_cache=True):
 
     local = {}
     n_mine = sum(1 for o in owner if o == rank)
+    # one factorisation per layer serves every candidate ratio (and the final decomposition): record the largest rank needed
+    # and factorise this rank's layers up front, same-shape layers batched (keeps the GPU full; nothing is recomputed later)
+    mine = [l for (l, _), o in zip(linears, owner) if o == rank]
+    for l in mine:
+        l._asvd_rank_hint = max(SVDLinear.compute_rank(l, r, args.rank_align) for r in param_ratio_candidates)
+    if keep_cache and getattr(args, "prefactorize", True) and all(l.weight.is_cuda for l in mine):
+        SVDLinear.prefactorize(mine, act_aware=True, alpha=args.alpha, ranks={l: l._asvd_rank_hint for l in mine},
+                               max_batch=getattr(args, "svd_batch", 16))
     pbar = tqdm(total=n_mine * len(param_ratio_candidates), disable=(rank != 0))
     for (raw_linear, info), own in zip(linears, owner):
         if own != rank:

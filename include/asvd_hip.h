@@ -103,7 +103,9 @@ int asvd_scale_cols(const void* w, int w_dtype, int64_t m, int64_t n, int64_t ld
  *   U_host      host array [batch] of device pointers to U_b [m, k] row-major (NULL: no vectors)
  *   S_host      host array [batch] of device pointers to S_b [k] descending
  *   V_host      host array [batch] of device pointers to V_b [n, k] row-major (NULL: no vectors)
- *   k           number of leading singular triplets to write, 1 <= k <= min(m, n)
+ *   k           number of leading singular triplets to write, 1 <= k <= min(m, n).  Convergence (tol) is enforced for these
+ *               k leading triplets and their orthogonality against the rest; with k < min(m,n) the sweeps stop as soon as
+ *               the leading part is done (the discarded tail converges last and would cost 2-4 more sweeps)
  *   max_sweeps  <=0: default (30);  tol <=0: default (1e-6) on max |cos(a_i, a_j)|
  *   info_host   optional host int[4*batch]: {status, sweeps, rotated pairs in last sweep, float bits of the last sweep's max |cos|}
  * Host-synchronous (one stream sync per sweep).  Returns worst status over the batch.
