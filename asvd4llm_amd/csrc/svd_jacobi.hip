@@ -274,8 +274,15 @@ __global__ __launch_bounds__(256) void evd_kernel(const float* __restrict__ Gpar
     }
     __syncthreads();
 
-    // scaled off-diagonal measure: max |g_ij| / sqrt(g_ii g_jj), NaN propagating
-    float loc = 0.0f;
+    // scaled off-diagonal measure: max |g_ij| / sqrt(g_ii g_jj), NaN propagating.
+    // `loc` decides whether the pair rotates; `loct` (entries touching a LEADING panel, index < kb) is what termination
+    // looks at: the caller asked for k leading triplets, pair sorting keeps the largest columns in the lowest panels, and the
+    // leading columns only need to be orthogonal among themselves and to the tail's SPAN - tail-internal angles (the JJ block
+    // of a leading/tail pair, or a tail/tail pair) keep being rotated but no longer hold up termination.
+    int I, J;
+    rr_pair(nb, step, pair, I, J);
+    const bool topI = I < kb, topJ = J < kb;
+    float loc = 0.0f, loct = 0.0f;
     for (int e = tid; e < PW * PW; e += 256) {
         const int i = e >> 6, j = e & 63;
         if (i != j) {
@@ -284,39 +291,49 @@ __global__ __launch_bounds__(256) void evd_kernel(const float* __restrict__ Gpar
             float v = (dd > 0.0f) ? fabsf(g) * rsqrtf(dd) : 0.0f;
             if (g != g || dd != dd) v = __builtin_nanf("");
             loc = (v != v) ? v : ((loc != loc) ? loc : fmaxf(loc, v));
+            const bool lead = ((i < 32) ? topI : topJ) || ((j < 32) ? topI : topJ);
+            if (lead) {
+                // termination measure = rotation ANGLE scale |g_ij| / max(g_ii, g_jj) = cos * sqrt(min/max): a tiny column
+                // may keep a large cosine against a big one for many sweeps while the rotation it induces on the big
+                // column (and the error it leaves in its sigma / vector) is already negligible.  This gives the small
+                // singular values absolute accuracy eps*sigma_max (what LAPACK's bidiagonal SVD gives too) instead of
+                // chasing their relative accuracy for 3-4 extra sweeps.
+                const float mx = fmaxf(sdiag[0][i], sdiag[0][j]);
+                float vt = (mx > 0.0f) ? fabsf(g) / mx : 0.0f;
+                if (v != v) vt = v;
+                loct = (vt != vt) ? vt : ((loct != loct) ? loct : fmaxf(loct, vt));
+            }
         }
     }
+    __shared__ float redmax_t[4];
     {
-        float v = loc;
+        float v = loc, vt = loct;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const float u = __shfl_xor(v, o, 64);
             v = (u != u) ? u : ((v != v) ? v : fmaxf(v, u));
+            const float ut = __shfl_xor(vt, o, 64);
+            vt = (ut != ut) ? ut : ((vt != vt) ? vt : fmaxf(vt, ut));
         }
-        if ((tid & 63) == 0) redmax[tid >> 6] = v;
+        if ((tid & 63) == 0) { redmax[tid >> 6] = v; redmax_t[tid >> 6] = vt; }
     }
     __syncthreads();
-    float off0 = redmax[0];
+    float off0 = redmax[0], offt = redmax_t[0];
     for (int i = 1; i < 4; ++i) {
         const float u = redmax[i];
         off0 = (u != u) ? u : ((off0 != off0) ? off0 : fmaxf(off0, u));
+        const float ut = redmax_t[i];
+        offt = (ut != ut) ? ut : ((offt != offt) ? offt : fmaxf(offt, ut));
     }
     const bool is_nan = (off0 != off0);
-    // Convergence is only REQUIRED for the leading kb panels (the caller asked for k leading triplets; pair sorting keeps the
-    // largest columns in the lowest panels).  Pairs living entirely in the tail still rotate - that keeps the process a
-    // plain Jacobi iteration - but they no longer hold up termination: the leading columns only need to be orthogonal to
-    // the tail's SPAN, which tail-internal rotations do not change.
-    int I, J;
-    rr_pair(nb, step, pair, I, J);
-    const bool counts = is_nan || I < kb;
-    if (tid == 0 && counts) atomicMax(&maxoff_bits[b], is_nan ? 0x7fc00000u : __float_as_uint(off0));
+    if (tid == 0) atomicMax(&maxoff_bits[b], is_nan ? 0x7fc00000u : __float_as_uint(offt));
     if (is_nan || off0 < tol) {
         if (tid == 0) active[b * npairs + pair] = 0;
         return;
     }
     if (tid == 0) {
         active[b * npairs + pair] = 1;
-        if (counts) atomicAdd(&nrot[b], 1);
+        if (offt >= tol) atomicAdd(&nrot[b], 1);
     }
 
     const int g = tid >> 5, tx = tid & 31;

@@ -102,15 +102,17 @@ class SVDLinear(nn.Module):
         return key, wc
 
     @staticmethod
-    def factorize(linear, act_aware=False, alpha=1, k=None):
+    def factorize(linear, act_aware=False, alpha=1, k=None, k_compute=None):
         """One exact SVD of W*diag(s) on the device, cached on the module.  Returns (U, S, V, s).
-        k: number of leading triplets needed (None = all).  A cached factorisation is reused when it holds >= k columns."""
+        k: number of leading triplets needed now (None = all); a cached factorisation is reused when it holds >= k columns.
+        k_compute: how many to compute on a cache miss (None = all, so that any later rank is a slice of this one SVD)."""
         key, wc = SVDLinear._cache_key(linear, act_aware, alpha)
         kmax = min(wc.shape)
         k = kmax if k is None else max(1, min(int(k), kmax))
         cache = getattr(linear, "_asvd_factor_cache", None)
         if cache is not None and cache[0] == key and cache[1][1].numel() >= k:
             return cache[1]
+        k = kmax if k_compute is None else max(k, min(int(k_compute), kmax))
         s = SVDLinear._scale_vector(linear, act_aware, alpha)
         U, S, V, info = ops.svd(wc, s, k=k)
         if info.status == 2:
@@ -175,7 +177,7 @@ class SVDLinear(nn.Module):
             if rank < 1 or rank > min(linear.in_features, linear.out_features):
                 raise ValueError(f"rank {rank} outside [1, min(in, out)]")  # torch.svd_lowrank(q=rank) raises too
             hint = getattr(linear, "_asvd_rank_hint", None)  # set by the sweep: the largest rank it will ask for
-            U, S, V, s = SVDLinear.factorize(linear, act_aware, alpha, k=max(rank, hint) if hint else None)
+            U, S, V, s = SVDLinear.factorize(linear, act_aware, alpha, k=rank, k_compute=hint)
         except (AsvdHipError, AttributeError):
             raise
         except Exception:

@@ -34,9 +34,9 @@ def synth(size_m, size_n, seed, n_calib=32):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=4, help="matrices factorised concurrently per step and GPU")
+    ap.add_argument("--batch", type=int, default=16, help="matrices factorised concurrently per step and GPU")
     ap.add_argument("--m", type=int, default=4096)
     ap.add_argument("--n", type=int, default=4096)
     ap.add_argument("--rank", type=int, default=512)
