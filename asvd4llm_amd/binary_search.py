@@ -106,6 +106,12 @@ def binary_search_truncation_rank(model, sensitivity_dict, calib_loader, args):
     owner_list = parallel.lpt_assign([parallel.svd_flops(l.out_features, l.in_features) for l, _ in linears], ws)
     owner = {info["full_name"]: o for (_, info), o in zip(linears, owner_list)}
 
+    # tied weights (OPT: lm_head.weight IS embed_tokens.weight): the reference's `raw_linear.to("cpu")` would drag the embedding to the
+    # CPU with it and break the next forward; only offload weights no other module shares
+    uses = {}
+    for _, prm in model.named_parameters(remove_duplicate=False):
+        uses[id(prm)] = uses.get(id(prm), 0) + 1
+
     st = time.time()
     for layername, param_ratio in tqdm(layers_min_ratio.items(), disable=(rank != 0)):
         raw_linear = module_dict[layername]
@@ -124,7 +130,7 @@ def binary_search_truncation_rank(model, sensitivity_dict, calib_loader, args):
                 rank_align=args.rank_align,
             )
             SVDLinear.drop_factor_cache(raw_linear)
-            if getattr(args, "offload_raw_to_cpu", True):
+            if getattr(args, "offload_raw_to_cpu", True) and uses.get(id(raw_linear.weight), 1) <= 1:
                 raw_linear.to("cpu")  # binary_search.py:127
         setattr(info["father"], info["name"], svd_linear)
     if torch.cuda.is_available():

@@ -11,9 +11,9 @@ NAMED = {
     "llama-2-13b": ("llama", dict(hidden_size=5120, intermediate_size=13824, num_hidden_layers=40, num_attention_heads=40,
                                   num_key_value_heads=40, vocab_size=32000, max_position_embeddings=4096)),
     "tiny-llama": ("llama", dict(hidden_size=128, intermediate_size=352, num_hidden_layers=2, num_attention_heads=4,
-                                 num_key_value_heads=4, vocab_size=512, max_position_embeddings=256)),
+                                 num_key_value_heads=4, vocab_size=512, max_position_embeddings=2048)),
     "tiny-opt": ("opt", dict(hidden_size=128, ffn_dim=512, num_hidden_layers=2, num_attention_heads=4, vocab_size=512,
-                             word_embed_proj_dim=128, max_position_embeddings=256)),
+                             word_embed_proj_dim=128, max_position_embeddings=2048)),
 }
 
 

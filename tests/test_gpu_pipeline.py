@@ -151,3 +151,54 @@ def test_full_pipeline_vs_reference_run(gpu, golden, tmp_path, monkeypatch):
     assert abs(ppl - rec["ppl_after"]) <= 2e-4 * rec["ppl_after"]
     sd = model.state_dict()
     assert any(k.endswith("ALinear.weight") for k in sd) and any(k.endswith("BLinear.weight") for k in sd)
+
+
+def test_prefactorize_batches_same_shape_layers(gpu):
+    """model-level batching: same-shape Linears are factorised concurrently and land in the cache from_linear uses"""
+    from asvd4llm_amd import ops
+    from asvd4llm_amd.modules.svd_linear import SVDLinear
+    torch.manual_seed(0)
+    lins = []
+    for i in range(5):
+        l = nn.Linear(96, 160, bias=False).half().to(gpu)
+        l.scaling_diag_matrix = (torch.rand(96, device=gpu) * 4).half()
+        lins.append(l)
+    odd = nn.Linear(160, 96, bias=False).half().to(gpu)
+    odd.scaling_diag_matrix = (torch.rand(160, device=gpu) * 4).half()
+    lins.append(odd)
+    calls = []
+    real = ops.svd_batched
+
+    def counting(mats, *a, **k):
+        calls.append(len(mats))
+        return real(mats, *a, **k)
+
+    ops.svd_batched = counting
+    try:
+        ranks = {l: SVDLinear.compute_rank(l, 0.9) for l in lins}
+        SVDLinear.prefactorize(lins, act_aware=True, alpha=0.5, ranks=ranks, max_batch=4)
+        assert sorted(calls) == [1, 1, 4]
+        n = len(calls)
+        for l in lins:
+            m = SVDLinear.from_linear(l, 0.6, act_aware=True, alpha=0.5)  # smaller rank: a slice of the cached factors
+            assert isinstance(m, SVDLinear)
+            o = O.from_linear_oracle(l.weight.data.cpu(), l.scaling_diag_matrix.cpu(), 0.6, alpha=0.5, act_aware=True)
+            e_live, e_scaled = O.recon_parity(m.ALinear.weight.data, m.BLinear.weight.data, o["A"], o["B"], l.weight.data.cpu(), o["s"])
+            assert e_live <= 3e-3 and e_scaled <= 3e-3
+        assert len(calls) == n  # no re-factorisation
+    finally:
+        ops.svd_batched = real
+
+
+def test_topk_request_converges_leading_part(gpu):
+    from asvd4llm_amd import ops
+    from tests.test_gpu_svd import llm_like
+    W, s = llm_like(768, 768)
+    So = torch.linalg.svdvals(O.scaled_weight(W, s))
+    U, S, V, info = ops.svd(W.to(gpu), s.to(gpu), k=200)
+    Uf, Sf, Vf, info_f = ops.svd(W.to(gpu), s.to(gpu))
+    assert info.status == 0 and info.sweeps <= info_f.sweeps
+    assert O.sigma_rel_err(S.cpu(), So, 200) <= 1e-4
+    R = (U.double() * S.double()) @ V.double().T
+    Rf = (Uf[:, :200].double() * Sf[:200].double()) @ Vf[:, :200].double().T
+    assert ((R - Rf).norm() / Rf.norm()).item() <= 1e-4
