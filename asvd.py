@@ -73,6 +73,10 @@ def main(args):
     with open("output/result.txt", "a+") as f:
         f.write(f"{args}\n")
         f.write(f"{result}\n")
+    if args.dist:
+        import torch.distributed as dist
+        if dist.is_initialized():
+            dist.destroy_process_group()
 
 
 def build_parser():

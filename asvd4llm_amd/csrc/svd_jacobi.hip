@@ -868,22 +868,28 @@ int asvd_svd_batched(int batch, const void* const* a_host, int a_dtype, int64_t 
     int sweep = 0;
     // Independent problems of a batch are split into two groups driven on two internal streams: while one group sits in its
     // LDS/VALU-bound evd phase the other streams panels through its HBM-bound gram/update phase (different resources).
-    const int ngroups = (batch >= 8 && !getenv("ASVD_ONE_STREAM")) ? 2 : 1;
-    hipStream_t gst[2] = {st, st};
-    int gb0[2] = {0, 0}, gnb[2] = {batch, 0};
-    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
-    if (ngroups == 2) {
-        static hipStream_t s_streams[2] = {nullptr, nullptr};
-        for (int g = 0; g < 2; ++g)
+    constexpr int MAXG = 4;
+    int ngroups = (batch >= 8 && !getenv("ASVD_ONE_STREAM")) ? 2 : 1;
+    if (getenv("ASVD_GROUPS")) ngroups = atoi(getenv("ASVD_GROUPS"));
+    if (ngroups < 1) ngroups = 1;
+    if (ngroups > MAXG) ngroups = MAXG;
+    if (ngroups > batch) ngroups = batch;
+    hipStream_t gst[MAXG] = {st, st, st, st};
+    int gb0[MAXG] = {0, 0, 0, 0}, gnb[MAXG] = {batch, 0, 0, 0};
+    hipEvent_t ev_fork = nullptr, ev_join[MAXG] = {nullptr, nullptr, nullptr, nullptr};
+    if (ngroups >= 2) {
+        static hipStream_t s_streams[MAXG] = {nullptr, nullptr, nullptr, nullptr};
+        int off = 0;
+        for (int g = 0; g < ngroups; ++g) {
             if (!s_streams[g]) ASVD_HIP_CHECK(hipStreamCreateWithFlags(&s_streams[g], hipStreamNonBlocking));
-        gst[0] = s_streams[0];
-        gst[1] = s_streams[1];
-        gnb[0] = (batch + 1) / 2;
-        gb0[1] = gnb[0];
-        gnb[1] = batch - gnb[0];
+            gst[g] = s_streams[g];
+            gnb[g] = batch / ngroups + (g < batch % ngroups ? 1 : 0);
+            gb0[g] = off;
+            off += gnb[g];
+        }
         ASVD_HIP_CHECK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
         ASVD_HIP_CHECK(hipEventRecord(ev_fork, st));
-        for (int g = 0; g < 2; ++g) {
+        for (int g = 0; g < ngroups; ++g) {
             ASVD_HIP_CHECK(hipStreamWaitEvent(gst[g], ev_fork, 0));
             ASVD_HIP_CHECK(hipEventCreateWithFlags(&ev_join[g], hipEventDisableTiming));
         }
@@ -918,8 +924,8 @@ int asvd_svd_batched(int batch, const void* const* a_host, int a_dtype, int64_t 
                 }
             }
         }
-        if (ngroups == 2) {
-            for (int g = 0; g < 2; ++g) {
+        if (ngroups >= 2) {
+            for (int g = 0; g < ngroups; ++g) {
                 ASVD_HIP_CHECK(hipEventRecord(ev_join[g], gst[g]));
                 ASVD_HIP_CHECK(hipStreamWaitEvent(st, ev_join[g], 0));
             }
@@ -954,10 +960,9 @@ int asvd_svd_batched(int batch, const void* const* a_host, int a_dtype, int64_t 
         }
     }
 
-    if (ngroups == 2) {
+    if (ngroups >= 2) {
         (void)hipEventDestroy(ev_fork);
-        (void)hipEventDestroy(ev_join[0]);
-        (void)hipEventDestroy(ev_join[1]);
+        for (int g = 0; g < ngroups; ++g) (void)hipEventDestroy(ev_join[g]);
     }
 
     // ---- finalize ----

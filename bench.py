@@ -157,13 +157,19 @@ def main():
                 times.append(time.perf_counter() - t1)
             times = sorted(times[1:])
             tcpu = times[len(times) // 2]
+            # what the reference literally calls (modules/svd_linear.py:65): randomized torch.svd_lowrank(q=rank), one run
+            t1 = time.perf_counter()
+            torch.manual_seed(233)
+            torch.svd_lowrank(O.scaled_weight(W0, s0), q=r)
+            t_lowrank = time.perf_counter() - t1
             r9 = int(m * n * 0.9) // (m + n)
             serr = O.sigma_rel_err(S[0].cpu(), So, r9)
             A_g, B_g, _ = outs[0]
             rerr, rerr_scaled = O.recon_parity(A_g, B_g, Ao, Bo, W0, s0)
             out["cpu_baseline"] = {"value": 1.0 / tcpu, "unit": "SVD/s", "cores": torch.get_num_threads(), "kind": "port",
                                    "sample": f"{args.cpu_reps} reps (median) after 1 warm-up of oracle scale+torch.linalg.svd(gesdd)+truncate/split on one {m}x{n} matrix of the batch",
-                                   "seconds_per_svd": tcpu, "host_cpu_count": os.cpu_count()}
+                                   "seconds_per_svd": tcpu, "host_cpu_count": os.cpu_count(),
+                                   "seconds_torch_svd_lowrank_q_rank": t_lowrank}
             out["parity"] = {"sigma_rel_err_top_r": serr, "r": r9, "recon_fro_err_rank512_vs_oracle": rerr, "recon_fro_err_scaled_norm": rerr_scaled, "tolerance": {"sigma": 1e-4, "recon": 1e-3}}
         print(json.dumps(out))
     if world > 1:
