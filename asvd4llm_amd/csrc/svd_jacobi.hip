@@ -19,6 +19,7 @@
 #include <cstring>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 
 namespace {
 
@@ -195,21 +196,22 @@ __global__ __launch_bounds__(256) void gram_kernel(const float* __restrict__ X, 
 // Every thread recomputes the four rotations it needs from the OLD matrix (G is ping-ponged between two LDS images), so
 // a step costs ONE barrier and no serialized "compute rotations" phase.  Pair tables are precomputed in LDS.
 __device__ __forceinline__ void jacobi_rot(float a, float d, float b, float& c, float& s, float& t) {
-    c = 1.0f; s = 0.0f; t = 0.0f;
+    // branch-free: b == 0 gives zeta = +-inf -> t = 0, c = 1, s = 0 by itself; a or d <= 0 (empty column) is masked at the end
     const float cosv = b * __builtin_amdgcn_rsqf(a) * __builtin_amdgcn_rsqf(d);  // |cos| of the two columns
-    if (fabsf(cosv) > 1e-8f) {
-        const float zeta = (d - a) * __builtin_amdgcn_rcpf(2.0f * b);
-        t = copysignf(1.0f, zeta) * __builtin_amdgcn_rcpf(fabsf(zeta) + __builtin_amdgcn_sqrtf(fmaf(zeta, zeta, 1.0f)));
-        c = __builtin_amdgcn_rsqf(fmaf(t, t, 1.0f));
-        s = t * c;
-        // unit-norm correction: delta = c^2 + s^2 - 1 via FMAs is accurate far below one ulp, so after scaling by
-        // (1 - delta/2) only the unbiased rounding of c and s themselves remains (no systematic norm drift; the
-        // hardware rcp/rsq approximations above only perturb the ANGLE, which the next visit corrects).
-        const float delta = fmaf(s, s, fmaf(c, c, -1.0f));
-        const float hd = 0.5f * delta;
-        c = fmaf(-c, hd, c);
-        s = fmaf(-s, hd, s);
-    }
+    const float zeta = (d - a) * __builtin_amdgcn_rcpf(2.0f * b);
+    float tt = copysignf(1.0f, zeta) * __builtin_amdgcn_rcpf(fabsf(zeta) + __builtin_amdgcn_sqrtf(fmaf(zeta, zeta, 1.0f)));
+    float cc = __builtin_amdgcn_rsqf(fmaf(tt, tt, 1.0f));
+    float ss = tt * cc;
+    // unit-norm correction: delta = c^2 + s^2 - 1 via FMAs is accurate far below one ulp, so after scaling by (1 - delta/2)
+    // only the unbiased rounding of c and s themselves remains (no systematic norm drift; the hardware rcp/rsq
+    // approximations above only perturb the ANGLE, which the next visit corrects).
+    const float hd = 0.5f * fmaf(ss, ss, fmaf(cc, cc, -1.0f));
+    cc = fmaf(-cc, hd, cc);
+    ss = fmaf(-ss, hd, ss);
+    const bool rot = fabsf(cosv) > 1e-8f;  // false for NaN (zero / negative diagonal) as well
+    c = rot ? cc : 1.0f;
+    s = rot ? ss : 0.0f;
+    t = rot ? tt : 0.0f;
 }
 
 // LDS image: element (row r, position c) lives at r*64 + pcol(c), pcol(c) = (c&1)*32 + (c>>1)  ("plane-major" columns:
@@ -224,7 +226,7 @@ __device__ __forceinline__ int pcol(int c) { return ((c & 1) << 5) | (c >> 1); }
 // Thread (g, tx): column pair tx, row pairs 4g..4g+3 (4 blocks of G), rows 8g..8g+7 of Q's column pair tx.
 // Each lane computes the rotation of ITS column pair from a small side array (diagonal + pivot off-diagonals, ping-ponged);
 // the four row-pair rotations are the ones lanes 4g..4g+3 of the same half-wave just computed -> fetched with ds_bpermute.
-__global__ __launch_bounds__(256) void evd_kernel(const float* __restrict__ Gpart, int nsplit, float* __restrict__ Qbuf,
+__global__ __launch_bounds__(256, 4) void evd_kernel(const float* __restrict__ Gpart, int nsplit, float* __restrict__ Qbuf,
                                                    int* __restrict__ active, unsigned* __restrict__ maxoff_bits,
                                                    int* __restrict__ nrot, const int* __restrict__ done, float tol,
                                                    int inner_sweeps, int nb, int step, int kb) {
@@ -267,7 +269,6 @@ __global__ __launch_bounds__(256) void evd_kernel(const float* __restrict__ Gpar
             const int e = tid + 256 * q;
             const int i = e >> 6, j = e & 63;
             G[i * PW + pcol(j)] = acc[q];
-            Q[i * PW + pcol(j)] = (i == j) ? 1.0f : 0.0f;
             if (i == j) sdiag[0][i] = acc[q];
             if (j == i + 1 && (i & 1) == 0) sb[0][i >> 1] = acc[q];  // phase A pivots G[2k][2k+1]
         }
@@ -339,7 +340,13 @@ __global__ __launch_bounds__(256) void evd_kernel(const float* __restrict__ Gpar
     const int g = tid >> 5, tx = tid & 31;
     const int half_base = tid & 32;  // first lane of this half-wave within the wave
     // a nearly diagonal pair needs one sweep (quadratic convergence finishes the job at the next visit)
-    const int nsw = min((off0 > 0.05f) ? 2 : 1, inner_sweeps);
+    const int nsw = (off0 > 0.05f) ? inner_sweeps : min(1, inner_sweeps);
+    float qa[8], qb[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        qa[r] = (8 * g + r == 2 * tx) ? 1.0f : 0.0f;
+        qb[r] = (8 * g + r == 2 * tx + 1) ? 1.0f : 0.0f;
+    }
     int cur = 0;
     for (int ph = 0; ph < nsw * PW; ++ph) {
         const int par = ph & 1;
@@ -355,6 +362,7 @@ __global__ __launch_bounds__(256) void evd_kernel(const float* __restrict__ Gpar
         const float al = col_idle ? 1.0f : s, be = col_idle ? 0.0f : c, ga = col_idle ? 0.0f : c, de = col_idle ? 1.0f : -s;
         const int acp = pcol(cp), acq = pcol(cq);
         const int nxt = cur ^ 1;
+        float piv_p = 0.0f, piv_q = 0.0f, nb_val = 0.0f;  // new diagonal of my pivot block, next pivot off-diagonal I produce
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int a = 4 * g + u;  // row pair index
@@ -370,40 +378,72 @@ __global__ __launch_bounds__(256) void evd_kernel(const float* __restrict__ Gpar
             const float y10 = rga * x00 + rde * x10, y11 = rga * x01 + rde * x11;
             float z00 = al * y00 + be * y01, z01 = ga * y00 + de * y01;
             float z10 = al * y10 + be * y11, z11 = ga * y10 + de * y11;
-            if (a == tx && !col_idle) {  // pivot block: exact update, annihilated off-diagonal; swapped diagonal
-                z00 = dd + t * bb;       // position p now holds the rotated q: d' = d + t b
-                z11 = da - t * bb;       // position q holds a' = a - t b
-                z01 = 0.0f;
-                z10 = 0.0f;
-                sdiag[nxt][cp] = z00;
-                sdiag[nxt][cq] = z11;
-            }
+            // pivot block: exact update, annihilated off-diagonal, swapped diagonal (position p now holds the rotated q:
+            // d' = d + t b; position q holds a' = a - t b)
+            const bool pivot = (a == tx) && !col_idle;
+            z00 = pivot ? dd + t * bb : z00;
+            z11 = pivot ? da - t * bb : z11;
+            z01 = pivot ? 0.0f : z01;
+            z10 = pivot ? 0.0f : z10;
+            piv_p = pivot ? z00 : piv_p;
+            piv_q = pivot ? z11 : piv_q;
+            nb_val = (tx == ((a + 1) & 31)) ? z10 : nb_val;
             G[rp * PW + acp] = z00;
             G[rp * PW + acq] = z01;
             G[rq * PW + acp] = z10;
             G[rq * PW + acq] = z11;
-            // next phase's pivot off-diagonals: element (rq, cp) of the block whose column pair is (row pair + 1) mod 32
-            if (tx == ((a + 1) & 31)) {
-                // after phase A (par 0): next pivots are B pairs k = a (positions 2a+1, 2a+2), k <= 30
-                // after phase B (par 1): next pivots are A pairs k = a + 1 mod 32 (positions 2k, 2k+1)
-                if (par == 0) { if (a < 31) sb[nxt][a] = z10; }
-                else sb[nxt][(a + 1) & 31] = z10;
+        }
+        // side arrays for the next phase (one predicated region per thread instead of one per block):
+        //   diagonal from the pivot block (row pair tx lives in thread group tx/4);
+        //   next pivot off-diagonal = element (rq, cp) of the block whose column pair is (row pair + 1) mod 32:
+        //     after phase A the next pivots are the B pairs k = a (positions 2a+1, 2a+2), k <= 30,
+        //     after phase B the A pairs k = a + 1 mod 32 (positions 2k, 2k+1).
+        if ((tx >> 2) == g && !col_idle) {
+            sdiag[nxt][cp] = piv_p;
+            sdiag[nxt][cq] = piv_q;
+        }
+        {
+            const int a_nb = (tx + 31) & 31;  // the row pair a with tx == a + 1 (mod 32)
+            if ((a_nb >> 2) == g) {
+                if (par == 0) { if (a_nb < 31) sb[nxt][a_nb] = nb_val; }
+                else sb[nxt][tx] = nb_val;
             }
         }
         if (par && tid == 0) {  // idle positions keep their diagonal; idle B pair has no pivot
             sdiag[nxt][63] = sdiag[cur][63];
             sdiag[nxt][0] = sdiag[cur][0];
         }
+        // eigenvector accumulation in REGISTERS: lane tx keeps rows 8g..8g+7 of the columns at positions 2tx (qa) and 2tx+1 (qb).
+        // Phase A rotates (qa, qb) in place.  Phase B pairs positions (2tx+1, 2tx+2): qb with the qa of lane tx+1, fetched and
+        // handed back with DPP wave shifts (VALU data path: the LDS, which bounds this kernel, is left to G alone).
+        if (par == 0) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int row = 8 * g + r;
-            const float u0 = Q[row * PW + acp], v0 = Q[row * PW + acq];
-            Q[row * PW + acp] = al * u0 + be * v0;
-            Q[row * PW + acq] = ga * u0 + de * v0;
+            for (int r = 0; r < 8; ++r) {
+                const float u0 = qa[r], v0 = qb[r];
+                qa[r] = al * u0 + be * v0;
+                qb[r] = ga * u0 + de * v0;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const float v0 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(qa[r]), 0x130 /*wave_shl:1: from lane+1*/, 0xF, 0xF, false));
+                const float u0 = qb[r];
+                qb[r] = al * u0 + be * v0;                 // position 2tx+1
+                const float back = ga * u0 + de * v0;      // position 2tx+2 -> lane tx+1's qa (identity on the idle lane 31)
+                const float recv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(back), 0x138 /*wave_shr:1: from lane-1*/, 0xF, 0xF, false));
+                qa[r] = (tx == 0) ? qa[r] : recv;          // position 0 is idle in phase B
+            }
         }
         __syncthreads();
         cur = nxt;
     }
+    // eigenvectors to LDS (plane-major image) for the normalisation / sort / store epilogue
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        Q[(8 * g + r) * PW + pcol(2 * tx)] = qa[r];
+        Q[(8 * g + r) * PW + pcol(2 * tx + 1)] = qb[r];
+    }
+    __syncthreads();
 
     // column norms of Q in double (4 threads x 16 rows per column): Q's columns are renormalised to unit length so
     // that the accumulated rounding of ~64-128 rotations per column cannot drift the norms of the updated panels.
@@ -657,6 +697,296 @@ __global__ __launch_bounds__(256) void gather_kernel(const float* __restrict__ X
     }
 }
 
+// ==================================================================================================
+// Tall problems (rows >= 1.5 cols): reduce to a square one first.   X = Q R  (Cholesky-QR with the Gram matrix and the
+// factorisation in FP64),  R = U_R S V^T by the block Jacobi above (cols x cols instead of rows x cols per step),  left
+// vectors  U = X V S^-1  by one fp32 MFMA GEMM.  FP64 keeps the squared condition number harmless: products of fp32 entries
+// are exact in fp64, so R carries a relative error ~1e-16 cond(X)^2 — below fp32 eps up to cond 3e4 — and the Gram matrix is
+// scaled to unit diagonal before the factorisation, which removes column scaling (the activation scales s!) from cond.
+// A non-positive pivot (rank deficiency / cond too large) makes the caller fall back to the direct path.
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+// G[b][I*32.., J*32..] (upper blocks, I <= J) = X_I^T X_J in fp64 with v_mfma_f64_16x16x4_f64.  One wave per 32x32 block,
+// whole K range (no split, no reduction: deterministic).  The 4 waves of a workgroup share panel I through L1.
+__global__ __launch_bounds__(256) void gram64_kernel(const float* __restrict__ X, int64_t panel_stride, int64_t batch_stride, int nb,
+                                                     int m_pad, double* __restrict__ G, int64_t ldg, int64_t g_batch_stride) {
+    const int I = blockIdx.x, jg = blockIdx.y, b = blockIdx.z;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int J = jg * 4 + w;
+    if (J < I || J >= nb) return;
+    const int kk = lane >> 4, cc = lane & 15;
+    const float* __restrict__ pi = X + (int64_t)b * batch_stride + (int64_t)I * panel_stride + kk * PB + cc;
+    const float* __restrict__ pj = X + (int64_t)b * batch_stride + (int64_t)J * panel_stride + kk * PB + cc;
+    f64x4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) acc[a][c] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    for (int r0 = 0; r0 < m_pad; r0 += 16) {  // m_pad is a multiple of 32
+        float ai[4][2], bj[4][2];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t off = (int64_t)(r0 + 4 * u) * PB;
+            ai[u][0] = pi[off]; ai[u][1] = pi[off + 16];
+            bj[u][0] = pj[off]; bj[u][1] = pj[off + 16];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+                    acc[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)ai[u][a], (double)bj[u][c], acc[a][c], 0, 0, 0);
+    }
+    double* __restrict__ out = G + (int64_t)b * g_batch_stride;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = I * PB + a * 16 + kk + 4 * q, col = J * PB + c * 16 + cc;
+                out[(int64_t)row * ldg + col] = acc[a][c][q];
+            }
+}
+
+__global__ void chol_diag_kernel(const double* __restrict__ G, int64_t ldg, int64_t g_batch_stride, int n_pad, double* __restrict__ d) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (j >= n_pad) return;
+    const double g = G[(int64_t)b * g_batch_stride + (int64_t)j * ldg + j];
+    d[(int64_t)b * n_pad + j] = g > 0.0 ? sqrt(g) : 0.0;
+}
+// unit-diagonal scaling of the upper triangle; empty columns (d = 0) become unit vectors so that the factorisation proceeds
+__global__ void chol_scale_kernel(double* __restrict__ G, int64_t ldg, int64_t g_batch_stride, int n_pad, const double* __restrict__ d) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y, b = blockIdx.z;
+    if (j >= n_pad || j < i) return;
+    const double di = d[(int64_t)b * n_pad + i], dj = d[(int64_t)b * n_pad + j];
+    double* g = G + (int64_t)b * g_batch_stride + (int64_t)i * ldg + j;
+    if (i == j) *g = 1.0;
+    else *g = (di > 0.0 && dj > 0.0) ? *g / (di * dj) : 0.0;
+}
+
+constexpr int CB = 64;        // Cholesky block size
+constexpr int CLD = CB + 1;   // LDS leading dimension (doubles)
+
+// Block step jb of the right-looking upper Cholesky  G = R^T R  (in place, fp64).  Every workgroup factors the 64x64 diagonal
+// block in LDS (redundantly: ~64 short steps) and inverts it; workgroup 0 stores R_jj, workgroup q >= 1 forms the block
+// R_{jb, jb+q} = R_jj^-T G_{jb, jb+q}.
+__global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ G, int64_t ldg, int64_t g_batch_stride, int jb,
+                                                         int* __restrict__ fail, double* __restrict__ Dg, int nbk) {
+    __shared__ double A[CB * CLD];
+    __shared__ double Ri[CB * CLD];
+    __shared__ double Bs[CB * CLD];
+    const int q = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    double* Gb = G + (int64_t)b * g_batch_stride;
+    const int64_t o = (int64_t)jb * CB;
+    for (int e = tid; e < CB * CB; e += 256) {
+        const int i = e >> 6, j = e & 63;
+        A[i * CLD + j] = (j >= i) ? Gb[(o + i) * ldg + o + j] : 0.0;
+        Ri[i * CLD + j] = 0.0;
+    }
+    __syncthreads();
+    bool bad = false;
+    for (int c = 0; c < CB; ++c) {
+        double piv = A[c * CLD + c];
+        if (!(piv > 1e-13)) { bad = true; piv = 1e-13; }  // unit-diagonal scaling: pivots live in (0, 1]
+        const double r = sqrt(piv), rinv = 1.0 / r;
+        __syncthreads();
+        if (tid == 0) A[c * CLD + c] = r;
+        for (int k = c + 1 + tid; k < CB; k += 256) A[c * CLD + k] *= rinv;
+        __syncthreads();
+        // trailing update of the upper triangle: A[i][k] -= R[c][i] R[c][k], c < i <= k
+        const int rem = CB - 1 - c;
+        for (int e = tid; e < rem * rem; e += 256) {
+            const int i = c + 1 + e / rem, k = c + 1 + e % rem;
+            if (k >= i) A[i * CLD + k] -= A[c * CLD + i] * A[c * CLD + k];
+        }
+        __syncthreads();
+    }
+    if (bad && tid == 0) atomicMax(&fail[b], 1000 * (q + 1) + jb + 1);
+    // inverse of the upper triangular R_jj: thread j solves R z = e_j by back substitution
+    if (tid < CB) {
+        const int j = tid;
+        Ri[j * CLD + j] = 1.0 / A[j * CLD + j];
+        for (int i = j - 1; i >= 0; --i) {
+            double acc = 0.0;
+            for (int k = i + 1; k <= j; ++k) acc += A[i * CLD + k] * Ri[k * CLD + j];
+            Ri[i * CLD + j] = -acc / A[i * CLD + i];
+        }
+    }
+    __syncthreads();
+    if (q == 0) {
+        // R_jj goes to a side buffer: the other workgroups of this step may still be loading the unfactored A_jj from G
+        double* dgo = Dg + ((int64_t)b * nbk + jb) * (CB * CB);
+        for (int e = tid; e < CB * CB; e += 256) {
+            const int i = e >> 6, j = e & 63;
+            dgo[e] = (j >= i) ? A[i * CLD + j] : 0.0;
+        }
+        return;
+    }
+    const int64_t oc = (int64_t)(jb + q) * CB;
+    for (int e = tid; e < CB * CB; e += 256) {
+        const int i = e >> 6, j = e & 63;
+        Bs[i * CLD + j] = Gb[(o + i) * ldg + oc + j];
+    }
+    __syncthreads();
+    // Y = Ri^T B :  Y[i][c] = sum_{k <= i} Ri[k][i] B[k][c]
+    for (int e = tid; e < CB * CB; e += 256) {
+        const int i = e >> 6, c = e & 63;
+        double acc = 0.0;
+        for (int k = 0; k <= i; ++k) acc += Ri[k * CLD + i] * Bs[k * CLD + c];
+        Gb[(o + i) * ldg + oc + c] = acc;
+    }
+}
+
+// trailing update  G_{ib,kb} -= R_{jb,ib}^T R_{jb,kb}  (jb < ib <= kb), fp64 MFMA, one workgroup per 64x64 block
+__global__ __launch_bounds__(256) void chol_syrk_kernel(double* __restrict__ G, int64_t ldg, int64_t g_batch_stride, int jb, int nbk) {
+    const int ib = jb + 1 + blockIdx.x, kb = jb + 1 + blockIdx.y, b = blockIdx.z;
+    if (kb < ib || kb >= nbk) return;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int kk = lane >> 4, cc = lane & 15;
+    double* Gb = G + (int64_t)b * g_batch_stride;
+    const double* __restrict__ Ra = Gb + ((int64_t)jb * CB + kk) * ldg + (int64_t)ib * CB + w * 16 + cc;  // wave w: rows tile w of the block
+    const double* __restrict__ Rb = Gb + ((int64_t)jb * CB + kk) * ldg + (int64_t)kb * CB + cc;
+    f64x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = (f64x4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+    for (int k0 = 0; k0 < CB; k0 += 4) {
+        const double a = Ra[(int64_t)k0 * ldg];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Rb[(int64_t)k0 * ldg + t * 16], acc[t], 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t row = (int64_t)ib * CB + w * 16 + kk + 4 * q, col = (int64_t)kb * CB + t * 16 + cc;
+            Gb[row * ldg + col] -= acc[t][q];
+        }
+}
+
+// R (fp32, dense [n_pad][n_pad], zero below the diagonal) = Rs * diag(d);  transposed != 0 writes R^T instead
+__global__ void r_to_f32_kernel(const double* __restrict__ G, int64_t ldg, int64_t g_batch_stride, const double* __restrict__ Dg,
+                                const double* __restrict__ d, int n_pad, int transposed, float* __restrict__ R, int64_t r_batch_stride) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y, b = blockIdx.z;
+    if (j >= n_pad) return;
+    double rv = 0.0;
+    if (j >= i) {
+        if ((i / CB) == (j / CB)) rv = Dg[((int64_t)b * (n_pad / CB) + i / CB) * (CB * CB) + (i % CB) * CB + (j % CB)];  // diagonal blocks
+        else rv = G[(int64_t)b * g_batch_stride + (int64_t)i * ldg + j];
+    }
+    const double v = rv * d[(int64_t)b * n_pad + j];
+    float* Rb = R + (int64_t)b * r_batch_stride;
+    if (!transposed) Rb[(int64_t)i * n_pad + j] = (float)v;
+    else Rb[(int64_t)j * n_pad + i] = (float)v;
+}
+
+// out[rows, k] = X[rows, cols] * Vr[cols, k] * diag(1 / S)   — left vectors of the tall problem from the packed panels.
+// Workgroup tile 128 x 128; wave w owns rows 32w..32w+31; per panel: A tile through a private padded LDS image (row-per-lane
+// b128 reads), B tile (32 x 128 of Vr) shared by the 4 waves through LDS.
+constexpr int NBLD = 132;  // LDS leading dimension of the B tile (floats)
+__global__ __launch_bounds__(256) void nn_gemm_kernel(const float* __restrict__ X, int64_t panel_stride, int nb, int rows, int cols,
+                                                      const float* __restrict__ Vr, int64_t ldv, const float* __restrict__ S, int k,
+                                                      float* __restrict__ out, int64_t ldo) {
+    __shared__ __attribute__((aligned(16))) float At[4][32 * 36];
+    __shared__ __attribute__((aligned(16))) float Bt[32 * NBLD];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, tid = threadIdx.x;
+    const int h = lane >> 5, c = lane & 31;
+    const int r0 = blockIdx.y * 128 + w * 32;
+    const int c0 = blockIdx.x * 128;
+    f32x16 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = (f32x16){0};
+    float* my = At[w];
+    for (int p = 0; p < nb; ++p) {
+        const float* P = X + (int64_t)p * panel_stride;
+        // A tile: rows r0..r0+31 of panel p (contiguous 4 KiB; rows >= rows_pad never read: the panel has m_pad rows)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int idx = it * 256 + lane * 4;
+            const int row = idx >> 5, col = idx & 31;
+            f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (r0 + row < rows) v = *(const f32x4*)(P + (int64_t)(r0 + row) * PB + col);
+            *(f32x4*)(my + row * 36 + col) = v;
+        }
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int idx = it * 256 + tid;
+            const int kr = idx >> 7, cc = idx & 127;
+            const int vr = p * PB + kr, vc = c0 + cc;
+            Bt[kr * NBLD + cc] = (vr < cols && vc < k) ? Vr[(int64_t)vr * ldv + vc] : 0.0f;
+        }
+        __syncthreads();
+        float a[16];
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) {
+            const f32x4 v = *(const f32x4*)(my + c * 36 + h * 16 + t4 * 4);
+            a[4 * t4 + 0] = v[0]; a[4 * t4 + 1] = v[1]; a[4 * t4 + 2] = v[2]; a[4 * t4 + 3] = v[3];
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+#pragma unroll
+            for (int tl = 0; tl < 4; ++tl)
+                acc[tl] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], Bt[(h * 16 + t) * NBLD + tl * 32 + c], acc[tl], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int tl = 0; tl < 4; ++tl) {
+        const int col = c0 + tl * 32 + c;
+        if (col >= k) continue;
+        const float sv = S ? S[col] : 1.0f;
+        const float inv = sv > 0.0f ? 1.0f / sv : 0.0f;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int row = r0 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            if (row < rows) out[(int64_t)row * ldo + col] = acc[tl][reg] * inv;
+        }
+    }
+}
+
+// sigma refinement of the tall path: Y = X Vr (unscaled) -> sigma_j = |y_j| (fp64, fixed order), u_j = y_j / sigma_j.
+// |X v_j| is second-order accurate in the error of v_j and does not see the fp32 rounding of R.
+__global__ __launch_bounds__(256) void colsumsq_kernel(const float* __restrict__ Y, int64_t ldy, int rows, int k, int rows_per_split,
+                                                       double* __restrict__ part) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6, split = blockIdx.y;
+    const int rb = split * rows_per_split, re = min(rb + rows_per_split, rows);
+    double acc = 0.0;
+    if (c < k)
+        for (int r = rb + rl; r < re; r += 4) {
+            const double v = Y[(int64_t)r * ldy + c];
+            acc += v * v;
+        }
+    __shared__ double red[4][64];
+    red[rl][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (rl == 0 && c < k) part[(int64_t)split * k + c] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+// one workgroup: ordered sum of the partials, sqrt, then a running minimum keeps S non-increasing (refined values of nearly equal
+// singular values may swap by ~1e-6 relative; the columns are not re-ordered)
+__global__ __launch_bounds__(256) void colfinish_kernel(const double* __restrict__ part, int nsplit, int k, float* __restrict__ S,
+                                                        float* __restrict__ inv) {
+    for (int c = threadIdx.x; c < k; c += 256) {
+        double acc = 0.0;
+        for (int sp = 0; sp < nsplit; ++sp) acc += part[(int64_t)sp * k + c];
+        const double sg = sqrt(acc);
+        S[c] = (float)sg;
+        inv[c] = sg > 0.0 ? (float)(1.0 / sg) : 0.0f;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float run = S[0];
+        for (int c = 1; c < k; ++c) { run = fminf(run, S[c]); S[c] = run; }
+    }
+}
+__global__ void colscale_kernel(float* __restrict__ Y, int64_t ldy, int rows, int k, const float* __restrict__ inv) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, r0 = blockIdx.y * 32;
+    if (c >= k) return;
+    const float f = inv[c];
+    for (int r = r0; r < min(r0 + 32, rows); ++r) Y[(int64_t)r * ldy + c] *= f;
+}
+
 // --------------------------------------------------------------------------------------------------
 struct Plan {
     int batch;
@@ -670,7 +1000,7 @@ struct Plan {
     size_t off_x, off_xorig, off_gpart, off_q, off_active, off_sig, off_ina, off_inv, off_perm, off_flags, total;
 };
 
-int make_plan(int batch, int64_t m, int64_t n, int want_v, Plan& p) {
+int make_plan(int batch, int64_t m, int64_t n, int want_u, int want_vv, Plan& p) {
     if (batch < 1 || m < 1 || n < 1 || m > (1 << 24) || n > (1 << 24)) return ASVD_E_BADARG;
     p.batch = batch;
     p.m = m;
@@ -682,13 +1012,14 @@ int make_plan(int batch, int64_t m, int64_t n, int want_v, Plan& p) {
     p.n_pad = (int)round_up64(p.cols, PW);
     p.nb = p.n_pad / PB;
     p.npairs = p.nb / 2;
-    p.want_v = want_v ? 1 : 0;
+    // want_u / want_vv: left / right vectors OF THE ORIENTED problem (columns of the rotated matrix / backsolved V rows)
+    p.want_v = (want_u || want_vv) ? 1 : 0;
     p.vmode = 0;
-    if (p.want_v) {
+    if (want_vv) {
         const char* e = getenv("ASVD_VMODE");
         p.vmode = (e && strcmp(e, "accumulate") == 0) ? 1 : 2;
     }
-    p.R = p.m_pad + (p.want_v ? p.n_pad : 0);
+    p.R = p.m_pad + (want_vv ? p.n_pad : 0);
     p.R_upd = (p.vmode == 1) ? p.R : p.m_pad;
     // gram: choose the row split that minimises (rounds of resident workgroups) x (chunks per wave + fixed overhead).
     // 3 workgroups of 4 waves fit per CU (148 VGPR+AGPR) -> 768 slots; a grid of 1.3 x slots costs 2 full rounds.
@@ -789,25 +1120,40 @@ int asvd_svd_get_profile(float* ms_host, int* launches_host) {
     return ASVD_OK;
 }
 
+// forward declarations of the tall-path helpers (defined after the direct driver)
+static bool tall_wanted(const Plan& p);
+static size_t tall_worksize(int batch, int64_t m, int64_t n, int want_vectors, int64_t k);
+
 int asvd_svd_worksize(int batch, int64_t m, int64_t n, int want_vectors, size_t* bytes) {
     if (!bytes) return ASVD_E_BADARG;
     Plan p;
-    int rc = make_plan(batch, m, n, want_vectors, p);
+    int rc = make_plan(batch, m, n, want_vectors, want_vectors, p);
     if (rc) return rc;
-    *bytes = p.total;
+    size_t need = p.total;  // the direct path is always available as the fallback
+    if (tall_wanted(p)) {
+        const size_t t = tall_worksize(batch, m, n, want_vectors, p.cols);
+        if (t > need) need = t;
+    }
+    *bytes = need;
     return ASVD_OK;
 }
 
-int asvd_svd_batched(int batch, const void* const* a_host, int a_dtype, int64_t m, int64_t n, int64_t lda,
-                     const void* const* cs_host, int cs_dtype, float* const* U_host, float* const* S_host,
-                     float* const* V_host, int64_t k, int max_sweeps, float tol, void* work, size_t work_bytes,
-                     int* info_host, void* stream) {
+static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t m, int64_t n, int64_t lda,
+                      const void* const* cs_host, int cs_dtype, float* const* U_host, float* const* S_host,
+                      float* const* V_host, int64_t k, int max_sweeps, float tol, void* work, size_t work_bytes,
+                      int* info_host, void* stream, bool manage_profile) {
     if (!a_host || !S_host || !work || !dtype_ok(a_dtype) || lda < n) return ASVD_E_BADARG;
     if (cs_host && !dtype_ok(cs_dtype)) return ASVD_E_BADARG;
-    const int want_v = (U_host != nullptr || V_host != nullptr) ? 1 : 0;
     Plan p;
-    int rc = make_plan(batch, m, n, want_v, p);
-    if (rc) return rc;
+    {
+        // vectors of the oriented problem: its left vectors are U of A (not transposed) or V of A (transposed)
+        const bool tr = m < n;
+        const int want_left = tr ? (V_host != nullptr) : (U_host != nullptr);
+        const int want_right = tr ? (U_host != nullptr) : (V_host != nullptr);
+        int rc0 = make_plan(batch, m, n, want_left, want_right, p);
+        if (rc0) return rc0;
+    }
+    int rc = ASVD_OK;
     if (k < 1 || k > p.cols) return ASVD_E_BADARG;
     if (work_bytes < p.total) return ASVD_E_WORKSPACE;
     for (int b = 0; b < batch; ++b)
@@ -829,7 +1175,7 @@ int asvd_svd_batched(int batch, const void* const* a_host, int a_dtype, int64_t 
     int* nrot = (int*)(wb + p.off_flags) + batch;
     int* done = (int*)(wb + p.off_flags) + 2 * batch;
 
-    if (g_prof_enabled) prof_begin();
+    if (g_prof_enabled && manage_profile) prof_begin();
 
     // ---- pack ----
     {
@@ -864,7 +1210,9 @@ int asvd_svd_batched(int batch, const void* const* a_host, int a_dtype, int64_t 
     const int nsteps = p.nb - 1;
     // panels whose convergence is enforced: those holding the k leading columns, plus one panel of margin
     const int kb = (int)(ceil_div64(k, PB) + 1 < p.nb ? ceil_div64(k, PB) + 1 : p.nb);
-    const int inner_sweeps = getenv("ASVD_INNER") ? atoi(getenv("ASVD_INNER")) : 2;
+    // two inner sweeps cut the outer sweeps 15 -> 13 at 4096^2 (fewer HBM passes: right for batches); a lone problem is bound
+    // by the eigen-solve latency instead, where one inner sweep is faster end to end
+    const int inner_sweeps = getenv("ASVD_INNER") ? atoi(getenv("ASVD_INNER")) : (batch >= 4 ? 2 : 1);
     int sweep = 0;
     // Independent problems of a batch are split into two groups driven on two internal streams: while one group sits in its
     // LDS/VALU-bound evd phase the other streams panels through its HBM-bound gram/update phase (different resources).
@@ -982,8 +1330,8 @@ int asvd_svd_batched(int batch, const void* const* a_host, int a_dtype, int64_t 
             // oriented left vectors (A part) are U of A when not transposed, V of A when transposed
             float* outA = p.transposed ? Vo : Uo;
             float* outV = p.transposed ? Uo : Vo;
-            const int rowsA = p.rows;
-            const int rowsV = p.want_v ? p.cols : 0;
+            const int rowsA = outA ? p.rows : 0;
+            const int rowsV = (p.vmode != 0 && outV) ? p.cols : 0;   // V rows exist only when the right vectors were requested
             dim3 grid((unsigned)ceil_div64(k, 64), (unsigned)ceil_div64(rowsA + rowsV > 0 ? rowsA + rowsV : 1, 64));
             gather_kernel<<<grid, 256, 0, st>>>(X + (int64_t)b * p.batch_stride, p.panel_stride, p.m_pad, p.R,
                                                 sig + (int64_t)b * p.n_pad, ina + (int64_t)b * p.n_pad,
@@ -993,7 +1341,7 @@ int asvd_svd_batched(int batch, const void* const* a_host, int a_dtype, int64_t 
     }
     ASVD_HIP_CHECK(hipStreamSynchronize(st));
     ASVD_HIP_CHECK(hipGetLastError());
-    if (g_prof_enabled) prof_end();
+    if (g_prof_enabled && manage_profile) prof_end();
 
     int worst = ASVD_OK;
     for (int b = 0; b < batch; ++b) {
@@ -1006,6 +1354,174 @@ int asvd_svd_batched(int batch, const void* const* a_host, int a_dtype, int64_t 
         if (status[b] > worst) worst = status[b];
     }
     return worst;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// tall path driver (see the kernel block "Tall problems" above)
+static bool tall_wanted(const Plan& p) {
+    if (getenv("ASVD_NO_REDUCE")) return false;
+    return p.cols >= 128 && (int64_t)p.rows * 2 >= (int64_t)p.cols * 3;
+}
+
+struct TallLayout {
+    size_t off_xp, off_g, off_dg, off_d, off_fail, off_r, off_vr, off_part, off_inv, off_inner, inner_bytes, total;
+    int n_pad64;
+};
+
+static int tall_layout(int batch, const Plan& p, int want_vectors, int64_t k, TallLayout& t) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    t.n_pad64 = p.n_pad;  // n_pad is a multiple of 64 = Cholesky block
+    t.off_xp = take((size_t)p.m_pad * PB * p.nb * batch * sizeof(float));
+    t.off_g = take((size_t)p.n_pad * p.n_pad * batch * sizeof(double));
+    t.off_dg = take((size_t)(p.n_pad / CB) * CB * CB * batch * sizeof(double));
+    t.off_d = take((size_t)p.n_pad * batch * sizeof(double));
+    t.off_fail = take((size_t)batch * sizeof(int));
+    t.off_r = take((size_t)p.n_pad * p.n_pad * batch * sizeof(float));
+    t.off_vr = take(want_vectors ? (size_t)p.cols * k * batch * sizeof(float) : 0);
+    t.off_part = take(want_vectors ? (size_t)64 * k * sizeof(double) : 0);
+    t.off_inv = take(want_vectors ? (size_t)k * sizeof(float) : 0);
+    Plan pi;
+    int rc = make_plan(batch, p.cols, p.cols, want_vectors, want_vectors, pi);
+    if (rc) return rc;
+    t.inner_bytes = pi.total;
+    t.off_inner = take(pi.total);
+    t.total = off;
+    return ASVD_OK;
+}
+
+static size_t tall_worksize(int batch, int64_t m, int64_t n, int want_vectors, int64_t k) {
+    Plan p;
+    if (make_plan(batch, m, n, 0, 0, p)) return 0;
+    TallLayout t;
+    if (tall_layout(batch, p, want_vectors, k, t)) return 0;
+    return t.total;
+}
+
+// returns ASVD_OK.., or -100 when the reduction is not applicable (Cholesky breakdown): the caller then runs the direct path
+static int svd_tall(int batch, const void* const* a_host, int a_dtype, int64_t m, int64_t n, int64_t lda, const void* const* cs_host,
+                    int cs_dtype, float* const* U_host, float* const* S_host, float* const* V_host, int64_t k, int max_sweeps,
+                    float tol, void* work, size_t work_bytes, int* info_host, void* stream) {
+    Plan p;
+    int rc = make_plan(batch, m, n, 0, 0, p);  // panels hold the A rows only
+    if (rc) return rc;
+    const int want_vectors = (U_host || V_host) ? 1 : 0;
+    TallLayout t;
+    rc = tall_layout(batch, p, want_vectors, k, t);
+    if (rc) return rc;
+    if (work_bytes < t.total) return -100;
+    hipStream_t st = (hipStream_t)stream;
+    char* wb = (char*)work;
+    float* Xp = (float*)(wb + t.off_xp);
+    double* G = (double*)(wb + t.off_g);
+    double* d = (double*)(wb + t.off_d);
+    double* Dg = (double*)(wb + t.off_dg);
+    int* fail = (int*)(wb + t.off_fail);
+    float* R = (float*)(wb + t.off_r);
+    float* Vr = (float*)(wb + t.off_vr);
+    const int64_t ldg = p.n_pad, gbs = (int64_t)p.n_pad * p.n_pad;
+    const int nbk = p.n_pad / CB;
+    // Jacobi on R^T (default): the leading right vectors of X are then the directly rotated columns (orthogonal to 1e-6) instead of
+    // backsolved ones, which matters because the long-side vectors X v / sigma amplify the error of v by sigma_1 / sigma_j;
+    // row-scaled problems (wide layers: the activation scales sit on the long side) also need 3 fewer sweeps.  ASVD_R=1: Jacobi on R.
+    const bool use_rt = getenv("ASVD_R") == nullptr;
+
+    {
+        ProfScope ps(0, st);
+        ASVD_HIP_CHECK(hipMemsetAsync(Xp, 0, (size_t)p.batch_stride * batch * sizeof(float), st));
+        ASVD_HIP_CHECK(hipMemsetAsync(fail, 0, (size_t)batch * sizeof(int), st));
+        for (int b = 0; b < batch; ++b) {
+            float* Xb = Xp + (int64_t)b * p.batch_stride;
+            const void* sc = cs_host ? cs_host[b] : nullptr;
+            int prc;
+            switch (a_dtype) {
+                case ASVD_F32: prc = launch_pack<ASVD_F32>(a_host[b], lda, sc, cs_dtype, p, Xb, st); break;
+                case ASVD_F16: prc = launch_pack<ASVD_F16>(a_host[b], lda, sc, cs_dtype, p, Xb, st); break;
+                default: prc = launch_pack<ASVD_BF16>(a_host[b], lda, sc, cs_dtype, p, Xb, st); break;
+            }
+            if (prc) return prc;
+        }
+        gram64_kernel<<<dim3(p.nb, (unsigned)ceil_div64(p.nb, 4), batch), 256, 0, st>>>(Xp, p.panel_stride, p.batch_stride, p.nb, p.m_pad, G, ldg, gbs);
+        chol_diag_kernel<<<dim3((unsigned)ceil_div64(p.n_pad, 256), batch), 256, 0, st>>>(G, ldg, gbs, p.n_pad, d);
+        chol_scale_kernel<<<dim3((unsigned)ceil_div64(p.n_pad, 256), p.n_pad, batch), 256, 0, st>>>(G, ldg, gbs, p.n_pad, d);
+        for (int jb = 0; jb < nbk; ++jb) {
+            chol_panel_kernel<<<dim3(nbk - jb, batch), 256, 0, st>>>(G, ldg, gbs, jb, fail, Dg, nbk);
+            if (jb + 1 < nbk) chol_syrk_kernel<<<dim3(nbk - jb - 1, nbk - jb - 1, batch), 256, 0, st>>>(G, ldg, gbs, jb, nbk);
+        }
+        r_to_f32_kernel<<<dim3((unsigned)ceil_div64(p.n_pad, 256), p.n_pad, batch), 256, 0, st>>>(G, ldg, gbs, Dg, d, p.n_pad, use_rt ? 1 : 0, R, gbs);
+    }
+    std::vector<int> hfail(batch, 0);
+    ASVD_HIP_CHECK(hipMemcpyAsync(hfail.data(), fail, (size_t)batch * sizeof(int), hipMemcpyDeviceToHost, st));
+    ASVD_HIP_CHECK(hipStreamSynchronize(st));
+    for (int b = 0; b < batch; ++b)
+        if (hfail[b]) {
+            if (getenv("ASVD_DEBUG")) fprintf(stderr, "[asvd_svd] Cholesky-QR breakdown for problem %d (code %d): falling back to the direct path\n", b, hfail[b]);
+            if (getenv("ASVD_DEBUG_TALL_STOP")) return ASVD_E_HIP;
+            return -100;
+        }
+
+    // right vectors of X = right vectors of R  (left vectors of R^T when ASVD_RT): written straight to the caller's short-side
+    // output when it exists, else to the temporary
+    std::vector<const void*> rp(batch);
+    std::vector<float*> vr(batch, nullptr);
+    for (int b = 0; b < batch; ++b) {
+        rp[b] = R + (int64_t)b * gbs;
+        if (want_vectors) {
+            float* short_out = p.transposed ? (U_host ? U_host[b] : nullptr) : (V_host ? V_host[b] : nullptr);
+            vr[b] = short_out ? short_out : Vr + (int64_t)b * p.cols * k;
+        }
+    }
+    float* const* inner_U = nullptr;
+    float* const* inner_V = nullptr;
+    if (want_vectors) { if (use_rt) inner_U = vr.data(); else inner_V = vr.data(); }
+    rc = svd_direct(batch, rp.data(), ASVD_F32, p.cols, p.cols, p.n_pad, nullptr, 0, inner_U, S_host, inner_V, k, max_sweeps, tol,
+                    wb + t.off_inner, t.inner_bytes, info_host, stream, false);
+    if (rc < 0) return rc;
+    if (want_vectors) {
+        ProfScope ps(4, st);
+        for (int b = 0; b < batch; ++b) {
+            float* long_out = p.transposed ? (V_host ? V_host[b] : nullptr) : (U_host ? U_host[b] : nullptr);
+            if (!long_out) continue;
+            nn_gemm_kernel<<<dim3((unsigned)ceil_div64(k, 128), (unsigned)ceil_div64(p.rows, 128)), 256, 0, st>>>(
+                Xp + (int64_t)b * p.batch_stride, p.panel_stride, p.nb, p.rows, p.cols, vr[b], k, nullptr, (int)k, long_out, k);
+            // sigma_j = |X v_j| and unit left vectors
+            const int nsp = (int)std::min<int64_t>(64, ceil_div64(p.rows, 256));
+            const int rps = (int)ceil_div64(p.rows, nsp);
+            double* part = (double*)(wb + t.off_part);
+            float* invs = (float*)(wb + t.off_inv);
+            colsumsq_kernel<<<dim3((unsigned)ceil_div64(k, 64), nsp), 256, 0, st>>>(long_out, k, p.rows, (int)k, rps, part);
+            colfinish_kernel<<<1, 256, 0, st>>>(part, nsp, (int)k, S_host[b], invs);
+            colscale_kernel<<<dim3((unsigned)ceil_div64(k, 256), (unsigned)ceil_div64(p.rows, 32)), 256, 0, st>>>(long_out, k, p.rows, (int)k, invs);
+        }
+        ASVD_HIP_CHECK(hipStreamSynchronize(st));
+        ASVD_HIP_CHECK(hipGetLastError());
+    }
+    return rc;
+}
+
+int asvd_svd_batched(int batch, const void* const* a_host, int a_dtype, int64_t m, int64_t n, int64_t lda,
+                     const void* const* cs_host, int cs_dtype, float* const* U_host, float* const* S_host,
+                     float* const* V_host, int64_t k, int max_sweeps, float tol, void* work, size_t work_bytes,
+                     int* info_host, void* stream) {
+    if (!a_host || !S_host || !work || !dtype_ok(a_dtype) || lda < n) return ASVD_E_BADARG;
+    if (cs_host && !dtype_ok(cs_dtype)) return ASVD_E_BADARG;
+    Plan p;
+    int rc = make_plan(batch, m, n, 0, 0, p);
+    if (rc) return rc;
+    if (k < 1 || k > p.cols) return ASVD_E_BADARG;
+    for (int b = 0; b < batch; ++b)
+        if (!a_host[b] || !S_host[b]) return ASVD_E_BADARG;
+    if (g_prof_enabled) prof_begin();
+    rc = -100;
+    if (tall_wanted(p))
+        rc = svd_tall(batch, a_host, a_dtype, m, n, lda, cs_host, cs_dtype, U_host, S_host, V_host, k, max_sweeps, tol, work, work_bytes,
+                      info_host, stream);
+    if (rc == -100)
+        rc = svd_direct(batch, a_host, a_dtype, m, n, lda, cs_host, cs_dtype, U_host, S_host, V_host, k, max_sweeps, tol, work, work_bytes,
+                        info_host, stream, false);
+    if (g_prof_enabled) prof_end();
+    return rc;
 }
 
 int asvd_svd(const void* a, int a_dtype, int64_t m, int64_t n, int64_t lda, const void* col_scale, int cs_dtype, float* U,
