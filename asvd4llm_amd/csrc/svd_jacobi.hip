@@ -766,6 +766,38 @@ __global__ void chol_scale_kernel(double* __restrict__ G, int64_t ldg, int64_t g
     else *g = (di > 0.0 && dj > 0.0) ? *g / (di * dj) : 0.0;
 }
 
+// column pivoting "light": order the columns by decreasing norm before the factorisation (symmetric permutation of the Gram
+// matrix).  With sorted columns R is graded and Jacobi on R^T starts much closer to diagonal (Drmac-Veselic preconditioning;
+// the CPU prototype needs 9 instead of 12 sweeps at n = 2048).
+__global__ void iota_kernel(int* __restrict__ perm, int n_pad) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (j < n_pad) perm[(int64_t)b * n_pad + j] = j;
+}
+__global__ void d_to_float_kernel(const double* __restrict__ d, int n, float* __restrict__ df) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) df[i] = (float)d[i];
+}
+// Gs[i][j] (i <= j) = G[perm i][perm j] / (d_perm_i d_perm_j), unit diagonal; dp[i] = d[perm[i]]
+__global__ void g_permute_scale_kernel(const double* __restrict__ G, int64_t ldg, int64_t g_batch_stride, const double* __restrict__ d,
+                                       const int* __restrict__ perm, int n_pad, double* __restrict__ Gs, double* __restrict__ dp) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y, b = blockIdx.z;
+    if (j >= n_pad || j < i) return;
+    const int pi = perm[(int64_t)b * n_pad + i], pj = perm[(int64_t)b * n_pad + j];
+    const double di = d[(int64_t)b * n_pad + pi], dj = d[(int64_t)b * n_pad + pj];
+    if (i == 0) dp[(int64_t)b * n_pad + j] = dj;
+    const int lo = pi < pj ? pi : pj, hi = pi < pj ? pj : pi;
+    double v;
+    if (i == j) v = 1.0;
+    else v = (di > 0.0 && dj > 0.0) ? G[(int64_t)b * g_batch_stride + (int64_t)lo * ldg + hi] / (di * dj) : 0.0;
+    Gs[(int64_t)b * g_batch_stride + (int64_t)i * ldg + j] = v;
+}
+// out[perm[i]][:] = in[i][:]   (rows of the right vectors back to the original column order)
+__global__ void row_unpermute_kernel(const float* __restrict__ in, const int* __restrict__ perm, int rows, int k, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+    if (c >= k || i >= rows) return;
+    out[(int64_t)perm[i] * k + c] = in[(int64_t)i * k + c];
+}
+
 constexpr int CB = 64;        // Cholesky block size
 constexpr int CLD = CB + 1;   // LDS leading dimension (doubles)
 
@@ -1360,12 +1392,15 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
 // ---------------------------------------------------------------------------------------------------------------------
 // tall path driver (see the kernel block "Tall problems" above)
 static bool tall_wanted(const Plan& p) {
+    // The reduction pays for every shape: for tall problems it shrinks each Jacobi step from rows x cols to cols x cols, and for all
+    // of them the norm-sorted Cholesky-QR is a preconditioner (Jacobi on R^T: 14 -> 10 sweeps at 4096^2, better orthogonality).
     if (getenv("ASVD_NO_REDUCE")) return false;
-    return p.cols >= 128 && (int64_t)p.rows * 2 >= (int64_t)p.cols * 3;
+    if (getenv("ASVD_TALL_ONLY")) return p.cols >= 128 && (int64_t)p.rows * 2 >= (int64_t)p.cols * 3;
+    return p.cols >= 128;
 }
 
 struct TallLayout {
-    size_t off_xp, off_g, off_dg, off_d, off_fail, off_r, off_vr, off_part, off_inv, off_inner, inner_bytes, total;
+    size_t off_xp, off_g, off_gs, off_dp, off_df, off_perm, off_dg, off_d, off_fail, off_r, off_vr, off_part, off_inv, off_inner, inner_bytes, total;
     int n_pad64;
 };
 
@@ -1375,11 +1410,15 @@ static int tall_layout(int batch, const Plan& p, int want_vectors, int64_t k, Ta
     t.n_pad64 = p.n_pad;  // n_pad is a multiple of 64 = Cholesky block
     t.off_xp = take((size_t)p.m_pad * PB * p.nb * batch * sizeof(float));
     t.off_g = take((size_t)p.n_pad * p.n_pad * batch * sizeof(double));
+    t.off_gs = take((size_t)p.n_pad * p.n_pad * batch * sizeof(double));
+    t.off_dp = take((size_t)p.n_pad * batch * sizeof(double));
+    t.off_df = take((size_t)p.n_pad * batch * sizeof(float));
+    t.off_perm = take((size_t)p.n_pad * batch * sizeof(int));
     t.off_dg = take((size_t)(p.n_pad / CB) * CB * CB * batch * sizeof(double));
     t.off_d = take((size_t)p.n_pad * batch * sizeof(double));
     t.off_fail = take((size_t)batch * sizeof(int));
     t.off_r = take((size_t)p.n_pad * p.n_pad * batch * sizeof(float));
-    t.off_vr = take(want_vectors ? (size_t)p.cols * k * batch * sizeof(float) : 0);
+    t.off_vr = take(want_vectors ? (size_t)2 * p.cols * k * batch * sizeof(float) : 0);  // permuted + un-permuted right vectors
     t.off_part = take(want_vectors ? (size_t)64 * k * sizeof(double) : 0);
     t.off_inv = take(want_vectors ? (size_t)k * sizeof(float) : 0);
     Plan pi;
@@ -1417,6 +1456,11 @@ static int svd_tall(int batch, const void* const* a_host, int a_dtype, int64_t m
     double* G = (double*)(wb + t.off_g);
     double* d = (double*)(wb + t.off_d);
     double* Dg = (double*)(wb + t.off_dg);
+    double* Gs = (double*)(wb + t.off_gs);
+    double* dp = (double*)(wb + t.off_dp);
+    float* dF = (float*)(wb + t.off_df);
+    int* cperm = (int*)(wb + t.off_perm);
+    const bool sort_cols = getenv("ASVD_NO_SORT") == nullptr;
     int* fail = (int*)(wb + t.off_fail);
     float* R = (float*)(wb + t.off_r);
     float* Vr = (float*)(wb + t.off_vr);
@@ -1444,12 +1488,16 @@ static int svd_tall(int batch, const void* const* a_host, int a_dtype, int64_t m
         }
         gram64_kernel<<<dim3(p.nb, (unsigned)ceil_div64(p.nb, 4), batch), 256, 0, st>>>(Xp, p.panel_stride, p.batch_stride, p.nb, p.m_pad, G, ldg, gbs);
         chol_diag_kernel<<<dim3((unsigned)ceil_div64(p.n_pad, 256), batch), 256, 0, st>>>(G, ldg, gbs, p.n_pad, d);
-        chol_scale_kernel<<<dim3((unsigned)ceil_div64(p.n_pad, 256), p.n_pad, batch), 256, 0, st>>>(G, ldg, gbs, p.n_pad, d);
+        // sort columns by decreasing norm (stable, padding last), permute + unit-scale the Gram matrix
+        d_to_float_kernel<<<(unsigned)ceil_div64((int64_t)p.n_pad * batch, 256), 256, 0, st>>>(d, p.n_pad * batch, dF);
+        if (sort_cols) rank_kernel<<<dim3((unsigned)ceil_div64(p.n_pad, 256), batch), 256, 0, st>>>(dF, p.n_pad, cperm);
+        else iota_kernel<<<dim3((unsigned)ceil_div64(p.n_pad, 256), batch), 256, 0, st>>>(cperm, p.n_pad);
+        g_permute_scale_kernel<<<dim3((unsigned)ceil_div64(p.n_pad, 256), p.n_pad, batch), 256, 0, st>>>(G, ldg, gbs, d, cperm, p.n_pad, Gs, dp);
         for (int jb = 0; jb < nbk; ++jb) {
-            chol_panel_kernel<<<dim3(nbk - jb, batch), 256, 0, st>>>(G, ldg, gbs, jb, fail, Dg, nbk);
-            if (jb + 1 < nbk) chol_syrk_kernel<<<dim3(nbk - jb - 1, nbk - jb - 1, batch), 256, 0, st>>>(G, ldg, gbs, jb, nbk);
+            chol_panel_kernel<<<dim3(nbk - jb, batch), 256, 0, st>>>(Gs, ldg, gbs, jb, fail, Dg, nbk);
+            if (jb + 1 < nbk) chol_syrk_kernel<<<dim3(nbk - jb - 1, nbk - jb - 1, batch), 256, 0, st>>>(Gs, ldg, gbs, jb, nbk);
         }
-        r_to_f32_kernel<<<dim3((unsigned)ceil_div64(p.n_pad, 256), p.n_pad, batch), 256, 0, st>>>(G, ldg, gbs, Dg, d, p.n_pad, use_rt ? 1 : 0, R, gbs);
+        r_to_f32_kernel<<<dim3((unsigned)ceil_div64(p.n_pad, 256), p.n_pad, batch), 256, 0, st>>>(Gs, ldg, gbs, Dg, dp, p.n_pad, use_rt ? 1 : 0, R, gbs);
     }
     std::vector<int> hfail(batch, 0);
     ASVD_HIP_CHECK(hipMemcpyAsync(hfail.data(), fail, (size_t)batch * sizeof(int), hipMemcpyDeviceToHost, st));
@@ -1464,23 +1512,25 @@ static int svd_tall(int batch, const void* const* a_host, int a_dtype, int64_t m
     // right vectors of X = right vectors of R  (left vectors of R^T when ASVD_RT): written straight to the caller's short-side
     // output when it exists, else to the temporary
     std::vector<const void*> rp(batch);
-    std::vector<float*> vr(batch, nullptr);
+    std::vector<float*> vr(batch, nullptr), vperm(batch, nullptr);
     for (int b = 0; b < batch; ++b) {
         rp[b] = R + (int64_t)b * gbs;
         if (want_vectors) {
             float* short_out = p.transposed ? (U_host ? U_host[b] : nullptr) : (V_host ? V_host[b] : nullptr);
-            vr[b] = short_out ? short_out : Vr + (int64_t)b * p.cols * k;
+            vperm[b] = Vr + (int64_t)(2 * b) * p.cols * k;                       // right vectors in sorted-column order
+            vr[b] = short_out ? short_out : Vr + (int64_t)(2 * b + 1) * p.cols * k;  // ... in the original order
         }
     }
     float* const* inner_U = nullptr;
     float* const* inner_V = nullptr;
-    if (want_vectors) { if (use_rt) inner_U = vr.data(); else inner_V = vr.data(); }
+    if (want_vectors) { if (use_rt) inner_U = vperm.data(); else inner_V = vperm.data(); }
     rc = svd_direct(batch, rp.data(), ASVD_F32, p.cols, p.cols, p.n_pad, nullptr, 0, inner_U, S_host, inner_V, k, max_sweeps, tol,
                     wb + t.off_inner, t.inner_bytes, info_host, stream, false);
     if (rc < 0) return rc;
     if (want_vectors) {
         ProfScope ps(4, st);
         for (int b = 0; b < batch; ++b) {
+            row_unpermute_kernel<<<dim3((unsigned)ceil_div64(k, 256), p.cols), 256, 0, st>>>(vperm[b], cperm + (int64_t)b * p.n_pad, p.cols, (int)k, vr[b]);
             float* long_out = p.transposed ? (V_host ? V_host[b] : nullptr) : (U_host ? U_host[b] : nullptr);
             if (!long_out) continue;
             nn_gemm_kernel<<<dim3((unsigned)ceil_div64(k, 128), (unsigned)ceil_div64(p.rows, 128)), 256, 0, st>>>(
