@@ -68,7 +68,41 @@ def calib_input_distribution(model, calib_loader, method, use_cache=True):
     torch.save(all_scaling_diag_matrix, cache_file)
 
 
-@torch.no_grad()
 def calib_fisher_info(model, calib_loader, use_cache=True):
-    """act_aware_utils.py:8-44 (--scaling_method fisher*): outside the hot-path scope of this build."""
-    raise NotImplementedError("fisher scaling is out of scope for the MI355X hot path build (SURVEY.md §8f row 4)")
+    """Fisher scaling statistics (act_aware_utils.py:8-44, `--scaling_method fisher*`): per Linear,
+    fisher_info = sqrt( mean over batches of  weight.grad.pow(2).mean(0) ).  The backward pass is ordinary PyTorch model execution;
+    the per-input-channel statistic of the gradient is the sq_mean mode of the hook kernel (asvd_absstat_accum)."""
+    model_id = model.config._name_or_path
+    cache_file = f"cache/{model_id.replace('/','_')}_calib_fisher_info.pt"
+    if os.path.exists(cache_file) and use_cache:
+        all_fisher_info = torch.load(cache_file, map_location="cpu")
+        for name, module in model.named_modules():
+            if isinstance(module, nn.Linear):
+                module.fisher_info = all_fisher_info[name].to(module.weight.device)
+        return
+    model.eval()
+    for name, module in model.named_modules():
+        if isinstance(module, nn.Linear):
+            module.fisher_info = 0
+    for batch in tqdm(calib_loader):
+        input_ids = batch["input_ids"][:, :-1].to(model.device)
+        labels = batch["input_ids"][:, 1:].to(model.device)
+        out = model(input_ids=input_ids, labels=labels)
+        out[0].backward()
+        for name, module in model.named_modules():
+            if isinstance(module, nn.Linear):
+                g = module.weight.grad.detach()
+                if not torch.is_tensor(module.fisher_info):
+                    module.fisher_info = torch.zeros(g.shape[1], dtype=g.dtype, device=g.device)
+                ops.absstat_accum(g if g.stride(1) == 1 else g.contiguous(), module.fisher_info, "sq_mean")
+        model.zero_grad()
+    for name, module in model.named_modules():
+        if isinstance(module, nn.Linear):
+            module.fisher_info = module.fisher_info.div(len(calib_loader)).sqrt()
+    all_fisher_info = {}
+    for name, module in model.named_modules():
+        if isinstance(module, nn.Linear):
+            module._forward_hooks.clear()
+            all_fisher_info[name] = module.fisher_info
+    os.makedirs(os.path.dirname(cache_file), exist_ok=True)
+    torch.save(all_fisher_info, cache_file)

@@ -52,8 +52,8 @@ __global__ __launch_bounds__(256) void absstat_partial_kernel(const void* __rest
         }
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
-            const float a = fabsf(vals[v]);
-            if (MODE == ASVD_STAT_ABS_MEAN) acc[v] += a;
+            const float a = (MODE == ASVD_STAT_SQ_MEAN) ? elem<DT>::rnd(vals[v] * vals[v]) : fabsf(vals[v]);
+            if (MODE != ASVD_STAT_ABS_MAX) acc[v] += a;
             else {
                 if (a != a) seen_nan |= (1 << v);
                 else acc[v] = fmaxf(acc[v], a);
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void absstat_partial_kernel(const void* __rest
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
             float s = red[0][v * 64 + lane];
-            if (MODE == ASVD_STAT_ABS_MEAN) s = ((s + red[1][v * 64 + lane]) + red[2][v * 64 + lane]) + red[3][v * 64 + lane];
+            if (MODE != ASVD_STAT_ABS_MAX) s = ((s + red[1][v * 64 + lane]) + red[2][v * 64 + lane]) + red[3][v * 64 + lane];
             else s = fmaxf(fmaxf(s, red[1][v * 64 + lane]), fmaxf(red[2][v * 64 + lane], red[3][v * 64 + lane]));
             if (c0 + v < cols) part[(int64_t)split * cols + c0 + v] = s;
         }
@@ -89,7 +89,7 @@ __global__ void absstat_final_kernel(const float* __restrict__ part, const int* 
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= cols) return;
     const float old = elem<AT>::ld(acc, c);
-    if (MODE == ASVD_STAT_ABS_MEAN) {
+    if (MODE != ASVD_STAT_ABS_MAX) {
         float s = 0.0f;
         for (int k = 0; k < nsplit; ++k) s += part[(int64_t)k * cols + c];
         const float mean = elem<AT>::rnd(__fdiv_rn(s, (float)rows));  // .mean() result in the activation dtype
@@ -345,7 +345,7 @@ int asvd_absstat_worksize(int64_t rows, int64_t cols, size_t* bytes) {
 int asvd_absstat_accum(const void* x, int x_dtype, int64_t rows, int64_t cols, int64_t ld, void* acc, int acc_dtype, int mode,
                        void* work, size_t work_bytes, void* stream) {
     if (!x || !acc || !work || rows < 1 || cols < 1 || ld < cols || !dtype_ok(x_dtype) || !dtype_ok(acc_dtype)) return ASVD_E_BADARG;
-    if (mode != ASVD_STAT_ABS_MEAN && mode != ASVD_STAT_ABS_MAX) return ASVD_E_BADARG;
+    if (mode != ASVD_STAT_ABS_MEAN && mode != ASVD_STAT_ABS_MAX && mode != ASVD_STAT_SQ_MEAN) return ASVD_E_BADARG;
     const int ns = absstat_nsplit(rows, cols);
     if (work_bytes < (size_t)ns * cols * (sizeof(float) + sizeof(int))) return ASVD_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
@@ -356,11 +356,12 @@ int asvd_absstat_accum(const void* x, int x_dtype, int64_t rows, int64_t cols, i
     dim3 grid((unsigned)ceil_div64(cols, 64 * vec), (unsigned)ns);
     ASVD_DISPATCH_DTYPE(x_dtype, XT, {
         if (mode == ASVD_STAT_ABS_MEAN) absstat_partial_kernel<XT, ASVD_STAT_ABS_MEAN><<<grid, 256, 0, st>>>(x, rows, cols, ld, rps, part, nanflag);
+        else if (mode == ASVD_STAT_SQ_MEAN) absstat_partial_kernel<XT, ASVD_STAT_SQ_MEAN><<<grid, 256, 0, st>>>(x, rows, cols, ld, rps, part, nanflag);
         else absstat_partial_kernel<XT, ASVD_STAT_ABS_MAX><<<grid, 256, 0, st>>>(x, rows, cols, ld, rps, part, nanflag);
     });
     const unsigned fg = (unsigned)ceil_div64(cols, 256);
     ASVD_DISPATCH_DTYPE(acc_dtype, AT, {
-        if (mode == ASVD_STAT_ABS_MEAN) absstat_final_kernel<AT, ASVD_STAT_ABS_MEAN><<<fg, 256, 0, st>>>(part, nanflag, ns, rows, cols, acc);
+        if (mode != ASVD_STAT_ABS_MAX) absstat_final_kernel<AT, ASVD_STAT_ABS_MEAN><<<fg, 256, 0, st>>>(part, nanflag, ns, rows, cols, acc);
         else absstat_final_kernel<AT, ASVD_STAT_ABS_MAX><<<fg, 256, 0, st>>>(part, nanflag, ns, rows, cols, acc);
     });
     ASVD_HIP_CHECK(hipGetLastError());

@@ -40,7 +40,7 @@ def absstat_accum(x2d, acc, method):
     _dev(x2d, "x"), _dev(acc, "acc")
     assert x2d.dim() == 2 and x2d.stride(1) == 1 and acc.is_contiguous() and acc.numel() == x2d.shape[1]
     rows, cols = x2d.shape
-    mode = L.STAT_ABS_MEAN if "abs_mean" in method else L.STAT_ABS_MAX
+    mode = L.STAT_SQ_MEAN if method == "sq_mean" else (L.STAT_ABS_MEAN if "abs_mean" in method else L.STAT_ABS_MAX)
     nb = ctypes.c_size_t()
     L.check(lib.asvd_absstat_worksize(rows, cols, ctypes.byref(nb)), "asvd_absstat_worksize")
     work = _work(nb.value, x2d.device)

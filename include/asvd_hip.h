@@ -49,6 +49,8 @@ extern "C" {
 /* activation-statistic modes of the calibration hook (act_aware_utils.py:64-74) */
 #define ASVD_STAT_ABS_MEAN 0
 #define ASVD_STAT_ABS_MAX 1
+/* column mean of x^2 with x^2 rounded to the dtype of x first: `weight.grad.pow(2).mean(0)` of calib_fisher_info (act_aware_utils.py:30) */
+#define ASVD_STAT_SQ_MEAN 2
 
 int asvd_version(void);
 const char* asvd_status_string(int status);
@@ -65,6 +67,7 @@ int asvd_device_count(void);
  * abs_mean: column sums accumulate in fp32, are divided by rows, rounded to acc_dtype, then added to
  *           acc in acc_dtype arithmetic (one rounding), i.e. the reference's two-op sequence.
  * abs_max : NaN in x never replaces acc (torch.where(nan > acc) is false).
+ * sq_mean : as abs_mean with x*x (rounded to x's dtype, as torch's .pow(2) does) in place of |x|; x = weight.grad [out, in].
  * work: asvd_absstat_worksize bytes (fp32 partial sums). Asynchronous on `stream`.
  */
 int asvd_absstat_worksize(int64_t rows, int64_t cols, size_t* bytes);

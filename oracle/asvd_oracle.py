@@ -45,6 +45,12 @@ def hook_update(acc, x, method):
     raise ValueError(method)
 
 
+def fisher_update(acc, grad):
+    """act_aware_utils.py:30: `module.fisher_info += module.weight.grad.detach().pow(2).mean(0)` (accumulator starts as python 0)"""
+    g2 = grad.detach().pow(2).mean(0)
+    return g2 if acc is None else acc + g2
+
+
 def hook_update_numpy(acc, x, method):
     """Independent numpy restatement of the same update (float64 column sums, one rounding to the activation dtype
     for .mean(), one for the += ), used to bound the rounding freedom of the fp32-accumulating device kernel."""
@@ -113,13 +119,14 @@ def from_linear_oracle(weight, scaling_diag_matrix, param_ratio, alpha=1, act_aw
     out_f, in_f = weight.shape
     rank = rank_from_ratio(out_f, in_f, param_ratio, rank_align)
     s = None
-    if act_aware:
-        if scaling_diag_matrix is not None or fisher_info is not None:
-            base = scaling_diag_matrix if scaling_diag_matrix is not None else 1
-            s = 1 * base ** alpha if scaling_diag_matrix is not None else 1
-            if fisher_info is not None:
-                s = s * fisher_info ** alpha
-            s = s + 1e-6
+    if act_aware and (scaling_diag_matrix is not None or fisher_info is not None):
+        # svd_linear.py:48-59: s = 1 * scaling**alpha (* fisher**alpha), then += 1e-6
+        s = 1
+        if scaling_diag_matrix is not None:
+            s = s * scaling_diag_matrix ** alpha
+        if fisher_info is not None:
+            s = s * fisher_info ** alpha
+        s = s + 1e-6
     w = scaled_weight(weight, s)
     U, S, V = exact_svd(w)
     A, B, nan = truncate_split(U, S, V, s, rank, sigma_fuse, weight.dtype)

@@ -174,3 +174,17 @@ def test_fro_and_reconstruct(gpu, dtype):
     e2 = (W.double() - A.double() @ B.double()).pow(2).sum().item()
     w2 = W.double().pow(2).sum().item()
     assert abs(out[0].item() - e2) <= 1e-5 * e2 and abs(out[1].item() - w2) <= 1e-9 * w2
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+def test_fisher_sq_mean_statistic(gpu, dtype):
+    """sq_mean mode = `weight.grad.pow(2).mean(0)` accumulated over batches (calib_fisher_info, act_aware_utils.py:30)"""
+    from asvd4llm_amd import ops
+    g = torch.Generator().manual_seed(6)
+    acc = torch.zeros(300, dtype=dtype, device=gpu)
+    want = None
+    for _ in range(3):
+        grad = (torch.randn(130, 300, generator=g) * 0.05).to(dtype)
+        ops.absstat_accum(grad.to(gpu), acc, "sq_mean")
+        want = O.fisher_update(want, grad)
+    _ulp_close(acc, want, dtype, n_ulp=3, frac_exact=0.9)

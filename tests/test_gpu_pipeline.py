@@ -202,3 +202,41 @@ def test_topk_request_converges_leading_part(gpu):
     R = (U.double() * S.double()) @ V.double().T
     Rf = (Uf[:, :200].double() * Sf[:200].double()) @ Vf[:, :200].double().T
     assert ((R - Rf).norm() / Rf.norm()).item() <= 1e-4
+
+
+def test_fisher_calibration_vs_cpu_restatement(gpu, tmp_path, monkeypatch):
+    """--scaling_method fisher*: calib_fisher_info (act_aware_utils.py:8-44) on a tiny HF Llama, GPU kernel statistic vs the same
+    torch-CPU ops the reference runs, then a fisher+abs_mean decomposition through from_linear."""
+    import copy
+    from asvd4llm_amd.act_aware_utils import calib_fisher_info
+    from asvd4llm_amd.model_zoo import random_init_model
+    from asvd4llm_amd.modules.svd_linear import SVDLinear
+    monkeypatch.chdir(tmp_path)
+    cpu_model = random_init_model("tiny-llama", dtype=torch.float32, seed=1)
+    gpu_model = copy.deepcopy(cpu_model).to(gpu)
+    g = torch.Generator().manual_seed(3)
+    calib = [{"input_ids": torch.randint(0, 512, (1, 33), generator=g)} for _ in range(2)]
+    with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+        calib_fisher_info(gpu_model, calib, use_cache=False)
+    assert os.path.exists("cache/tiny-llama_calib_fisher_info.pt")
+    # CPU restatement with the oracle's update rule
+    acc = {}
+    for batch in calib:
+        out = cpu_model(input_ids=batch["input_ids"][:, :-1], labels=batch["input_ids"][:, 1:])
+        out[0].backward()
+        for n, m in cpu_model.named_modules():
+            if isinstance(m, nn.Linear):
+                acc[n] = O.fisher_update(acc.get(n), m.weight.grad)
+        cpu_model.zero_grad()
+    for n, m in gpu_model.named_modules():
+        if isinstance(m, nn.Linear):
+            want = (acc[n] / len(calib)).sqrt()
+            got = m.fisher_info.float().cpu()
+            assert got.shape == want.shape
+            assert ((got - want).abs() <= 2e-3 * want.abs() + 1e-9).all(), n
+    lin = gpu_model.model.layers[0].mlp.down_proj
+    lin.scaling_diag_matrix = torch.rand(lin.in_features, device=gpu) + 0.5
+    m = SVDLinear.from_linear(lin, 0.5, act_aware=True, alpha=0.5)
+    o = O.from_linear_oracle(lin.weight.data.cpu(), lin.scaling_diag_matrix.cpu(), 0.5, alpha=0.5, act_aware=True, fisher_info=lin.fisher_info.cpu())
+    e_live, e_scaled = O.recon_parity(m.ALinear.weight.data, m.BLinear.weight.data, o["A"], o["B"], lin.weight.data.cpu(), o["s"])
+    assert e_live <= 1e-3 and e_scaled <= 1e-3
