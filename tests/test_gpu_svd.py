@@ -133,3 +133,45 @@ def test_svd_llama_mlp_shapes_sigma_only(gpu):
         r = O.rank_from_ratio(m, n, 0.9)
         assert info.status == 0
         assert O.sigma_rel_err(S.cpu(), So, r) <= SIG_TOL
+
+
+def test_reduction_breakdown_falls_back(gpu):
+    """>= 128 columns takes the Cholesky-QR reduction; an exactly rank-deficient input breaks the Cholesky down (non-positive
+    pivot) and the call must fall back to the direct path and still deliver the contract."""
+    from asvd4llm_amd import ops
+    g = torch.Generator().manual_seed(11)
+    A = torch.randn(400, 40, generator=g) @ torch.randn(40, 256, generator=g)  # rank 40 of 256 columns
+    U, S, V, info = ops.svd(A.to(gpu))
+    So = torch.linalg.svdvals(A.double())
+    assert info.status == 0
+    assert O.sigma_rel_err(S.cpu(), So, 40) < 1e-4
+    assert (S.cpu().double()[40:].abs().max() / So[0]).item() < 1e-5
+    R = (U.cpu().double() * S.cpu().double()) @ V.cpu().double().T
+    assert ((R - A.double()).norm() / A.double().norm()).item() < 1e-4
+    # a duplicated column and an all-zero column (dead channel with zero weight) must not poison anything either
+    B = torch.randn(512, 192, generator=g)
+    B[:, 7] = B[:, 3]
+    B[:, 100] = 0
+    U, S, V, info = ops.svd(B.to(gpu))
+    So = torch.linalg.svdvals(B.double())
+    assert info.status == 0 and not torch.isnan(U).any() and not torch.isnan(V).any()
+    assert O.sigma_rel_err(S.cpu(), So, 190) < 1e-4
+
+
+def test_reduction_matches_direct_path(gpu):
+    """the preconditioned (Cholesky-QR + Jacobi on R^T) and the direct path agree on the contract quantities"""
+    import os
+    from asvd4llm_amd import ops
+    W, s = llm_like(640, 384)
+    U, S, V, info = ops.svd(W.to(gpu), s.to(gpu))
+    os.environ["ASVD_NO_REDUCE"] = "1"
+    try:
+        U2, S2, V2, info2 = ops.svd(W.to(gpu), s.to(gpu))
+    finally:
+        del os.environ["ASVD_NO_REDUCE"]
+    r = 150
+    assert info.status == 0 and info2.status == 0
+    assert ((S[:r] - S2[:r]).abs() / S2[:r]).max().item() <= 5e-5
+    R1 = (U[:, :r].double() * S[:r].double()) @ V[:, :r].double().T
+    R2 = (U2[:, :r].double() * S2[:r].double()) @ V2[:, :r].double().T
+    assert ((R1 - R2).norm() / R2.norm()).item() <= 1e-4
