@@ -808,8 +808,9 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ G,
                                                          int* __restrict__ fail, double* __restrict__ Dg, int nbk) {
     __shared__ double A[CB * CLD];
     __shared__ double Ri[CB * CLD];
-    __shared__ double Bs[CB * CLD];
-    const int q = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    double* Bs = A;  // the unfactored / factored diagonal block is dead once its inverse exists
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int nq = nbk - jb;  // column blocks jb .. nbk-1 of this block row; workgroup w handles q = w, w + gridDim.x, ...
     double* Gb = G + (int64_t)b * g_batch_stride;
     const int64_t o = (int64_t)jb * CB;
     for (int e = tid; e < CB * CB; e += 256) {
@@ -835,7 +836,7 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ G,
         }
         __syncthreads();
     }
-    if (bad && tid == 0) atomicMax(&fail[b], 1000 * (q + 1) + jb + 1);
+    if (bad && tid == 0) atomicMax(&fail[b], jb + 1);
     // inverse of the upper triangular R_jj: thread j solves R z = e_j by back substitution
     if (tid < CB) {
         const int j = tid;
@@ -847,27 +848,29 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ G,
         }
     }
     __syncthreads();
-    if (q == 0) {
+    if (blockIdx.x == 0) {
         // R_jj goes to a side buffer: the other workgroups of this step may still be loading the unfactored A_jj from G
         double* dgo = Dg + ((int64_t)b * nbk + jb) * (CB * CB);
         for (int e = tid; e < CB * CB; e += 256) {
             const int i = e >> 6, j = e & 63;
             dgo[e] = (j >= i) ? A[i * CLD + j] : 0.0;
         }
-        return;
     }
-    const int64_t oc = (int64_t)(jb + q) * CB;
-    for (int e = tid; e < CB * CB; e += 256) {
-        const int i = e >> 6, j = e & 63;
-        Bs[i * CLD + j] = Gb[(o + i) * ldg + oc + j];
-    }
-    __syncthreads();
-    // Y = Ri^T B :  Y[i][c] = sum_{k <= i} Ri[k][i] B[k][c]
-    for (int e = tid; e < CB * CB; e += 256) {
-        const int i = e >> 6, c = e & 63;
-        double acc = 0.0;
-        for (int k = 0; k <= i; ++k) acc += Ri[k * CLD + i] * Bs[k * CLD + c];
-        Gb[(o + i) * ldg + oc + c] = acc;
+    for (int q = (blockIdx.x == 0 ? (int)gridDim.x : (int)blockIdx.x); q < nq; q += gridDim.x) {
+        __syncthreads();  // previous block's reads of Bs (and the R_jj store above) are done
+        const int64_t oc = (int64_t)(jb + q) * CB;
+        for (int e = tid; e < CB * CB; e += 256) {
+            const int i = e >> 6, j = e & 63;
+            Bs[i * CLD + j] = Gb[(o + i) * ldg + oc + j];
+        }
+        __syncthreads();
+        // Y = Ri^T B :  Y[i][c] = sum_{k <= i} Ri[k][i] B[k][c]
+        for (int e = tid; e < CB * CB; e += 256) {
+            const int i = e >> 6, c = e & 63;
+            double acc = 0.0;
+            for (int k = 0; k <= i; ++k) acc += Ri[k * CLD + i] * Bs[k * CLD + c];
+            Gb[(o + i) * ldg + oc + c] = acc;
+        }
     }
 }
 
@@ -1007,10 +1010,17 @@ __global__ __launch_bounds__(256) void colfinish_kernel(const double* __restrict
         inv[c] = sg > 0.0 ? (float)(1.0 / sg) : 0.0f;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        float run = S[0];
-        for (int c = 1; c < k; ++c) { run = fminf(run, S[c]); S[c] = run; }
-    }
+    // running minimum, three short passes: per-thread chunk minima, exclusive prefix over the 256 chunk minima, apply
+    __shared__ float cmin[256];
+    const int chunk = (k + 255) / 256;
+    const int c0 = threadIdx.x * chunk, c1 = min(c0 + chunk, k);
+    float m = INFINITY;
+    for (int c = c0; c < c1; ++c) m = fminf(m, S[c]);
+    cmin[threadIdx.x] = m;
+    __syncthreads();
+    float run = INFINITY;
+    for (int t = 0; t < (int)threadIdx.x; ++t) run = fminf(run, cmin[t]);
+    for (int c = c0; c < c1; ++c) { run = fminf(run, S[c]); S[c] = run; }
 }
 __global__ void colscale_kernel(float* __restrict__ Y, int64_t ldy, int rows, int k, const float* __restrict__ inv) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x, r0 = blockIdx.y * 32;
@@ -1494,7 +1504,7 @@ static int svd_tall(int batch, const void* const* a_host, int a_dtype, int64_t m
         else iota_kernel<<<dim3((unsigned)ceil_div64(p.n_pad, 256), batch), 256, 0, st>>>(cperm, p.n_pad);
         g_permute_scale_kernel<<<dim3((unsigned)ceil_div64(p.n_pad, 256), p.n_pad, batch), 256, 0, st>>>(G, ldg, gbs, d, cperm, p.n_pad, Gs, dp);
         for (int jb = 0; jb < nbk; ++jb) {
-            chol_panel_kernel<<<dim3(nbk - jb, batch), 256, 0, st>>>(Gs, ldg, gbs, jb, fail, Dg, nbk);
+            chol_panel_kernel<<<dim3(std::min(nbk - jb, 16), batch), 256, 0, st>>>(Gs, ldg, gbs, jb, fail, Dg, nbk);
             if (jb + 1 < nbk) chol_syrk_kernel<<<dim3(nbk - jb - 1, nbk - jb - 1, batch), 256, 0, st>>>(Gs, ldg, gbs, jb, nbk);
         }
         r_to_f32_kernel<<<dim3((unsigned)ceil_div64(p.n_pad, 256), p.n_pad, batch), 256, 0, st>>>(Gs, ldg, gbs, Dg, dp, p.n_pad, use_rt ? 1 : 0, R, gbs);
