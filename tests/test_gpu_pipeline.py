@@ -240,3 +240,51 @@ def test_fisher_calibration_vs_cpu_restatement(gpu, tmp_path, monkeypatch):
     o = O.from_linear_oracle(lin.weight.data.cpu(), lin.scaling_diag_matrix.cpu(), 0.5, alpha=0.5, act_aware=True, fisher_info=lin.fisher_info.cpu())
     e_live, e_scaled = O.recon_parity(m.ALinear.weight.data, m.BLinear.weight.data, o["A"], o["B"], lin.weight.data.cpu(), o["s"])
     assert e_live <= 1e-3 and e_scaled <= 1e-3
+
+
+def test_kv_cache_mode_and_rank_align(gpu, golden, tmp_path, monkeypatch):
+    """KV-cache compression mode: 19 candidate ratios up to 1.9 per layer from ONE factorisation, search restricted to
+    k_proj / v_proj with default ratio 2, plus rank_align."""
+    from asvd4llm_amd import ops
+    from asvd4llm_amd.binary_search import binary_search_truncation_rank
+    from asvd4llm_amd.modules.svd_linear import SVDLinear
+    from asvd4llm_amd.sensitivity import calib_sensitivity_ppl
+    monkeypatch.chdir(tmp_path)
+    t = golden.json("tiny_lm.json")
+    model, scal = load_golden_tiny(golden)
+    model = model.to(gpu)
+    for n, m in model.named_modules():
+        if isinstance(m, nn.Linear):
+            m.scaling_diag_matrix = scal[n].to(gpu)
+    calib = [{"input_ids": torch.tensor(ids)} for ids in t["calib_ids"]]
+    args = default_args(compress_kv_cache=True, kv_cache_ratio_target=0.5, rank_align=4)
+    calls = {"n": 0}
+    real = ops.svd_batched
+
+    def counting(mats, *a, **k):
+        calls["n"] += len(mats)
+        return real(mats, *a, **k)
+
+    ops.svd_batched = counting
+    # the reference sweeps EVERY Linear with ratios up to 1.9 in this mode; for the non-square ones the rank then exceeds min(in, out),
+    # torch.svd_lowrank raises and the reference substitutes a random Linear ("svd failed ...") - reproduced in non-strict mode
+    os.environ["ASVD_STRICT"] = "0"
+    buf = io.StringIO()
+    try:
+        with contextlib.redirect_stdout(buf), contextlib.redirect_stderr(io.StringIO()):
+            sens = calib_sensitivity_ppl(model, calib, args, use_cache=False)
+    finally:
+        ops.svd_batched = real
+        os.environ["ASVD_STRICT"] = "1"
+    assert "svd failed" in buf.getvalue()
+    assert calls["n"] == 15  # one factorisation per Linear for all 19 ratios
+    assert all(len(v) == 19 for v in sens.values()) and list(sens.keys()) == t["order"]
+    with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+        binary_search_truncation_rank(model, sens, calib, args)
+    for n, m in model.named_modules():
+        if isinstance(m, SVDLinear):
+            assert ("k_proj" in n or "v_proj" in n) and m.truncation_rank % 4 == 0
+            ratio = model._asvd_layers_min_ratio[n]
+            assert m.truncation_rank == O.rank_from_ratio(32, 32, ratio, 4)
+    assert any(isinstance(m, SVDLinear) for m in model.modules())
+    assert all(v == 2 for k, v in model._asvd_layers_min_ratio.items() if isinstance(dict(model.named_modules())[k], nn.Linear))
