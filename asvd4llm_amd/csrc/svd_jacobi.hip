@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
+#include <type_traits>
 
 namespace {
 
@@ -244,31 +245,23 @@ __global__ __launch_bounds__(256, 4) void evd_kernel(const float* __restrict__ G
     const float* gp = Gpart + ((int64_t)b * npairs + pair) * nsplit * 3072;
 
     {
-        // sum the row-split partials in fixed order; 16 independent elements per thread keep 16+ loads in flight per split
-        const float* src[16];
-        float acc[16];
+        // sum the row-split partials in fixed order: the three stored 32x32 blocks (II, IJ, JJ) are read fully coalesced (12
+        // independent elements per thread keep 12+ loads in flight per split); the JI block is the mirror of IJ, written to LDS twice
+        float acc[12];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int e = tid + 256 * q;
-            const int i = e >> 6, j = e & 63;
-            int t, ii, jj;
-            if (i < 32 && j < 32) { t = 0; ii = i; jj = j; }
-            else if (i < 32) { t = 1; ii = i; jj = j - 32; }
-            else if (j < 32) { t = 1; ii = j; jj = i - 32; }
-            else { t = 2; ii = i - 32; jj = j - 32; }
-            src[q] = gp + t * 1024 + ii * 32 + jj;
-            acc[q] = 0.0f;
-        }
+        for (int q = 0; q < 12; ++q) acc[q] = 0.0f;
 #pragma unroll 2
         for (int sp = 0; sp < nsplit; ++sp) {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) acc[q] += src[q][(int64_t)sp * 3072];
+            for (int q = 0; q < 12; ++q) acc[q] += gp[(int64_t)sp * 3072 + tid + 256 * q];
         }
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int e = tid + 256 * q;
-            const int i = e >> 6, j = e & 63;
+        for (int q = 0; q < 12; ++q) {
+            const int o = tid + 256 * q;
+            const int t = o >> 10, ii = (o & 1023) >> 5, jj = o & 31;
+            const int i = ii + (t == 2 ? 32 : 0), j = jj + (t == 0 ? 0 : 32);
             G[i * PW + pcol(j)] = acc[q];
+            if (t == 1) G[j * PW + pcol(i)] = acc[q];
             if (i == j) sdiag[0][i] = acc[q];
             if (j == i + 1 && (i & 1) == 0) sb[0][i >> 1] = acc[q];  // phase A pivots G[2k][2k+1]
         }
@@ -348,8 +341,9 @@ __global__ __launch_bounds__(256, 4) void evd_kernel(const float* __restrict__ G
         qb[r] = (8 * g + r == 2 * tx + 1) ? 1.0f : 0.0f;
     }
     int cur = 0;
-    for (int ph = 0; ph < nsw * PW; ++ph) {
-        const int par = ph & 1;
+    // one phase, parity known at compile time (positions, idle tests and the DPP pattern constant-fold per parity)
+    auto phase = [&](auto parc) {
+        constexpr int par = decltype(parc)::value;
         // positions of this lane's column pair; phase B pair 31 = (63, 0) is idle (identity, no swap)
         const int cp = par ? ((2 * tx + 1) & 63) : 2 * tx;
         const int cq = par ? ((2 * tx + 2) & 63) : 2 * tx + 1;
@@ -416,7 +410,7 @@ __global__ __launch_bounds__(256, 4) void evd_kernel(const float* __restrict__ G
         // eigenvector accumulation in REGISTERS: lane tx keeps rows 8g..8g+7 of the columns at positions 2tx (qa) and 2tx+1 (qb).
         // Phase A rotates (qa, qb) in place.  Phase B pairs positions (2tx+1, 2tx+2): qb with the qa of lane tx+1, fetched and
         // handed back with DPP wave shifts (VALU data path: the LDS, which bounds this kernel, is left to G alone).
-        if (par == 0) {
+        if constexpr (par == 0) {
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 const float u0 = qa[r], v0 = qb[r];
@@ -436,6 +430,10 @@ __global__ __launch_bounds__(256, 4) void evd_kernel(const float* __restrict__ G
         }
         __syncthreads();
         cur = nxt;
+    };
+    for (int ph2 = 0; ph2 < nsw * (PW / 2); ++ph2) {
+        phase(std::integral_constant<int, 0>{});
+        phase(std::integral_constant<int, 1>{});
     }
     // eigenvectors to LDS (plane-major image) for the normalisation / sort / store epilogue
 #pragma unroll
