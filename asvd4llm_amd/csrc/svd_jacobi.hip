@@ -230,7 +230,7 @@ __device__ __forceinline__ int pcol(int c) { return ((c & 1) << 5) | (c >> 1); }
 __global__ __launch_bounds__(256, 4) void evd_kernel(const float* __restrict__ Gpart, int nsplit, float* __restrict__ Qbuf,
                                                    int* __restrict__ active, unsigned* __restrict__ maxoff_bits,
                                                    int* __restrict__ nrot, const int* __restrict__ done, float tol,
-                                                   int inner_sweeps, int nb, int step, int kb) {
+                                                   int inner_sweeps, int nb, int step, int kb, int* __restrict__ hist) {
     __shared__ float G[PW * PW];
     __shared__ float Q[PW * PW];
     __shared__ float sdiag[2][PW];
@@ -320,6 +320,10 @@ __global__ __launch_bounds__(256, 4) void evd_kernel(const float* __restrict__ G
         offt = (ut != ut) ? ut : ((offt != offt) ? offt : fmaxf(offt, ut));
     }
     const bool is_nan = (off0 != off0);
+    if (hist && tid == 0 && !is_nan) {  // debug: decade histogram of the pair measure (ASVD_DEBUG_HIST)
+        int bk = (off0 > 0.0f) ? (int)floorf(-log10f(off0)) : 9;
+        atomicAdd(&hist[bk < 0 ? 0 : (bk > 9 ? 9 : bk)], 1);
+    }
     if (tid == 0) atomicMax(&maxoff_bits[b], is_nan ? 0x7fc00000u : __float_as_uint(offt));
     if (is_nan || off0 < tol) {
         if (tid == 0) active[b * npairs + pair] = 0;
@@ -1282,7 +1286,10 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
             ASVD_HIP_CHECK(hipEventCreateWithFlags(&ev_join[g], hipEventDisableTiming));
         }
     }
+    int* hist_dev = nullptr;
+    if (getenv("ASVD_DEBUG_HIST")) { ASVD_HIP_CHECK(hipMalloc(&hist_dev, 10 * sizeof(int))); }
     for (; sweep < max_sweeps; ++sweep) {
+        if (hist_dev) ASVD_HIP_CHECK(hipMemsetAsync(hist_dev, 0, 10 * sizeof(int), st));
         for (int g = 0; g < ngroups; ++g) {  // maxoff, nrot of this group's problems
             ASVD_HIP_CHECK(hipMemsetAsync(maxoff + gb0[g], 0, (size_t)gnb[g] * sizeof(int), gst[g]));
             ASVD_HIP_CHECK(hipMemsetAsync(nrot + gb0[g], 0, (size_t)gnb[g] * sizeof(int), gst[g]));
@@ -1303,7 +1310,7 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
                 {
                     ProfScope ps(2, s2);
                     evd_kernel<<<dim3(p.npairs, nbg), 256, 0, s2>>>(Gg, p.nsplit, Qg, ag, maxoff + b0, nrot + b0, done + b0, tol,
-                                                                     inner_sweeps, p.nb, step, kb);
+                                                                     inner_sweeps, p.nb, step, kb, hist_dev);
                 }
                 {
                     ProfScope ps(3, s2);
@@ -1320,6 +1327,13 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
         }
         ASVD_HIP_CHECK(hipMemcpyAsync(flags.data(), wb + p.off_flags, (size_t)batch * 4 * sizeof(int), hipMemcpyDeviceToHost, st));
         ASVD_HIP_CHECK(hipStreamSynchronize(st));
+        if (hist_dev) {
+            int hh[10];
+            ASVD_HIP_CHECK(hipMemcpy(hh, hist_dev, sizeof(hh), hipMemcpyDeviceToHost));
+            fprintf(stderr, "[asvd_svd] sweep %d pair-measure histogram by decade 1e0..1e-9:", sweep + 1);
+            for (int i = 0; i < 10; ++i) fprintf(stderr, " %d", hh[i]);
+            fprintf(stderr, "\n");
+        }
         bool all_done = true;
         bool changed = false;
         for (int b = 0; b < batch; ++b) {
@@ -1348,6 +1362,7 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
         }
     }
 
+    if (hist_dev) (void)hipFree(hist_dev);
     if (ngroups >= 2) {
         (void)hipEventDestroy(ev_fork);
         for (int g = 0; g < ngroups; ++g) (void)hipEventDestroy(ev_join[g]);
