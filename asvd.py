@@ -108,6 +108,8 @@ def build_parser():
     # ---- additive, build-only flags ----
     parser.add_argument("--random_init", action="store_true", help="shape-faithful random-init model named by --model_id (no checkpoints offline)")
     parser.add_argument("--exclude_lm_head", action="store_true", help="do not hook/sweep/compress lm_head (the reference includes it)")
+    parser.add_argument("--no_fused_sweep", dest="fused_sweep", action="store_false",
+                        help="evaluate every (layer, ratio) with full model forwards as the reference does (default: prefix-cached evaluator, same values)")
     parser.add_argument("--dist", action="store_true", help="torchrun launch: one rank per GPU, layers sharded, RCCL all-gather of sensitivities")
     return parser
 

@@ -3,6 +3,7 @@
 calib_sensitivity_ppl:  for every nn.Linear (reverse-DFS order, lm_head first) x candidate ratios, swap in the rank-r
 SVDLinear and measure calibration perplexity.  Differences from the reference that do not change results' meaning:
   * the SVD of a layer is computed ONCE (exact, on device) and sliced for all 6 (19 in kv mode) ratios;
+  * perplexities are evaluated from cached block inputs of the unmodified model (sweep_eval.py) — bit-identical values;
   * with torch.distributed initialised, layers are LPT-sharded over ranks and the per-layer results are exchanged with one
     all-gather (asvd4llm_amd/parallel.py); every rank returns the complete dict in the reference's insertion order.
 calib_sensitivity_stable_rank: forward-free metric -(|W|_F / sigma_max) * ratio**0.1 on the UNSCALED weight; sigma_max
@@ -16,6 +17,7 @@ from tqdm import tqdm
 from . import ops, parallel
 from .evaluate_utils import evaluate_perplexity
 from .modules.svd_linear import SVDLinear
+from .sweep_eval import PrefixCachedEvaluator
 
 
 def collect_linear_info(model):
@@ -69,6 +71,10 @@ def calib_sensitivity_ppl(model, calib_loader, args, use_cache=True):
     if keep_cache and getattr(args, "prefactorize", True) and all(l.weight.is_cuda for l in mine):
         SVDLinear.prefactorize(mine, act_aware=True, alpha=args.alpha, ranks={l: l._asvd_rank_hint for l in mine},
                                max_batch=getattr(args, "svd_batch", 16))
+    # prefix-cached evaluation (sweep_eval.py): same perplexities, about half the forward work; --no_fused_sweep disables
+    evaluator = None
+    if getattr(args, "fused_sweep", True) and n_mine > 0:
+        evaluator = PrefixCachedEvaluator(model, input_ids, args.n_calib_samples)
     pbar = tqdm(total=n_mine * len(param_ratio_candidates), disable=(rank != 0))
     for (raw_linear, info), own in zip(linears, owner):
         if own != rank:
@@ -83,7 +89,10 @@ def calib_sensitivity_ppl(model, calib_loader, args, use_cache=True):
                 rank_align=args.rank_align,
             )
             setattr(info["father"], info["name"], svd_linear)
-            ppl = evaluate_perplexity(model, input_ids, args.n_calib_samples)
+            if evaluator is not None:
+                ppl = evaluator.perplexity(info["full_name"], svd_linear)
+            else:
+                ppl = evaluate_perplexity(model, input_ids, args.n_calib_samples)
             local[info["full_name"]][param_ratio] = ppl
             print(f"{info['full_name']} {param_ratio} {ppl}")
             pbar.update(1)

@@ -1,0 +1,202 @@
+"""Prefix-cached sweep evaluator for calib_sensitivity_ppl.
+
+The reference sweep (sensitivity.py:43-59) swaps ONE Linear, runs `evaluate_perplexity` (evaluate_utils.py:90-115: a full model
+forward per calibration sample), restores the Linear, and repeats for every (layer, ratio): 1350 x n_calib full forwards on
+Llama-2-7B.  Every one of those forwards recomputes the part of the network in front of the swapped layer, which is the
+UNMODIFIED model every time (the sweep restores the raw Linear before moving on, sensitivity.py:59).
+
+This evaluator runs the unmodified model once per calibration sample, keeps the hidden states entering each decoder block
+resident in HBM (n_calib x n_blocks x T x C fp16: 17 GB for Llama-2-7B at n_calib=32 — sized for 288 GB, with a stride
+fallback when memory is short), and evaluates a swapped layer that lives in block i by running only blocks i..N-1 and the
+head.  Blocks in front of i are turned into pass-throughs and block i's input is replaced by the cached tensor, so the
+model's own forward still does everything else (masks, rotary tables, final norm, head): the suffix executes the same
+kernels on the same values as the full forward and the perplexities are bit-identical to the plain evaluator's.
+A Linear that is called after the last block (lm_head, OPT project_out) is evaluated with every block skipped and its own
+cached input substituted.  Average cost per evaluation: (N+1)/2N of a full forward, and ~0 for the head.
+"""
+import torch
+import torch.nn as nn
+
+
+def find_decoder_blocks(model):
+    """The nn.ModuleList holding the repeated decoder blocks: the list whose members own the most nn.Linear parameters."""
+    best, best_name, best_params = None, None, 0
+    for name, mod in model.named_modules():
+        if isinstance(mod, nn.ModuleList) and len(mod) > 0:
+            n = sum(p.numel() for m in mod.modules() if isinstance(m, nn.Linear) for p in m.parameters(recurse=False))
+            if n > best_params:
+                best, best_name, best_params = mod, name, n
+    return best_name, best
+
+
+def _hidden_of(args, kwargs):
+    return args[0] if len(args) > 0 else kwargs["hidden_states"]
+
+
+def _with_hidden(args, kwargs, h):
+    if len(args) > 0:
+        return (h,) + tuple(args[1:]), kwargs
+    kwargs = dict(kwargs)
+    kwargs["hidden_states"] = h
+    return args, kwargs
+
+
+class PrefixCachedEvaluator:
+    def __init__(self, model, input_ids, limit, mem_fraction=0.5):
+        self.model = model
+        self.input_ids = input_ids
+        nsamples, self.seqlen = input_ids.size()
+        self.n = min(nsamples, limit)
+        self.blocks_name, self.blocks = find_decoder_blocks(model)
+        if self.blocks is None:
+            raise RuntimeError("no decoder block list found")
+        self.nblocks = len(self.blocks)
+        self.block_index = {}  # Linear full name -> block index
+        prefix = self.blocks_name + "."
+        self.linear_names = {}
+        for name, mod in model.named_modules():
+            if isinstance(mod, nn.Linear):
+                self.linear_names[mod] = name
+                if name.startswith(prefix):
+                    self.block_index[name] = int(name[len(prefix):].split(".")[0])
+        self._capture(mem_fraction)
+
+    # ------------------------------------------------------------------------------------------------------------
+    def _budget_stride(self, per_block_bytes, mem_fraction):
+        dev = self.model.device
+        if dev.type != "cuda":
+            return 1
+        free, _ = torch.cuda.mem_get_info(dev)
+        total = per_block_bytes * self.nblocks * self.n
+        budget = free * mem_fraction
+        stride = 1
+        while total / stride > budget and stride < self.nblocks:
+            stride += 1
+        return stride
+
+    @torch.no_grad()
+    def _capture(self, mem_fraction):
+        """One forward of the unmodified model per sample: block inputs, post-block Linear inputs, call order."""
+        model = self.model
+        self.cached = [dict() for _ in range(self.n)]  # sample -> {block idx: hidden states}
+        self.tail_inputs = [dict() for _ in range(self.n)]  # sample -> {linear name: input tensor}
+        self.tuple_out = {}
+        order = []
+        cur = {"i": 0}
+        handles = []
+        stride_box = {"s": None}
+
+        def block_pre(idx):
+            def hook(mod, args, kwargs):
+                h = _hidden_of(args, kwargs)
+                if stride_box["s"] is None:
+                    stride_box["s"] = self._budget_stride(h.numel() * h.element_size(), mem_fraction)
+                if idx % stride_box["s"] == 0:
+                    self.cached[cur["i"]][idx] = h.detach().clone()
+                order.append(("block", idx))
+            return hook
+
+        def block_post(idx):
+            def hook(mod, args, out):
+                self.tuple_out[idx] = isinstance(out, tuple)
+            return hook
+
+        for idx, blk in enumerate(self.blocks):
+            handles.append(blk.register_forward_pre_hook(block_pre(idx), with_kwargs=True))
+            handles.append(blk.register_forward_hook(block_post(idx)))
+
+        outside = [(m, n) for m, n in self.linear_names.items() if n not in self.block_index]
+
+        def lin_pre(name):
+            def hook(mod, args):
+                order.append(("linear", name))
+                self.tail_inputs[cur["i"]][name] = args[0].detach().clone()
+            return hook
+
+        for m, n in outside:
+            handles.append(m.register_forward_pre_hook(lin_pre(n)))
+        try:
+            for i in range(self.n):
+                cur["i"] = i
+                if i == 1:
+                    order_first = list(order)
+                ids = self.input_ids[i:i + 1, :-1].to(model.device)
+                model(input_ids=ids, use_cache=False)
+        finally:
+            for h in handles:
+                h.remove()
+        self.stride = stride_box["s"] or 1
+        first = order_first if self.n > 1 else order
+        last_block_pos = max((p for p, (k, _) in enumerate(first) if k == "block"), default=-1)
+        # Linears outside the blocks that run AFTER the last block can be evaluated from their own cached input
+        self.after_blocks = {name for p, (k, name) in enumerate(first) if k == "linear" and p > last_block_pos}
+        for i in range(self.n):
+            self.tail_inputs[i] = {k: v for k, v in self.tail_inputs[i].items() if k in self.after_blocks}
+
+    # ------------------------------------------------------------------------------------------------------------
+    def _skip_blocks(self, upto):
+        """Turn blocks [0, upto) into pass-throughs; returns the undo list."""
+        undo = []
+        for idx in range(upto):
+            blk = self.blocks[idx]
+            had = "forward" in blk.__dict__
+            old = blk.__dict__.get("forward")
+            tup = self.tuple_out.get(idx, False)
+
+            def passthrough(*args, _tup=tup, **kwargs):
+                h = _hidden_of(args, kwargs)
+                return (h,) if _tup else h
+
+            blk.forward = passthrough
+            undo.append((blk, had, old))
+        return undo
+
+    @staticmethod
+    def _restore(undo):
+        for blk, had, old in undo:
+            if had:
+                blk.forward = old
+            else:
+                del blk.forward
+
+    @torch.no_grad()
+    def perplexity(self, full_name, current_module):
+        """Calibration perplexity of the model as it is NOW (one Linear `full_name` swapped for `current_module`);
+        same arithmetic as evaluate_perplexity on the part of the network behind the swap."""
+        model = self.model
+        cur = {"i": 0}
+        undo, handle = [], None
+        if full_name in self.block_index:
+            start = (self.block_index[full_name] // self.stride) * self.stride
+            if start > 0:
+                undo = self._skip_blocks(start)
+
+                def sub(mod, args, kwargs):
+                    return _with_hidden(args, kwargs, self.cached[cur["i"]][start])
+
+                handle = self.blocks[start].register_forward_pre_hook(sub, with_kwargs=True)
+        elif full_name in self.after_blocks:
+            undo = self._skip_blocks(self.nblocks)
+
+            def sub(mod, args):
+                return (self.tail_inputs[cur["i"]][full_name],) + tuple(args[1:])
+
+            handle = current_module.register_forward_pre_hook(sub)
+        # else: a Linear in front of the blocks — nothing can be reused, full forward
+        nlls = []
+        seqlen = self.seqlen
+        try:
+            for i in range(self.n):
+                cur["i"] = i
+                input_ids = self.input_ids[i:i + 1, :-1].to(model.device)
+                labels = self.input_ids[i:i + 1, 1:].contiguous()
+                logits = model(input_ids=input_ids, use_cache=False)[0]
+                shift_labels = labels.to(model.device)
+                loss = nn.CrossEntropyLoss()(logits.view(-1, logits.size(-1)), shift_labels.view(-1))
+                nlls.append(loss.float() * seqlen)
+        finally:
+            if handle is not None:
+                handle.remove()
+            self._restore(undo)
+        ppl = torch.exp(torch.stack(nlls).sum() / (len(nlls) * seqlen))
+        return ppl.item()

@@ -288,3 +288,22 @@ def test_kv_cache_mode_and_rank_align(gpu, golden, tmp_path, monkeypatch):
             assert m.truncation_rank == O.rank_from_ratio(32, 32, ratio, 4)
     assert any(isinstance(m, SVDLinear) for m in model.modules())
     assert all(v == 2 for k, v in model._asvd_layers_min_ratio.items() if isinstance(dict(model.named_modules())[k], nn.Linear))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["tiny-llama", "tiny-opt"])
+def test_fused_sweep_equals_plain_sweep(gpu, name, tmp_path, monkeypatch):
+    """the prefix-cached evaluator returns exactly the perplexities of full forwards (fp16 HF model on the GPU)."""
+    from asvd4llm_amd.act_aware_utils import calib_input_distribution
+    from asvd4llm_amd.datautils import get_calib_data
+    from asvd4llm_amd.model_zoo import random_init_model
+    from asvd4llm_amd.sensitivity import calib_sensitivity_ppl
+    monkeypatch.chdir(tmp_path)
+    model = random_init_model(name, dtype=torch.float16, seed=3).to(gpu)
+    calib = get_calib_data("synthetic", None, name, 2, seed=7, vocab_size=model.config.vocab_size, seqlen=128)
+    with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+        calib_input_distribution(model, calib, "abs_mean", False)
+        fused = calib_sensitivity_ppl(model, calib, default_args(n_calib_samples=2, calib_dataset="synthetic", fused_sweep=True), use_cache=False)
+        plain = calib_sensitivity_ppl(model, calib, default_args(n_calib_samples=2, calib_dataset="synthetic", fused_sweep=False), use_cache=False)
+    assert list(fused.keys()) == list(plain.keys())
+    assert fused == plain

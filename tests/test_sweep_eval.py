@@ -1,0 +1,75 @@
+"""Prefix-cached sweep evaluator (asvd4llm_amd/sweep_eval.py) == plain evaluate_perplexity, bit for bit, on CPU.
+The swapped module is an arbitrary perturbed nn.Linear, so no GPU kernel is involved."""
+import copy
+
+import pytest
+import torch
+import torch.nn as nn
+
+from asvd4llm_amd.evaluate_utils import evaluate_perplexity
+from asvd4llm_amd.model_zoo import random_init_model
+from asvd4llm_amd.sensitivity import collect_linear_info
+from asvd4llm_amd.sweep_eval import PrefixCachedEvaluator, find_decoder_blocks
+from tests.tiny_lm import TinyLM
+
+
+def _perturbed(linear, seed):
+    g = torch.Generator().manual_seed(seed)
+    new = copy.deepcopy(linear)
+    new.weight.data += 0.05 * new.weight.data.std() * torch.randn(new.weight.shape, generator=g)
+    return new
+
+
+def _check_model(model, vocab, n=3, T=24):
+    torch.manual_seed(5)
+    ids = torch.randint(0, vocab, (n, T))
+    model.eval()
+    ev = PrefixCachedEvaluator(model, ids, n)
+    info = collect_linear_info(model)
+    base = evaluate_perplexity(model, ids, n)
+    checked = set()
+    for k, (lin, meta) in enumerate(info.items()):
+        swapped = _perturbed(lin, k)
+        setattr(meta["father"], meta["name"], swapped)
+        try:
+            plain = evaluate_perplexity(model, ids, n)
+            fused = ev.perplexity(meta["full_name"], swapped)
+        finally:
+            setattr(meta["father"], meta["name"], lin)
+        assert plain == fused, (meta["full_name"], plain, fused)
+        assert plain != base
+        checked.add("block" if meta["full_name"] in ev.block_index else "tail" if meta["full_name"] in ev.after_blocks else "full")
+    assert evaluate_perplexity(model, ids, n) == base  # nothing left patched
+    return ev, checked
+
+
+def test_blocks_found_and_values_identical_tiny_lm():
+    model = TinyLM(n_layers=3)
+    name, blocks = find_decoder_blocks(model)
+    assert name == "model.layers" and len(blocks) == 3
+    ev, kinds = _check_model(model, 50)
+    assert kinds == {"block", "tail"} and ev.after_blocks == {"lm_head"}
+
+
+@pytest.mark.parametrize("name", ["tiny-llama", "tiny-opt"])
+def test_values_identical_hf(name):
+    model = random_init_model(name, dtype=torch.float32, seed=1)
+    ev, kinds = _check_model(model, model.config.vocab_size)
+    assert "block" in kinds and "tail" in kinds
+    assert ev.nblocks == model.config.num_hidden_layers
+
+
+def test_stride_fallback_identical():
+    model = TinyLM(n_layers=4)
+    torch.manual_seed(1)
+    ids = torch.randint(0, 50, (2, 16))
+    ev = PrefixCachedEvaluator(model, ids, 2)
+    # emulate a memory-limited capture: keep only every 2nd block input
+    ev.stride = 2
+    for c in ev.cached:
+        for k in [k for k in c if k % 2]:
+            del c[k]
+    lin = model.model.layers[3].mlp.up_proj
+    swapped = _perturbed(lin, 0)
+    model.model.layers[3].mlp.up_proj = swapped
+    assert ev.perplexity("model.layers.3.mlp.up_proj", swapped) == evaluate_perplexity(model, ids, 2)

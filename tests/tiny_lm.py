@@ -22,6 +22,12 @@ class Layer(nn.Module):
         super().__init__()
         self.self_attn, self.mlp = Attn(d), Mlp(d, f)
 
+    def forward(self, h):
+        a = self.self_attn
+        h = h + a.o_proj(torch.tanh(a.q_proj(h)) * torch.sigmoid(a.k_proj(h)) + a.v_proj(h))
+        m = self.mlp
+        return h + m.down_proj(torch.nn.functional.silu(m.gate_proj(h)) * m.up_proj(h))
+
 
 class TinyLM(nn.Module):
     def __init__(self, d=32, f=80, n_layers=2, vocab=50, seed=0):
@@ -40,10 +46,7 @@ class TinyLM(nn.Module):
     def forward(self, input_ids=None, **kw):
         h = self.model.embed_tokens(input_ids)
         for l in self.model.layers:
-            a = l.self_attn
-            h = h + a.o_proj(torch.tanh(a.q_proj(h)) * torch.sigmoid(a.k_proj(h)) + a.v_proj(h))
-            m = l.mlp
-            h = h + m.down_proj(torch.nn.functional.silu(m.gate_proj(h)) * m.up_proj(h))
+            h = l(h)
         return (self.lm_head(h),)
 
 

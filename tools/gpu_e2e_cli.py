@@ -7,7 +7,7 @@ name = sys.argv[1] if len(sys.argv) > 1 else "tiny-llama"
 n_calib = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 os.makedirs("gpurun_out/e2e", exist_ok=True); os.chdir("gpurun_out/e2e")
 args = asvd.build_parser().parse_args(["--model_id", name, "--random_init", "--act_aware", "--alpha", "0.5", "--n_calib_samples", str(n_calib),
-                                       "--calib_dataset", "synthetic", "--param_ratio_target", "0.9", "--scaling_method", "abs_mean"])
+                                       "--calib_dataset", "synthetic", "--param_ratio_target", "0.9", "--scaling_method", "abs_mean"] + sys.argv[3:])
 from asvd4llm_amd.act_aware_utils import calib_input_distribution
 from asvd4llm_amd.binary_search import binary_search_truncation_rank
 from asvd4llm_amd.datautils import get_calib_data
@@ -29,5 +29,5 @@ with contextlib.redirect_stdout(buf), contextlib.redirect_stderr(io.StringIO()):
     ppl1 = evaluate_perplexity(model, ids, n_calib)
 nsvd = sum(1 for m in model.modules() if isinstance(m, SVDLinear))
 tot = sum(p.numel() for p in model.parameters())
-print(json.dumps({"model": name, "n_calib": n_calib, "linears": len(sens), "svd_linears_after": nsvd, "ppl_raw": ppl0, "ppl_after": ppl1, "params_after": tot,
+print(json.dumps({"model": name, "n_calib": n_calib, "fused_sweep": args.fused_sweep, "linears": len(sens), "svd_linears_after": nsvd, "ppl_raw": ppl0, "ppl_after": ppl1, "params_after": tot,
                   "timings_s": t, "trace_tail": [l for l in buf.getvalue().splitlines() if l.startswith("low=") or l.startswith("decompose")][-3:]}))
