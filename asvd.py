@@ -64,6 +64,12 @@ def main(args):
         if args.weight_quant != "none":
             raise NotImplementedError("weight quantization (rtn/awq) is outside the hot-path scope of this build (SURVEY.md §2)")
 
+        if args.save_repo and (not args.dist or int(os.environ.get("RANK", "0")) == 0):
+            # exported-repo layout of huggingface_repos/build_asvd_repo.py:58-92 (truncation_ranks + ALinear/BLinear keys)
+            from asvd4llm_amd.export import save_asvd_repo
+            ranks = save_asvd_repo(model, args.save_repo, tokenizer if hasattr(tokenizer, "save_pretrained") else None)
+            print(f"saved ASVD repo with {len(ranks)} factorised layers to {args.save_repo}")
+
     eval_ids = torch.cat([_["input_ids"] for _ in calib_loader], 0) if (not args.raw_model and args.calib_dataset == "synthetic") else None
     result = evaluate_model(model, tokenizer, args.model_id, "mmlu" if args.eval_mmlu else args.eval_tasks, eval_ppl=args.eval_ppl, limit=-1,
                             use_bos=args.use_bos, eval_ids=eval_ids)
@@ -108,6 +114,7 @@ def build_parser():
     # ---- additive, build-only flags ----
     parser.add_argument("--random_init", action="store_true", help="shape-faithful random-init model named by --model_id (no checkpoints offline)")
     parser.add_argument("--exclude_lm_head", action="store_true", help="do not hook/sweep/compress lm_head (the reference includes it)")
+    parser.add_argument("--save_repo", type=str, default="", help="write the compressed model in the exported HF-repo layout of the reference (truncation_ranks in config.json)")
     parser.add_argument("--no_fused_sweep", dest="fused_sweep", action="store_false",
                         help="evaluate every (layer, ratio) with full model forwards as the reference does (default: prefix-cached evaluator, same values)")
     parser.add_argument("--dist", action="store_true", help="torchrun launch: one rank per GPU, layers sharded, RCCL all-gather of sensitivities")
