@@ -131,6 +131,16 @@ def main():
         achieved = f_svd * (value / world) / 1e12  # algorithmic TFLOP/s per GPU of the whole SVD job, from the timed region's wall clock
         roofline["svd_level"] = {"bound": "mfma", "unit_of_work": "one economy SVD, F = 14 m n^2 + 8 n^3", "achieved": achieved, "peak": 157.3,
                                  "unit": "TFLOP/s", "frac": achieved / 157.3}
+        # the same kernels seen from the MFMA side: executed fp32-MFMA flops of one gram/update launch (2*rows*64*64 per panel pair) and
+        # of the whole Jacobi phase — at panel width 32 the HBM and the fp32-MFMA ceilings of the streaming kernels nearly coincide
+        pairs = (cols_pad // 32) // 2
+        flops_launch = 2.0 * rows_pad * 64 * 64 * pairs * per_launch_problems
+        if dom in alg_bytes:
+            roofline["mfma_view"] = {"flops_per_launch": flops_launch, "achieved": flops_launch / (classes[dom]["avg_us"] * 1e-6) / 1e12,
+                                     "peak": 157.3, "unit": "TFLOP/s", "frac": flops_launch / (classes[dom]["avg_us"] * 1e-6) / 1e12 / 157.3}
+        issued = flops_launch * (classes["gram"]["launches"] + classes["update"]["launches"])  # upper estimate: skipped pairs not subtracted
+        roofline["executed_tflops_whole_job"] = {"issued_fp32_mfma_flops_per_step": issued, "achieved": issued / (dt / args.steps) / 1e12,
+                                                 "peak": 157.3, "unit": "TFLOP/s"}
         roofline["classes"] = classes
         roofline["sweeps"] = [i.sweeps for i in infos]
         out = {

@@ -35,7 +35,7 @@ def build_linears(name, dev, n_layers=None, seed=233):
     for l in range(L):
         for nm in ("q", "k", "v", "o"):
             out.append(mk(*cfg["attn"], f"l{l}.{nm}"))
-        for nm in ("gate", "up"):
+        for nm in (("fc1",) if name.startswith("opt") else ("gate", "up")):
             out.append(mk(*cfg["mlp_up"], f"l{l}.{nm}"))
         out.append(mk(*cfg["mlp_down"], f"l{l}.down"))
     if n_layers is None:
