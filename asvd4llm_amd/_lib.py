@@ -29,6 +29,8 @@ SIGNATURES = {
     "asvd_svd_batched": (_i, [_i, _c.POINTER(_vp), _i, _i64, _i64, _i64, _c.POINTER(_vp), _i, _c.POINTER(_vp),
                               _c.POINTER(_vp), _c.POINTER(_vp), _i64, _i, _f, _vp, _sz, _c.POINTER(_i), _vp]),
     "asvd_svd": (_i, [_vp, _i, _i64, _i64, _i64, _vp, _i, _vp, _vp, _vp, _i64, _i, _f, _vp, _sz, _c.POINTER(_i), _vp]),
+    "asvd_sigma_max_worksize": (_i, [_i, _i64, _i64, _i, _c.POINTER(_sz)]),
+    "asvd_sigma_max_batched": (_i, [_i, _c.POINTER(_vp), _i, _i64, _i64, _i64, _c.POINTER(_vp), _i, _f, _vp, _sz, _c.POINTER(_i), _vp]),
     "asvd_truncate_split": (_i, [_vp, _i64, _vp, _vp, _i64, _vp, _i, _i64, _i64, _i64, _i, _vp, _vp, _i, _vp, _vp]),
     "asvd_fro_worksize": (_i, [_i64, _i64, _c.POINTER(_sz)]),
     "asvd_fro_norm_sq": (_i, [_vp, _i, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),

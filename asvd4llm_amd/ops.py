@@ -134,6 +134,47 @@ def svd(a, col_scale=None, k=None, want_vectors=True, max_sweeps=0, tol=0.0):
     return None, S[0], None, infos[0]
 
 
+SIGMA_MAX_COLS = 16384  # asvd_sigma_max_batched keeps the Lanczos vector in LDS
+
+
+def sigma_max_batched(mats, max_steps=0, tol=0.0):
+    """Largest singular value of each matrix of a same-shape list (Lanczos, asvd_sigma_max_batched).
+    Returns (list of 0-dim fp32 device tensors, list of (status, steps)).  Matrices with more than SIGMA_MAX_COLS columns,
+    and any problem the Lanczos iteration reports as not converged, go through the values-only k=1 mode of the Jacobi SVD."""
+    lib = L.load(True)
+    B = len(mats)
+    assert B >= 1
+    m, n = mats[0].shape
+    dev = mats[0].device
+    for a in mats:
+        _dev(a, "matrix")
+        assert a.shape == (m, n) and a.dtype == mats[0].dtype and a.stride(1) == 1 and a.stride(0) == mats[0].stride(0)
+    if n > SIGMA_MAX_COLS:
+        _, S, _, infos = svd_batched(mats, None, k=1, want_vectors=False)
+        return [s[0] for s in S], [(i.status, -i.sweeps) for i in infos]
+    nb = ctypes.c_size_t()
+    L.check(lib.asvd_sigma_max_worksize(B, m, n, int(max_steps), ctypes.byref(nb)), "asvd_sigma_max_worksize")
+    work = _work(nb.value, dev)
+    out = torch.empty(B, dtype=torch.float32, device=dev)
+    arr = ctypes.c_void_p * B
+    a_p = arr(*[a.data_ptr() for a in mats])
+    o_p = arr(*[out.data_ptr() + 4 * b for b in range(B)])
+    info = (ctypes.c_int * (2 * B))()
+    with torch.cuda.device(dev):
+        rc = lib.asvd_sigma_max_batched(B, a_p, _dt(mats[0]), m, n, mats[0].stride(0), o_p, int(max_steps), float(tol), _ptr(work),
+                                        work.numel(), info, _stream(mats[0]))
+    L.check(rc, "asvd_sigma_max_batched")
+    sig = [out[b] for b in range(B)]
+    infos = [(info[2 * b], info[2 * b + 1]) for b in range(B)]
+    redo = [b for b in range(B) if infos[b][0] == 1]  # ASVD_N_NOCONV: still moving after max_steps
+    if redo:
+        _, S, _, jinfos = svd_batched([mats[b] for b in redo], None, k=1, want_vectors=False)
+        for b, s, ji in zip(redo, S, jinfos):
+            sig[b] = s[0]
+            infos[b] = (ji.status, -ji.sweeps)
+    return sig, infos
+
+
 def truncate_split(U, S, V, s, r, sigma_fuse, out_dtype):
     """(A [m,r], B [r,n], nan_flags[3]) per SVDLinear.__init__ + un-scaling (svd_linear.py:69-70,16-24,102)"""
     lib = L.load(True)

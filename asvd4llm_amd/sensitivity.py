@@ -7,7 +7,8 @@ SVDLinear and measure calibration perplexity.  Differences from the reference th
   * with torch.distributed initialised, layers are LPT-sharded over ranks and the per-layer results are exchanged with one
     all-gather (asvd4llm_amd/parallel.py); every rank returns the complete dict in the reference's insertion order.
 calib_sensitivity_stable_rank: forward-free metric -(|W|_F / sigma_max) * ratio**0.1 on the UNSCALED weight; sigma_max
-comes from the values-only mode of the same HIP SVD, |W|_F^2 from asvd_fro_norm_sq."""
+comes from the Lanczos kernel asvd_sigma_max_batched (the reference factorises the whole matrix for this one number),
+|W|_F^2 from asvd_fro_norm_sq."""
 import os
 
 import torch
@@ -125,17 +126,29 @@ def calib_sensitivity_stable_rank(model, calib_loader, args, use_cache=True):
     owner = parallel.lpt_assign([parallel.svd_flops(l.out_features, l.in_features) for l, _ in linears], ws)
     local = {}
     pbar = tqdm(total=len(linears) * len(param_ratio_candidates), disable=(rank != 0))
-    for (raw_linear, info), own in zip(linears, owner):
-        if own != rank:
-            continue
+    # sigma_max of this rank's layers: Lanczos kernel (asvd_sigma_max_batched), same-shape layers batched (keeps the GPU full)
+    mine = [(raw_linear, info) for (raw_linear, info), own in zip(linears, owner) if own == rank]
+    contiguous = {l: (l.weight.data if l.weight.data.stride(1) == 1 else l.weight.data.contiguous()) for l, _ in mine}
+    groups = {}
+    for l, _ in mine:
+        w = contiguous[l]
+        groups.setdefault((tuple(w.shape), w.dtype, w.stride(0), w.device), []).append(l)
+    sigma_max = {}
+    max_batch = getattr(args, "svd_batch", 16)
+    for members in groups.values():
+        for i in range(0, len(members), max_batch):
+            chunk = members[i:i + max_batch]
+            sig, _ = ops.sigma_max_batched([contiguous[l] for l in chunk])
+            for l, sv in zip(chunk, sig):
+                sigma_max[l] = sv
+    for raw_linear, info in mine:
         # stable rank = |W|_F / sigma_max on the unscaled weight (sensitivity.py:96-104; scaling commented out there).
         w = raw_linear.weight.data
-        wc = w if w.stride(1) == 1 else w.contiguous()
+        wc = contiguous[raw_linear]
         sumsq = ops.fro_norm_sq(wc)  # fp32 sum of squares
         # torch.norm(w, "fro") ** 2 is evaluated in the weight dtype: sqrt rounded to w.dtype, then squared in w.dtype
         w_fro = (sumsq.sqrt().to(w.dtype)) ** 2
-        _, S, _, _ = ops.svd(wc, None, k=1, want_vectors=False)
-        spectral_norm = S[0]
+        spectral_norm = sigma_max[raw_linear]
         w_spec = spectral_norm ** 2
         sr = (w_fro / w_spec) ** 0.5
         sr = sr.reshape(())

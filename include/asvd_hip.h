@@ -124,6 +124,25 @@ int asvd_svd(const void* a, int a_dtype, int64_t m, int64_t n, int64_t lda, cons
              void* work, size_t work_bytes, int* info_host, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * K4s  largest singular value only.  Replaces sensitivity.py:101-102 of calib_sensitivity_stable_rank
+ * (`_, singular_values, _ = torch.svd(w.float(), compute_uv=False); spectral_norm = torch.max(singular_values)`):
+ * the reference factorises the whole matrix and keeps one number.  Lanczos on W^T W (two matrix-vector passes
+ * over W per step, fp32 vectors, fp64 recurrence coefficients); every 16 steps the largest Ritz value is found by
+ * multisection on the Sturm count and the iteration stops when it moved by less than tol (relative, in sigma^2)
+ * over the last 16 steps.  HBM/L2-bound: 2*m*n*sizeof(elem) bytes per step.
+ *   a_host      host array [batch] of device pointers to W_b [m, n] row-major (leading dim lda), n <= 16384
+ *   sigma_host  host array [batch] of device pointers to one float each (sigma_max of W_b)
+ *   max_steps   <=0: default 1024 (rounded up to a multiple of 16);  tol <=0: default 1e-8
+ *   info_host   optional host int[2*batch]: {status, Lanczos steps}
+ * Host-synchronous (one stream sync per 16 steps).  Returns worst status over the batch (ASVD_N_NOCONV: value is a
+ * lower bound that was still moving — callers fall back to asvd_svd_batched with k = 1).
+ */
+int asvd_sigma_max_worksize(int batch, int64_t m, int64_t n, int max_steps, size_t* bytes);
+int asvd_sigma_max_batched(int batch, const void* const* a_host, int a_dtype, int64_t m, int64_t n, int64_t lda,
+                           float* const* sigma_host, int max_steps, float tol, void* work, size_t work_bytes,
+                           int* info_host, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * K5/K6  truncate to rank r, un-scale V, fuse sigma, transpose V, down-cast, NaN flag.
  * Replaces svd_linear.py:69-70 (`V = V / s.view(-1,1)`), :81-98 (NaN checks) and SVDLinear.__init__
  * :16-24 + the `.to(dtype)` at :102:

@@ -48,5 +48,18 @@ for (m, n, r) in ((4096, 4096, 512), (4096, 4096, 1843), (11008, 4096, 2686)):
     out.append({"kernel": "scale_cols", "shape": [m, n], "us": t * 1e6, "alg_bytes": b, "GBps": b / t / 1e9})
     t = timeit(lambda: ops.fro_norm_sq(W))
     out.append({"kernel": "fro_norm_sq", "shape": [m, n], "us": t * 1e6, "alg_bytes": m * n * 2, "GBps": m * n * 2 / t / 1e9})
+# K4s sigma_max (Lanczos): algorithmic bytes = 2 passes over W per step (the second pass re-reads the 64-row chunk from L2)
+import time
+for (m, n, B) in ((4096, 4096, 16), (11008, 4096, 16), (4096, 11008, 16), (4096, 4096, 1)):
+    mats = [(torch.randn(m, n, device=dev) * 0.02).half() for _ in range(B)]
+    ops.sigma_max_batched(mats)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    sig, info = ops.sigma_max_batched(mats)
+    torch.cuda.synchronize(); t = time.perf_counter() - t0
+    steps = max(i[1] for i in info)
+    b = 2.0 * m * n * 2 * B * steps
+    _, S, _, _ = ops.svd_batched(mats[:1], None, k=1, want_vectors=False)
+    out.append({"kernel": "sigma_max_lanczos", "shape": [m, n], "batch": B, "lanczos_steps": steps, "ms_total": t * 1e3, "ms_per_matrix": t * 1e3 / B,
+                "alg_bytes": b, "GBps": b / t / 1e9, "rel_diff_vs_jacobi_k1": abs(sig[0].item() - S[0][0].item()) / S[0][0].item()})
 for o in out:
     print(json.dumps(o))

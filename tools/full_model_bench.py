@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--ratio", type=float, default=0.9)
     ap.add_argument("--alpha", type=float, default=0.5)
     ap.add_argument("--svd_batch", type=int, default=16)
+    ap.add_argument("--stable_rank", action="store_true", help="time calib_sensitivity_stable_rank (values-only sigma_max per layer) instead")
     ap.add_argument("--full_rank", action="store_true", help="factorise all min(m,n) triplets instead of the rank needed at --ratio")
     args = ap.parse_args()
     from asvd4llm_amd import _lib, ops
@@ -62,6 +63,19 @@ def main():
     lins = build_linears(args.model, dev, args.layers)
     torch.cuda.synchronize()
     t_build = time.time() - t0
+    if args.stable_rank:
+        import types
+        from asvd4llm_amd.sensitivity import calib_sensitivity_stable_rank
+        holder = nn.Module()
+        holder.layers = nn.ModuleList(lins)
+        holder.config = types.SimpleNamespace(_name_or_path="bench/" + args.model)
+        sargs = types.SimpleNamespace(scaling_method="abs_mean", alpha=args.alpha, n_calib_samples=1, calib_dataset="synthetic", svd_batch=args.svd_batch)
+        os.makedirs("gpurun_out/sr", exist_ok=True); os.chdir("gpurun_out/sr")
+        torch.cuda.synchronize(); t0 = time.time()
+        sens = calib_sensitivity_stable_rank(holder, [{"input_ids": torch.zeros(1, 4, dtype=torch.long)}], sargs, use_cache=False)
+        torch.cuda.synchronize(); t_sr = time.time() - t0
+        print(json.dumps({"model": args.model, "linears": len(lins), "stable_rank_sensitivity_s": t_sr, "layers_in_dict": len(sens)}))
+        return
     ranks = {l: SVDLinear.compute_rank(l, args.ratio) for l in lins}
     flops = sum(svd_flops(l.out_features, l.in_features) for l in lins)
     torch.cuda.synchronize(); t0 = time.time()
