@@ -21,6 +21,28 @@ import torch
 
 # ---------------------------------------------------------------------------------------------------------------
 # a2  rank arithmetic — modules/svd_linear.py:39-44
+def synth_linear_numpy(out_features, in_features, seed, n_calib=16):
+    """Seed-regenerated 'LLM-like' Linear for the mid-size fixtures (tests/golden/svd_mid.*): numpy PCG64 streams are
+    platform-stable, so the fixture stores only a checksum of the inputs instead of megabytes of weights.
+    Returns (W fp16 [out,in], scaling_diag_matrix fp16 [in]) as torch tensors."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    W = (rng.standard_normal((out_features, in_features)) * 0.02).astype(np.float32)
+    k = max(1, int(0.005 * in_features))
+    W[:, rng.permutation(in_features)[:k]] *= 20
+    scal = (n_calib * np.abs(rng.standard_normal(in_features))).astype(np.float32)
+    k = max(1, int(0.01 * in_features))
+    scal[rng.permutation(in_features)[:k]] *= 30
+    return torch.from_numpy(W).to(torch.float16), torch.from_numpy(scal).to(torch.float16)
+
+
+def tensor_checksum(*tensors):
+    import hashlib
+    h = hashlib.sha256()
+    for t in tensors:
+        h.update(t.contiguous().cpu().numpy().tobytes())
+    return h.hexdigest()
+
+
 def rank_from_ratio(out_features, in_features, param_ratio, rank_align=1):
     n_params = out_features * in_features
     compressed_params = int(n_params * param_ratio)

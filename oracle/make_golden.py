@@ -177,6 +177,44 @@ def gen_svd():
     json.dump(meta, open(os.path.join(OUT, "svd_linear_meta.json"), "w"), indent=0)
 
 
+# ---- F-svd-mid: opt-125m shapes (BASELINE configs[0]), inputs regenerated from a seed ---------------------------
+def gen_svd_mid():
+    sys.path.insert(0, os.path.join(OUT, "..", ".."))
+    from oracle import asvd_oracle as O
+    out, meta = {}, []
+    stock = torch.svd_lowrank
+    captured = {}
+
+    def capturing_lowrank(w, q=6, niter=2, M=None):
+        U, S, Vh = torch.linalg.svd(w, full_matrices=False)
+        captured["S"] = S.clone()
+        return U[:, :q], S[:q], Vh[:q].transpose(0, 1)
+
+    for ci, (o, i, ratio) in enumerate([(768, 768, 0.9), (3072, 768, 0.9), (768, 3072, 0.9), (768, 768, 0.4)]):
+        seed = 7000 + ci
+        W, scal = O.synth_linear_numpy(o, i, seed)
+        lin = nn.Linear(i, o, bias=False).to(torch.float16)
+        lin.weight.data = W
+        lin.scaling_diag_matrix = scal
+        torch.svd_lowrank = capturing_lowrank
+        with contextlib.redirect_stdout(io.StringIO()):
+            m = SVDLinear.from_linear(lin, ratio, act_aware=True, alpha=0.5, sigma_fuse="UV")
+        torch.svd_lowrank = stock
+        assert isinstance(m, SVDLinear)
+        r = int(m.truncation_rank)
+        X = torch.from_numpy(np.random.Generator(np.random.PCG64(99 + ci)).standard_normal((i, 16)).astype(np.float32))
+        A, B = m.ALinear.weight.data.float(), m.BLinear.weight.data.float()
+        out[f"m{ci}_probe_x"] = npy(X)
+        out[f"m{ci}_probe_y"] = npy(A @ (B @ X))          # the reference's compressed layer applied to 16 probe vectors
+        out[f"m{ci}_probe_wx"] = npy(W.float() @ X)
+        out[f"m{ci}_sigma"] = npy(captured["S"])           # full fp32 spectrum of W*diag(s) as the reference's factorisation saw it
+        meta.append({"case": ci, "out": o, "in": i, "ratio": ratio, "alpha": 0.5, "seed": seed, "rank": r,
+                     "inputs_sha256": O.tensor_checksum(W, scal),
+                     "ref_rel_err_unscaled": float((W.float() - A @ B).norm() / W.float().norm())})
+    np.savez_compressed(os.path.join(OUT, "svd_mid.npz"), **out)
+    json.dump(meta, open(os.path.join(OUT, "svd_mid_meta.json"), "w"), indent=0)
+
+
 # ---- tiny model for order / search / stable-rank / ppl ---------------------------------------------------------
 class Attn(nn.Module):
     def __init__(self, d):
@@ -308,6 +346,7 @@ if __name__ == "__main__":
     gen_rank()
     gen_hook()
     gen_svd()
+    gen_svd_mid()
     gen_search()
     gen_order_hf()
     for f in sorted(os.listdir(OUT)):

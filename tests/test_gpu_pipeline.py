@@ -307,3 +307,29 @@ def test_fused_sweep_equals_plain_sweep(gpu, name, tmp_path, monkeypatch):
         plain = calib_sensitivity_ppl(model, calib, default_args(n_calib_samples=2, calib_dataset="synthetic", fused_sweep=False), use_cache=False)
     assert list(fused.keys()) == list(plain.keys())
     assert fused == plain
+
+
+def test_from_linear_vs_reference_mid_size_fixtures(gpu, golden):
+    """opt-125m shapes (BASELINE configs[0]) against what the imported reference produced for the same seeded inputs:
+    sigma over the retained rank <= 1e-4, the compressed layer applied to 16 probe vectors <= 1e-3 |W x|."""
+    from asvd4llm_amd.modules.svd_linear import SVDLinear
+    meta = golden.json("svd_mid_meta.json")
+    g = golden.npz("svd_mid.npz")
+    for rec in meta:
+        ci = rec["case"]
+        W, scal = O.synth_linear_numpy(rec["out"], rec["in"], rec["seed"])
+        assert O.tensor_checksum(W, scal) == rec["inputs_sha256"]
+        lin = nn.Linear(rec["in"], rec["out"], bias=False).to(torch.float16)
+        lin.weight.data = W
+        lin = lin.to(gpu)
+        lin.scaling_diag_matrix = scal.to(gpu)
+        m = SVDLinear.from_linear(lin, rec["ratio"], act_aware=True, alpha=rec["alpha"], sigma_fuse="UV")
+        r = rec["rank"]
+        assert isinstance(m, SVDLinear) and m.truncation_rank == r
+        _, S, _, _ = SVDLinear.factorize(lin, act_aware=True, alpha=rec["alpha"], k=r)
+        S_ref = torch.from_numpy(g[f"m{ci}_sigma"])
+        assert O.sigma_rel_err(S.cpu(), S_ref, r) <= 1e-4
+        X = torch.from_numpy(g[f"m{ci}_probe_x"])
+        y = (m.ALinear.weight.data.float() @ (m.BLinear.weight.data.float() @ X.to(gpu))).cpu()
+        y_ref, wx = torch.from_numpy(g[f"m{ci}_probe_y"]), torch.from_numpy(g[f"m{ci}_probe_wx"])
+        assert ((y - y_ref).norm() / wx.norm()).item() <= 1e-3, (ci, ((y - y_ref).norm() / wx.norm()).item())

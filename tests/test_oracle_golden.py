@@ -93,3 +93,23 @@ def test_stable_rank_and_search_trace(golden):
                 assert want_rank == -1
             else:
                 assert O.rank_from_ratio(lin.out_features, lin.in_features, ratio) == want_rank
+
+
+def test_mid_size_fixtures_pin_the_oracle(golden):
+    """opt-125m shapes (BASELINE configs[0]): inputs regenerated from the seed, outputs produced by the imported reference."""
+    meta = golden.json("svd_mid_meta.json")
+    g = golden.npz("svd_mid.npz")
+    for rec in meta:
+        ci = rec["case"]
+        W, scal = O.synth_linear_numpy(rec["out"], rec["in"], rec["seed"])
+        assert O.tensor_checksum(W, scal) == rec["inputs_sha256"], "seed-regenerated fixture inputs differ from the ones the reference saw"
+        o = O.from_linear_oracle(W, scal, rec["ratio"], alpha=rec["alpha"], act_aware=True, sigma_fuse="UV")
+        r = rec["rank"]
+        assert o["rank"] == r
+        S_ref = torch.from_numpy(g[f"m{ci}_sigma"])
+        assert O.sigma_rel_err(o["S"], S_ref, r) <= 1e-5
+        X = torch.from_numpy(g[f"m{ci}_probe_x"])
+        y = o["A"].float() @ (o["B"].float() @ X)
+        y_ref, wx = torch.from_numpy(g[f"m{ci}_probe_y"]), torch.from_numpy(g[f"m{ci}_probe_wx"])
+        assert torch.allclose(W.float() @ X, wx, rtol=1e-5, atol=1e-6)
+        assert ((y - y_ref).norm() / wx.norm()).item() <= 1e-3
