@@ -38,6 +38,7 @@ SIGNATURES = {
     "asvd_reconstruct_err": (_i, [_vp, _i, _i64, _vp, _vp, _i, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
     "asvd_svd_set_profiling": (None, [_i]),
     "asvd_svd_get_profile": (_i, [_c.POINTER(_f), _c.POINTER(_i)]),
+    "asvd_svd_get_pair_counts": (_i, [_c.POINTER(_c.c_longlong)]),
 }
 
 _lib = None

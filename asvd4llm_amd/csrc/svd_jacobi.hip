@@ -1143,6 +1143,7 @@ int make_plan(int batch, int64_t m, int64_t n, int want_u, int want_vv, Plan& p)
 bool g_prof_enabled = false;
 float g_prof_ms[5] = {0, 0, 0, 0, 0};
 int g_prof_launches[5] = {0, 0, 0, 0, 0};
+long long g_prof_pairs[2] = {0, 0};  // {pair visits (gram), rotated pairs (evd + update)} of the last profiled call
 struct ProfRec { int cls; hipEvent_t a, b; };
 std::vector<ProfRec> g_prof_recs;
 
@@ -1157,6 +1158,7 @@ struct ProfScope {
 };
 void prof_begin() {
     for (int i = 0; i < 5; ++i) { g_prof_ms[i] = 0; g_prof_launches[i] = 0; }
+    g_prof_pairs[0] = g_prof_pairs[1] = 0;
     g_prof_recs.clear();
 }
 void prof_end() {
@@ -1190,6 +1192,13 @@ int launch_pack(const void* src, int64_t ld, const void* s, int cs_dtype, const 
 extern "C" {
 
 void asvd_svd_set_profiling(int enabled) { g_prof_enabled = enabled != 0; }
+int asvd_svd_get_pair_counts(long long* counts_host) {
+    if (!counts_host) return ASVD_E_BADARG;
+    counts_host[0] = g_prof_pairs[0];
+    counts_host[1] = g_prof_pairs[1];
+    return ASVD_OK;
+}
+
 int asvd_svd_get_profile(float* ms_host, int* launches_host) {
     if (!ms_host || !launches_host) return ASVD_E_BADARG;
     for (int i = 0; i < 5; ++i) { ms_host[i] = g_prof_ms[i]; launches_host[i] = g_prof_launches[i]; }
@@ -1378,6 +1387,7 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
             std::memcpy(&mo, &bits, sizeof(float));
             sweeps_done[b] = sweep + 1;
             last_rot[b] = flags[batch + b];
+            if (g_prof_enabled) { g_prof_pairs[0] += (long long)p.nb * (p.nb - 1) / 2; g_prof_pairs[1] += last_rot[b]; }
             last_off[b] = mo;
             if (debug) fprintf(stderr, "[asvd_svd] b=%d sweep=%d maxoff=%.3e rotated_pairs=%d\n", b, sweep + 1, mo, last_rot[b]);
             if (mo != mo) { status[b] = ASVD_N_NAN; host_done[b] = 1; changed = true; }

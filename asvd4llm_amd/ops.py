@@ -233,4 +233,8 @@ def svd_profile(enable=None):
     n = (ctypes.c_int * 5)()
     lib.asvd_svd_get_profile(ms, n)
     names = ["pack", "gram", "evd", "update", "finalize"]
-    return {names[i]: {"ms": ms[i], "launches": n[i]} for i in range(5)}
+    out = {names[i]: {"ms": ms[i], "launches": n[i]} for i in range(5)}
+    cnt = (ctypes.c_longlong * 2)()
+    lib.asvd_svd_get_pair_counts(cnt)
+    out["pairs"] = {"visited": int(cnt[0]), "rotated": int(cnt[1])}
+    return out

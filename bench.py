@@ -102,16 +102,22 @@ def main():
         total_svds = B * args.steps * world
         value = total_svds / dt
         f_svd = svd_flops(m, n)
+        pairs_cnt = prof.pop("pairs")
         dom = max(("gram", "evd", "update"), key=lambda k: prof[k]["ms"])
         classes = {k: {"ms_per_step": v["ms"], "launches": v["launches"], "avg_us": (1e3 * v["ms"] / v["launches"]) if v["launches"] else 0.0}
                    for k, v in prof.items()}
-        # algorithmic HBM bytes of ONE launch of the two streaming kernels: per problem the update reads and writes
-        # every panel once (2 * rows_pad * cols_pad * 4 B), the gram reads every panel once; launches of the two stream groups
-        # carry half the batch each
+        # ALGORITHMIC HBM bytes of the two streaming kernels, from the library's own pair counters of this step:
+        # a gram launch reads both panels of every pair it visits (rows * 64 * 4 B per pair); an update launch reads and writes both
+        # panels of every pair that was actually rotated (converged pairs are skipped: no eigen-solve, no update, no bytes).
+        # With >= 128 columns the Jacobi sweeps run on the square Cholesky factor (cols_pad rows), otherwise on the matrix itself.
         rows_pad = ((max(m, n) + 31) // 32) * 32
         cols_pad = ((min(m, n) + 63) // 64) * 64
+        rows_j = cols_pad if min(m, n) >= 128 else rows_pad
         per_launch_problems = (B + 1) // 2 if B >= 8 else B
-        alg_bytes = {"update": 2.0 * rows_pad * cols_pad * 4 * per_launch_problems, "gram": 1.0 * rows_pad * cols_pad * 4 * per_launch_problems}
+        pair_bytes = rows_j * 64 * 4
+        alg_bytes = {"update": 2.0 * pair_bytes * pairs_cnt["rotated"] / max(1, classes["update"]["launches"]),
+                     "gram": 1.0 * pair_bytes * pairs_cnt["visited"] / max(1, classes["gram"]["launches"])}
+        all_active = {"update": 2.0 * rows_j * cols_pad * 4 * per_launch_problems, "gram": 1.0 * rows_j * cols_pad * 4 * per_launch_problems}
         traffic = None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
@@ -123,8 +129,12 @@ def main():
         if dom in alg_bytes:
             ach = alg_bytes[dom] / (classes[dom]["avg_us"] * 1e-6) / 1e9
             roofline = {"bound": "hbm", "kernel": dom + "_kernel", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
-                        "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes[dom], "avg_launch_us": classes[dom]["avg_us"],
-                        "note": "dominant kernel by total time; both streaming kernels of the block-Jacobi SVD are HBM-bound at panel width 32"}
+                        "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes[dom],
+                        "algorithmic_bytes_per_launch_if_no_pair_were_skipped": all_active[dom],
+                        "pairs": {"visited": pairs_cnt["visited"], "rotated": pairs_cnt["rotated"]},
+                        "avg_launch_us": classes[dom]["avg_us"],
+                        "note": "dominant kernel by total time, averaged over ALL its launches of the step (the late sweeps' launches move few bytes: "
+                                "most pairs are converged and skipped); measured while the other stream group's kernels share the GPU"}
         else:
             roofline = {"bound": "lds", "kernel": "evd_kernel", "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": traffic,
                         "avg_launch_us": classes[dom]["avg_us"], "note": "dominant kernel is the LDS-resident 64x64 eigen-solve (latency bound)"}
@@ -133,12 +143,12 @@ def main():
                                  "unit": "TFLOP/s", "frac": achieved / 157.3}
         # the same kernels seen from the MFMA side: executed fp32-MFMA flops of one gram/update launch (2*rows*64*64 per panel pair) and
         # of the whole Jacobi phase — at panel width 32 the HBM and the fp32-MFMA ceilings of the streaming kernels nearly coincide
-        pairs = (cols_pad // 32) // 2
-        flops_launch = 2.0 * rows_pad * 64 * 64 * pairs * per_launch_problems
+        pair_flops = {"update": 2.0 * rows_j * 64 * 64, "gram": 2.0 * rows_j * 64 * 64 * 0.75}  # gram: 3 of the 4 32x32 blocks
         if dom in alg_bytes:
+            flops_launch = pair_flops[dom] * pairs_cnt["rotated" if dom == "update" else "visited"] / max(1, classes[dom]["launches"])
             roofline["mfma_view"] = {"flops_per_launch": flops_launch, "achieved": flops_launch / (classes[dom]["avg_us"] * 1e-6) / 1e12,
                                      "peak": 157.3, "unit": "TFLOP/s", "frac": flops_launch / (classes[dom]["avg_us"] * 1e-6) / 1e12 / 157.3}
-        issued = flops_launch * (classes["gram"]["launches"] + classes["update"]["launches"])  # upper estimate: skipped pairs not subtracted
+        issued = pair_flops["update"] * pairs_cnt["rotated"] + pair_flops["gram"] * pairs_cnt["visited"]
         roofline["executed_tflops_whole_job"] = {"issued_fp32_mfma_flops_per_step": issued, "achieved": issued / (dt / args.steps) / 1e12,
                                                  "peak": 157.3, "unit": "TFLOP/s"}
         roofline["classes"] = classes

@@ -180,6 +180,9 @@ int asvd_reconstruct_err(const void* W, int w_dtype, int64_t ldw, const void* A,
  * ms_host: float[5] total milliseconds; launches_host: int[5].  */
 void asvd_svd_set_profiling(int enabled);
 int asvd_svd_get_profile(float* ms_host, int* launches_host);
+/* counts_host: long long[2] = {panel-pair visits (one Gram each), pairs actually rotated (one eigen-solve + one update each)} summed
+ * over the sweeps and problems of the last profiled call: the algorithmic byte counts of the streaming kernels follow from these. */
+int asvd_svd_get_pair_counts(long long* counts_host);
 
 #ifdef __cplusplus
 }
