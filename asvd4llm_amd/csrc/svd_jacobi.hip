@@ -17,6 +17,7 @@
 #include <vector>
 #include <cmath>
 #include <cstring>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
@@ -1333,6 +1334,7 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
     int* hist_dev = nullptr;
     if (getenv("ASVD_DEBUG_HIST")) { ASVD_HIP_CHECK(hipMalloc(&hist_dev, 10 * sizeof(int))); }
     for (; sweep < max_sweeps; ++sweep) {
+        const auto sweep_t0 = std::chrono::steady_clock::now();
         if (hist_dev) ASVD_HIP_CHECK(hipMemsetAsync(hist_dev, 0, 10 * sizeof(int), st));
         for (int g = 0; g < ngroups; ++g) {  // maxoff, nrot of this group's problems
             ASVD_HIP_CHECK(hipMemsetAsync(maxoff + gb0[g], 0, (size_t)gnb[g] * sizeof(int), gst[g]));
@@ -1377,6 +1379,12 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
             fprintf(stderr, "[asvd_svd] sweep %d pair-measure histogram by decade 1e0..1e-9:", sweep + 1);
             for (int i = 0; i < 10; ++i) fprintf(stderr, " %d", hh[i]);
             fprintf(stderr, "\n");
+        }
+        if (debug) {
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - sweep_t0).count();
+            long rot = 0;
+            for (int b = 0; b < batch; ++b) rot += host_done[b] ? 0 : flags[batch + b];
+            fprintf(stderr, "[asvd_svd] sweep %d wall %.2f ms, rotated pairs (all problems) %ld\n", sweep + 1, ms, rot);
         }
         bool all_done = true;
         bool changed = false;
