@@ -578,6 +578,180 @@ __global__ __launch_bounds__(256) void update_kernel(float* __restrict__ X, int6
 }
 
 // --------------------------------------------------------------------------------------------------
+// upgram: update of step d fused with the Gram matrices of step e (the step that follows).  Under the XOR ordering the four
+// panels {a, a^d, a^e, a^d^e} are closed under both steps: pairs (a, a^d), (a^e, a^d^e) rotate now, pairs (a, a^e), (a^d, a^d^e)
+// meet next.  One workgroup streams a row chunk of such a quad ONCE: rotate both pairs (fp32 MFMA against the 64x64 Q held in
+// registers), write the panels back, and accumulate the six 32x32 Gram blocks of the two next pairs from the updated tile in
+// LDS.  HBM traffic per step drops from 3 panel passes (gram read + update read + update write) to 2; the kernel is MFMA-bound
+// (224 MFMA per 32-row tile per wave), so it runs one workgroup per CU with the whole register file (Q 128 + accumulators 128
+// + prefetch 64 VGPRs) and prefetches the next tile into registers while the current one is in the matrix pipe.
+constexpr int TLQ = 4 * PB + 4;  // LDS row stride of the quad tile in floats (528 B: 16-B multiple, conflict-free b128 row reads)
+
+__device__ __forceinline__ int insert_zero_bit(int v, int pos) { return ((v >> pos) << (pos + 1)) | (v & ((1 << pos) - 1)); }
+__device__ __forceinline__ int remove_bit(int v, int pos) { return ((v >> (pos + 1)) << pos) | (v & ((1 << pos) - 1)); }
+
+__global__ __launch_bounds__(256, 1) void upgram_kernel(float* __restrict__ X, int64_t panel_stride, int64_t batch_stride, int nb,
+                                                        int d, int e, int R, int m_pad, int rows_per_wg,
+                                                        const float* __restrict__ Qbuf, const int* __restrict__ active,
+                                                        float* __restrict__ Gpart, const int* __restrict__ done) {
+    const int chunk = blockIdx.x, quad = blockIdx.y, b = blockIdx.z, nsplit = gridDim.x, npairs = nb >> 1;
+    if (done[b]) return;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int h = lane >> 5, c = lane & 31;
+    // ---- quad geometry (uniform per workgroup) ----
+    const int h1 = 31 - __clz(d);
+    const int e1 = ((e >> h1) & 1) ? (e ^ d) : e;
+    const int h2 = 31 - __clz(e1);
+    const int lo = min(h1, h2), hi = max(h1, h2);
+    const int a0 = insert_zero_bit(insert_zero_bit(quad, lo), hi);
+    const int P0 = a0, P1 = a0 ^ d, P2 = a0 ^ e, P3 = a0 ^ d ^ e;  // tile slots 0..3
+    // current pairs (step d): A = slots (0,1), B = slots (2,3); the lower-index member has bit h1 clear
+    const bool swapB = (P2 >> h1) & 1;
+    const int kA = remove_bit(P0, h1), kB = remove_bit(swapB ? P3 : P2, h1);
+    const bool actA = active[b * npairs + kA] != 0, actB = active[b * npairs + kB] != 0;
+    // next pairs (step e): C = slots (0,2), D = slots (1,3)
+    const int he = 31 - __clz(e);
+    const bool swapD = (P1 >> he) & 1;
+    const int kC = remove_bit(P0, he), kD = remove_bit(swapD ? P3 : P1, he);
+
+    float* __restrict__ Xb = X + (int64_t)b * batch_stride;
+    float* __restrict__ Xp[4] = {Xb + (int64_t)P0 * panel_stride, Xb + (int64_t)P1 * panel_stride, Xb + (int64_t)P2 * panel_stride,
+                                 Xb + (int64_t)P3 * panel_stride};
+    // Q of the two current pairs: rows (h*32 + t), columns c (first output panel) and 32 + c (second)
+    float qa0[32], qa1[32], qb0[32], qb1[32];
+    if (actA) {
+        const float* __restrict__ Qp = Qbuf + ((int64_t)b * npairs + kA) * (PW * PW);
+#pragma unroll
+        for (int t = 0; t < 32; ++t) { qa0[t] = Qp[(h * 32 + t) * PW + c]; qa1[t] = Qp[(h * 32 + t) * PW + 32 + c]; }
+    }
+    if (actB) {
+        const float* __restrict__ Qp = Qbuf + ((int64_t)b * npairs + kB) * (PW * PW);
+#pragma unroll
+        for (int t = 0; t < 32; ++t) { qb0[t] = Qp[(h * 32 + t) * PW + c]; qb1[t] = Qp[(h * 32 + t) * PW + 32 + c]; }
+    }
+    const int sAi = 0, sAj = 1, sBi = swapB ? 3 : 2, sBj = swapB ? 2 : 3;  // tile slots of (I, J) of the current pairs
+
+    __shared__ __attribute__((aligned(16))) float tile[4][32 * TLQ];
+    float* my = tile[w];
+    f32x16 gC0 = {0}, gC1 = {0}, gC2 = {0}, gD0 = {0}, gD1 = {0}, gD2 = {0};  // (II, IJ, JJ) of the next pairs
+
+    const int r_begin = chunk * rows_per_wg;
+    const int r_end = min(r_begin + rows_per_wg, R);
+    f32x4 pre[4][4];
+    auto prefetch = [&](int r0) {
+#pragma unroll
+        for (int p4 = 0; p4 < 4; ++p4)
+#pragma unroll
+            for (int it = 0; it < 4; ++it) pre[p4][it] = *(const f32x4*)(Xp[p4] + (int64_t)r0 * PB + it * 256 + lane * 4);
+    };
+    int r0 = r_begin + w * 32;  // R and rows_per_wg are multiples of 32; a wave strides by 128 rows
+    if (r0 < r_end) prefetch(r0);
+    for (; r0 < r_end; r0 += 128) {
+        // registers -> this wave's LDS tile (wave-private: LDS operations of one wave complete in order, no barrier needed)
+#pragma unroll
+        for (int p4 = 0; p4 < 4; ++p4)
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int idx = it * 256 + lane * 4;
+                *(f32x4*)(my + (idx >> 5) * TLQ + p4 * 32 + (idx & 31)) = pre[p4][it];
+            }
+        if (r0 + 128 < r_end) prefetch(r0 + 128);
+        // ---- rotate the two current pairs ----
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            const bool act = pr == 0 ? actA : actB;
+            if (!act) continue;
+            const int si = pr == 0 ? sAi : sBi, sj = pr == 0 ? sAj : sBj;
+            float av[32];
+            const float* src = my + c * TLQ + (h ? sj : si) * 32;
+#pragma unroll
+            for (int t4 = 0; t4 < 8; ++t4) {
+                const f32x4 v = *(const f32x4*)(src + t4 * 4);
+                av[4 * t4 + 0] = v[0]; av[4 * t4 + 1] = v[1]; av[4 * t4 + 2] = v[2]; av[4 * t4 + 3] = v[3];
+            }
+            f32x16 acc0 = {0}, acc1 = {0};
+            if (pr == 0) {
+#pragma unroll
+                for (int t = 0; t < 32; ++t) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], qa0[t], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], qa1[t], acc1, 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < 32; ++t) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], qb0[t], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], qb1[t], acc1, 0, 0, 0);
+                }
+            }
+            float* __restrict__ XI = Xp[si];
+            float* __restrict__ XJ = Xp[sj];
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int i = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                XI[(int64_t)(r0 + i) * PB + c] = acc0[reg];
+                XJ[(int64_t)(r0 + i) * PB + c] = acc1[reg];
+                my[i * TLQ + si * 32 + c] = acc0[reg];
+                my[i * TLQ + sj * 32 + c] = acc1[reg];
+            }
+        }
+        // ---- Gram blocks of the next pairs from the updated tile (rows of the matrix proper only, not accumulated V rows) ----
+        if (r0 < m_pad) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const float* rowp = my + (2 * u + h) * TLQ + c;
+                const float x0 = rowp[0], x1 = rowp[32], x2 = rowp[64], x3 = rowp[96];
+                const float di = swapD ? x3 : x1, dj = swapD ? x1 : x3;
+                gC0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, x0, gC0, 0, 0, 0);
+                gC1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, x2, gC1, 0, 0, 0);
+                gC2 = __builtin_amdgcn_mfma_f32_32x32x2f32(x2, x2, gC2, 0, 0, 0);
+                gD0 = __builtin_amdgcn_mfma_f32_32x32x2f32(di, di, gD0, 0, 0, 0);
+                gD1 = __builtin_amdgcn_mfma_f32_32x32x2f32(di, dj, gD1, 0, 0, 0);
+                gD2 = __builtin_amdgcn_mfma_f32_32x32x2f32(dj, dj, gD2, 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- cross-wave reduction in a fixed order ((w0 + w2) + (w1 + w3)) through the tile memory, then wave 0 stores ----
+    __syncthreads();
+    float* red = &tile[0][0];  // 4 * 32 * 132 floats = 16896 >= 2 * 96 * 64 = 12288
+    auto put = [&](float* dst) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            dst[(0 + reg) * 64 + lane] = gC0[reg]; dst[(16 + reg) * 64 + lane] = gC1[reg]; dst[(32 + reg) * 64 + lane] = gC2[reg];
+            dst[(48 + reg) * 64 + lane] = gD0[reg]; dst[(64 + reg) * 64 + lane] = gD1[reg]; dst[(80 + reg) * 64 + lane] = gD2[reg];
+        }
+    };
+    auto add = [&](const float* src) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            gC0[reg] += src[(0 + reg) * 64 + lane]; gC1[reg] += src[(16 + reg) * 64 + lane]; gC2[reg] += src[(32 + reg) * 64 + lane];
+            gD0[reg] += src[(48 + reg) * 64 + lane]; gD1[reg] += src[(64 + reg) * 64 + lane]; gD2[reg] += src[(80 + reg) * 64 + lane];
+        }
+    };
+    if (w >= 2) put(red + (w - 2) * 96 * 64);
+    __syncthreads();
+    if (w < 2) add(red + w * 96 * 64);
+    __syncthreads();
+    if (w == 1) put(red);
+    __syncthreads();
+    if (w == 0) {
+        add(red);
+        float* outC = Gpart + (((int64_t)b * npairs + kC) * nsplit + chunk) * 3072;
+        float* outD = Gpart + (((int64_t)b * npairs + kD) * nsplit + chunk) * 3072;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int i = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            outC[0 * 1024 + i * 32 + c] = gC0[reg];
+            outC[1 * 1024 + i * 32 + c] = gC1[reg];
+            outC[2 * 1024 + i * 32 + c] = gC2[reg];
+            outD[0 * 1024 + i * 32 + c] = gD0[reg];
+            outD[1 * 1024 + i * 32 + c] = gD1[reg];
+            outD[2 * 1024 + i * 32 + c] = gD2[reg];
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
 // backsolve: right vectors without accumulating V during the sweeps.  After convergence X_J holds a_j = sigma_j u_j and
 //   Xorig^T a_j = V Sigma U^T (sigma_j u_j) = sigma_j^2 v_j ,
 // so the V rows of panel J are the cross-Gram blocks between the ORIGINAL packed panels and the final ones: the same MFMA
@@ -1056,6 +1230,8 @@ __global__ void colscale_kernel(float* __restrict__ Y, int64_t ldy, int rows, in
 }
 
 // --------------------------------------------------------------------------------------------------
+static int stream_groups_for(int batch) { return batch >= 12 ? 3 : (batch >= 8 ? 2 : 1); }
+
 static bool pair_order_xor() {
     const char* e = getenv("ASVD_ORDER");
     return !(e && !strncmp(e, "rr", 2));
@@ -1068,6 +1244,7 @@ struct Plan {
     int rows, cols;       // oriented dims, rows >= cols
     int m_pad, n_pad, nb, npairs, R, R_upd, want_v, vmode;  // vmode: 0 none, 1 accumulate V in the sweeps, 2 backsolve at the end
     int nsplit, rows_per_split, rows_per_wg, nchunks;
+    int fused, nchunks_f, rows_per_wg_f;  // upgram path (XOR ordering, power-of-two panel count)
     int64_t panel_stride, batch_stride;
     // workspace offsets in bytes
     size_t off_x, off_xorig, off_gpart, off_q, off_active, off_sig, off_ina, off_inv, off_perm, off_flags, total;
@@ -1101,7 +1278,7 @@ int make_plan(int batch, int64_t m, int64_t n, int want_u, int want_vv, Plan& p)
     // gram: choose the row split that minimises (rounds of resident workgroups) x (chunks per wave + fixed overhead).
     // 3 workgroups of 4 waves fit per CU (148 VGPR+AGPR) -> 768 slots; a grid of 1.3 x slots costs 2 full rounds.
     {
-        const int launch_batch = batch >= 8 ? (batch + 1) / 2 : batch;  // problems per launch (two stream groups from batch 8)
+        const int launch_batch = (int)ceil_div64(batch, stream_groups_for(batch));  // problems per launch (stream groups)
         const int64_t nchunk_total = p.m_pad / 32;
         int64_t best_ns = 1;
         double best_cost = 1e300;
@@ -1122,13 +1299,28 @@ int make_plan(int batch, int64_t m, int64_t n, int want_u, int want_vv, Plan& p)
     int64_t nc = wantc < 1 ? 1 : (wantc > iters_total ? iters_total : wantc);
     p.rows_per_wg = (int)(ceil_div64(iters_total, nc) * 128);
     p.nchunks = (int)ceil_div64(p.R_upd, p.rows_per_wg);
+    {
+        // upgram: one workgroup per CU; aim for ~4 workgroups per CU-slot over the launch, >= 128 rows per workgroup
+        const char* ef = getenv("ASVD_FUSED");
+        // opt-in (ASVD_FUSED=1): measured +4 % on the 16 x 4096^2 bench but -3 % on the mixed-shape full-model run — at one
+        // workgroup per CU the kernel is latency-sensitive; kept as the building block for the split-precision / two-level plan
+        p.fused = (pair_order_xor() && p.nb == 2 * p.npairs && p.nb >= 4 && ef && atoi(ef) == 1) ? 1 : 0;
+        const int launch_batch = (int)ceil_div64(batch, stream_groups_for(batch));
+        const int64_t quads = (int64_t)(p.nb / 4) * launch_batch;
+        int64_t want = ceil_div64(1024, quads > 0 ? quads : 1);
+        const int64_t iters = ceil_div64(p.R_upd, 128);
+        if (want < 1) want = 1;
+        if (want > iters) want = iters;
+        p.rows_per_wg_f = (int)(ceil_div64(iters, want) * 128);
+        p.nchunks_f = (int)ceil_div64(p.R_upd, p.rows_per_wg_f);
+    }
     p.panel_stride = (int64_t)p.R * PB;
     p.batch_stride = p.panel_stride * p.nb;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
     p.off_x = take((size_t)p.batch_stride * batch * sizeof(float));
     p.off_xorig = take(p.vmode == 2 ? (size_t)p.m_pad * PB * p.nb * batch * sizeof(float) : 0);
-    p.off_gpart = take((size_t)batch * p.npairs * p.nsplit * 3072 * sizeof(float));
+    p.off_gpart = take((size_t)batch * p.npairs * std::max(p.nsplit, p.fused ? p.nchunks_f : 0) * 3072 * sizeof(float));
     p.off_q = take((size_t)batch * p.npairs * PW * PW * sizeof(float));
     p.off_active = take((size_t)batch * p.npairs * sizeof(int));
     p.off_sig = take((size_t)batch * p.n_pad * sizeof(float));
@@ -1306,7 +1498,7 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
     // Independent problems of a batch are split into two groups driven on two internal streams: while one group sits in its
     // LDS/VALU-bound evd phase the other streams panels through its HBM-bound gram/update phase (different resources).
     constexpr int MAXG = 4;
-    int ngroups = batch >= 8 ? 2 : 1;
+    int ngroups = stream_groups_for(batch);  // measured at 4096^2: 16 problems as 6/5/5 +3 % over 8/8; 4 groups lose
     if (getenv("ASVD_GROUPS")) ngroups = atoi(getenv("ASVD_GROUPS"));
     if (ngroups < 1) ngroups = 1;
     if (ngroups > MAXG) ngroups = MAXG;
@@ -1340,28 +1532,40 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
             ASVD_HIP_CHECK(hipMemsetAsync(maxoff + gb0[g], 0, (size_t)gnb[g] * sizeof(int), gst[g]));
             ASVD_HIP_CHECK(hipMemsetAsync(nrot + gb0[g], 0, (size_t)gnb[g] * sizeof(int), gst[g]));
         }
+        const int gstride = std::max(p.nsplit, p.fused ? p.nchunks_f : 0);  // partial-Gram slots per pair in the buffer
         for (int step = 0; step < nsteps; ++step) {
             for (int g = 0; g < ngroups; ++g) {
                 const int b0 = gb0[g], nbg = gnb[g];
                 hipStream_t s2 = gst[g];
                 float* Xg = X + (int64_t)b0 * p.batch_stride;
-                float* Gg = Gpart + (int64_t)b0 * p.npairs * p.nsplit * 3072;
+                float* Gg = Gpart + (int64_t)b0 * p.npairs * gstride * 3072;
                 float* Qg = Qbuf + (int64_t)b0 * p.npairs * PW * PW;
                 int* ag = active + (int64_t)b0 * p.npairs;
-                {
+                // fused path: the Gram blocks of this step were produced by the previous step's upgram launch (or by the last one
+                // of the previous sweep); only the very first step of the call needs the stand-alone gram kernel
+                const bool gram_here = !p.fused || (sweep == 0 && step == 0);
+                const int ns_here = gram_here ? p.nsplit : p.nchunks_f;
+                if (gram_here) {
                     ProfScope ps(1, s2);
                     gram_kernel<<<dim3(p.nsplit, p.npairs, nbg), 256, 0, s2>>>(Xg, p.panel_stride, p.batch_stride, p.nb, step, p.m_pad,
                                                                                p.rows_per_split, Gg, done + b0);
                 }
                 {
                     ProfScope ps(2, s2);
-                    evd_kernel<<<dim3(p.npairs, nbg), 256, 0, s2>>>(Gg, p.nsplit, Qg, ag, maxoff + b0, nrot + b0, done + b0, tol,
+                    evd_kernel<<<dim3(p.npairs, nbg), 256, 0, s2>>>(Gg, ns_here, Qg, ag, maxoff + b0, nrot + b0, done + b0, tol,
                                                                      inner_sweeps, p.nb, step, kb, hist_dev);
                 }
                 {
                     ProfScope ps(3, s2);
-                    update_kernel<<<dim3(p.nchunks, p.npairs, nbg), 256, 0, s2>>>(Xg, p.panel_stride, p.batch_stride, p.nb, step,
-                                                                                  p.R_upd, p.rows_per_wg, Qg, ag, done + b0);
+                    if (p.fused) {
+                        const int d = step + 1, e = (step + 1 < nsteps) ? step + 2 : 1;
+                        upgram_kernel<<<dim3(p.nchunks_f, p.nb / 4, nbg), 256, 0, s2>>>(Xg, p.panel_stride, p.batch_stride, p.nb, d, e,
+                                                                                        p.R_upd, p.m_pad, p.rows_per_wg_f, Qg, ag, Gg,
+                                                                                        done + b0);
+                    } else {
+                        update_kernel<<<dim3(p.nchunks, p.npairs, nbg), 256, 0, s2>>>(Xg, p.panel_stride, p.batch_stride, p.nb, step,
+                                                                                      p.R_upd, p.rows_per_wg, Qg, ag, done + b0);
+                    }
                 }
             }
         }

@@ -113,7 +113,8 @@ def main():
         rows_pad = ((max(m, n) + 31) // 32) * 32
         cols_pad = ((min(m, n) + 63) // 64) * 64
         rows_j = cols_pad if min(m, n) >= 128 else rows_pad
-        per_launch_problems = (B + 1) // 2 if B >= 8 else B
+        ngroups = 3 if B >= 12 else (2 if B >= 8 else 1)  # stream groups of asvd_svd_batched
+        per_launch_problems = B / ngroups
         pair_bytes = rows_j * 64 * 4
         alg_bytes = {"update": 2.0 * pair_bytes * pairs_cnt["rotated"] / max(1, classes["update"]["launches"]),
                      "gram": 1.0 * pair_bytes * pairs_cnt["visited"] / max(1, classes["gram"]["launches"])}

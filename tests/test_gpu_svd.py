@@ -175,3 +175,31 @@ def test_reduction_matches_direct_path(gpu):
     R1 = (U[:, :r].double() * S[:r].double()) @ V[:, :r].double().T
     R2 = (U2[:, :r].double() * S2[:r].double()) @ V2[:, :r].double().T
     assert ((R1 - R2).norm() / R2.norm()).item() <= 1e-4
+
+
+def test_fused_update_gram_path_matches_default(gpu):
+    """ASVD_FUSED=1: update of step d fused with the Gram blocks of step d+1 (upgram_kernel, power-of-two panel counts).
+    Same arithmetic in a different summation order: singular values agree to fp32 noise, parity bars hold."""
+    import os
+    from asvd4llm_amd import ops
+    W, s = llm_like(1024, 1024, seed=77)
+    Wd, sd = W.to(gpu), s.to(gpu)
+    U0, S0, V0, i0 = ops.svd(Wd, sd)
+    os.environ["ASVD_FUSED"] = "1"
+    try:
+        U1, S1, V1, i1 = ops.svd(Wd, sd)
+        mats = [llm_like(512, 512, seed=90 + b)[0].to(gpu) for b in range(3)]
+        _, Sb, _, ib = ops.svd_batched(mats)
+    finally:
+        del os.environ["ASVD_FUSED"]
+    assert i1.status == 0 and abs(i1.sweeps - i0.sweeps) <= 1
+    assert ((S1 - S0).abs().max() / S0[0]).item() <= 2e-6
+    So = O.exact_svd(O.scaled_weight(W, s))[1]
+    assert O.sigma_rel_err(S1.cpu(), So, 460) <= SIG_TOL
+    R1 = (U1[:, :460] * S1[:460]) @ V1[:, :460].T
+    R0 = (U0[:, :460] * S0[:460]) @ V0[:, :460].T
+    assert ((R1 - R0).norm() / R0.norm()).item() <= 1e-4
+    for b, m in enumerate(mats):
+        assert ib[b].status == 0
+        ref = torch.linalg.svdvals(m.cpu().double())
+        assert ((Sb[b].cpu().double() - ref).abs().max() / ref[0]).item() <= 1e-5
