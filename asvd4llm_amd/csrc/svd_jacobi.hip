@@ -51,6 +51,20 @@ __device__ __forceinline__ void rr_pair(int nb, int step, int k, int& I, int& J)
     J = a < b ? b : a;
 }
 
+// Pair handled by a workgroup: from the schedule (plist == nullptr) or, in sparse sweeps, from an explicit per-problem list of
+// marked pairs (code = I << 16 | J, -1 = empty slot).  Returns false when there is nothing to do for this slot.
+__device__ __forceinline__ bool get_pair(const int* __restrict__ plist, int list_stride, int b, int nb, int step, int pair, int& I, int& J) {
+    if (plist) {
+        const int code = plist[b * list_stride + pair];
+        if (code < 0) return false;
+        I = code >> 16;
+        J = code & 0xffff;
+        return true;
+    }
+    rr_pair(nb, step, pair, I, J);
+    return J < nb;  // padding pair of the XOR ordering
+}
+
 // --------------------------------------------------------------------------------------------------
 // pack: oriented, scaled, fp32 copy of the input into panel layout.  X must be zero-filled before.
 //   transposed == 0:  X[blk][r][c] = float(src[r][blk*32+c]) * float(s[blk*32+c])      r < rows, col < cols
@@ -119,13 +133,13 @@ constexpr int GCH = 32;  // rows per staged chunk
 
 __global__ __launch_bounds__(256) void gram_kernel(const float* __restrict__ X, int64_t panel_stride, int64_t batch_stride,
                                                    int nb, int step, int m_pad, int rows_per_split,
-                                                   float* __restrict__ Gpart, const int* __restrict__ done) {
+                                                   float* __restrict__ Gpart, const int* __restrict__ done,
+                                                   const int* __restrict__ plist, int list_stride) {
     const int split = blockIdx.x, pair = blockIdx.y, b = blockIdx.z;
     const int nsplit = gridDim.x, npairs = gridDim.y;
     if (done[b]) return;
     int I, J;
-    rr_pair(nb, step, pair, I, J);
-    if (J >= nb) return;  // padding pair of the XOR ordering
+    if (!get_pair(plist, list_stride, b, nb, step, pair, I, J)) return;
     const float* __restrict__ XI = X + (int64_t)b * batch_stride + (int64_t)I * panel_stride;
     const float* __restrict__ XJ = X + (int64_t)b * batch_stride + (int64_t)J * panel_stride;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -253,7 +267,8 @@ __device__ __forceinline__ int pcol(int c) { return ((c & 1) << 5) | (c >> 1); }
 __global__ __launch_bounds__(256, 4) void evd_kernel(const float* __restrict__ Gpart, int nsplit, float* __restrict__ Qbuf,
                                                    int* __restrict__ active, unsigned* __restrict__ maxoff_bits,
                                                    int* __restrict__ nrot, const int* __restrict__ done, float tol,
-                                                   int inner_sweeps, int nb, int step, int kb, int* __restrict__ hist) {
+                                                   int inner_sweeps, int nb, int step, int kb, int* __restrict__ hist,
+                                                   const int* __restrict__ plist, int list_stride) {
     __shared__ float G[PW * PW];
     __shared__ float Q[PW * PW];
     __shared__ float sdiag[2][PW];
@@ -265,13 +280,10 @@ __global__ __launch_bounds__(256, 4) void evd_kernel(const float* __restrict__ G
     const int pair = blockIdx.x, b = blockIdx.y, npairs = gridDim.x;
     if (done[b]) return;
     const int tid = threadIdx.x;
-    {
-        int I0, J0;
-        rr_pair(nb, step, pair, I0, J0);
-        if (J0 >= nb) {  // padding pair of the XOR ordering: nothing to rotate
-            if (tid == 0) active[b * npairs + pair] = 0;
-            return;
-        }
+    int I, J;
+    if (!get_pair(plist, list_stride, b, nb, step, pair, I, J)) {  // padding pair / empty slot: nothing to rotate
+        if (tid == 0) active[b * npairs + pair] = 0;
+        return;
     }
     const float* gp = Gpart + ((int64_t)b * npairs + pair) * nsplit * 3072;
 
@@ -304,8 +316,6 @@ __global__ __launch_bounds__(256, 4) void evd_kernel(const float* __restrict__ G
     // looks at: the caller asked for k leading triplets, pair sorting keeps the largest columns in the lowest panels, and the
     // leading columns only need to be orthogonal among themselves and to the tail's SPAN - tail-internal angles (the JJ block
     // of a leading/tail pair, or a tail/tail pair) keep being rotated but no longer hold up termination.
-    int I, J;
-    rr_pair(nb, step, pair, I, J);
     const bool topI = I < kb, topJ = J < kb;
     float loc = 0.0f, loct = 0.0f;
     for (int e = tid; e < PW * PW; e += 256) {
@@ -520,11 +530,11 @@ constexpr int TLD = PW + 4;  // LDS row stride in floats (272 B, multiple of 16 
 __global__ __launch_bounds__(256) void update_kernel(float* __restrict__ X, int64_t panel_stride, int64_t batch_stride,
                                                      int nb, int step, int R, int rows_per_wg,
                                                      const float* __restrict__ Qbuf, const int* __restrict__ active,
-                                                     const int* __restrict__ done) {
+                                                     const int* __restrict__ done, const int* __restrict__ plist, int list_stride) {
     const int chunk = blockIdx.x, pair = blockIdx.y, b = blockIdx.z, npairs = gridDim.y;
     if (done[b] || !active[b * npairs + pair]) return;
     int I, J;
-    rr_pair(nb, step, pair, I, J);
+    if (!get_pair(plist, list_stride, b, nb, step, pair, I, J)) return;
     float* __restrict__ XI = X + (int64_t)b * batch_stride + (int64_t)I * panel_stride;
     float* __restrict__ XJ = X + (int64_t)b * batch_stride + (int64_t)J * panel_stride;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -581,6 +591,123 @@ __global__ __launch_bounds__(256) void update_kernel(float* __restrict__ X, int6
             }
         }
         __syncthreads();
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
+// Sparse sweeps.  Once fewer than half of the pairs still rotate, most of a sweep is Gram passes that only confirm convergence
+// (the last sweep of a 4096^2 problem rotates 0.3 % of its pairs and still costs a third of a full sweep, all of it panel reads).
+// A sparse sweep starts with ONE snapshot of all couplings — X^T X as a blocked GEMM: each panel is read nb/4 times through L2
+// instead of nb-1 times from HBM and the diagonal blocks are not recomputed per pair — which marks the pairs whose scaled
+// coupling is >= tol.  The host turns the marks into per-step lists (XOR steps are perfect matchings, so the pairs of one step
+// are disjoint) and launches gram / evd / update for marked pairs only, skipping empty steps.  Couplings of unmarked pairs move
+// only by (rotation angle) x (other couplings) during the sweep, second order in what is left; the next snapshot sees them.
+// The termination measure is the snapshot's (same definition as in evd_kernel), so the stopping rule is unchanged.
+__global__ __launch_bounds__(256) void panel_sumsq_kernel(const float* __restrict__ X, int64_t panel_stride, int64_t batch_stride,
+                                                          int m_pad, int n_pad, float* __restrict__ dn, const int* __restrict__ done) {
+    const int I = blockIdx.x, b = blockIdx.y, c = threadIdx.x & 31, g = threadIdx.x >> 5;
+    if (done[b]) return;
+    const float* __restrict__ P = X + (int64_t)b * batch_stride + (int64_t)I * panel_stride;
+    float s = 0.0f;
+    for (int r = g; r < m_pad; r += 8) { const float x = P[(int64_t)r * PB + c]; s = fmaf(x, x, s); }
+    __shared__ float red[8][32];
+    red[g][c] = s;
+    __syncthreads();
+    if (g == 0) {
+        float t = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t += red[i][c];
+        dn[(int64_t)b * n_pad + I * PB + c] = t;
+    }
+}
+
+__device__ __forceinline__ float nanmax(float a, float b) { return (b != b) ? b : ((a != a) ? a : fmaxf(a, b)); }
+
+// grid (ceil(nb/4), ceil(nb/4), batch); upper-triangular tiles only.  Wave w owns panel J = 4*jg + w against panels I = 4*ig + a.
+// 32-row chunks of the eight panels are staged in LDS (coalesced 16-B loads, next chunk prefetched into registers while the
+// current one is in the matrix pipe); every wave reads its operands from LDS as conflict-free 256-B rows.
+__global__ __launch_bounds__(256) void fullcheck_kernel(const float* __restrict__ X, int64_t panel_stride, int64_t batch_stride, int nb,
+                                                        int m_pad, int n_pad, const float* __restrict__ dn, float tol, int kb,
+                                                        unsigned char* __restrict__ pflag, unsigned* __restrict__ maxoff_bits,
+                                                        const int* __restrict__ done) {
+    const int ig = blockIdx.x, jg = blockIdx.y, b = blockIdx.z;
+    if (ig > jg || done[b]) return;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int J = jg * 4 + w;
+    bool ok[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) ok[a] = (ig * 4 + a <= J) && (J < nb);  // blocks below the diagonal are mirrors
+    // slot q of the stage: q < 4 -> panel 4*ig + q (A side), q >= 4 -> panel 4*jg + q - 4 (B side); clamp padding panels
+    __shared__ __attribute__((aligned(16))) float stage[8][32 * PB];
+    const float* __restrict__ Xb = X + (int64_t)b * batch_stride;
+    const float* src[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int pnl = (q < 4) ? ig * 4 + q : jg * 4 + q - 4;
+        src[q] = Xb + (int64_t)(pnl < nb ? pnl : nb - 1) * panel_stride + tid * 4;  // 256 threads x 16 B = one 32x32 chunk
+    }
+    f32x4 pre[8];
+    auto fetch = [&](int r0) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) pre[q] = *(const f32x4*)(src[q] + (int64_t)r0 * PB);
+    };
+    f32x16 acc[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) acc[a] = (f32x16){0};
+    fetch(0);
+    for (int r0 = 0; r0 < m_pad; r0 += 32) {
+        __syncthreads();  // previous chunk fully consumed
+#pragma unroll
+        for (int q = 0; q < 8; ++q) *(f32x4*)(&stage[q][tid * 4]) = pre[q];
+        __syncthreads();
+        if (r0 + 32 < m_pad) fetch(r0 + 32);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const float bf = stage[4 + w][u * 64 + lane];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(stage[a][u * 64 + lane], bf, acc[a], 0, 0, 0);
+        }
+    }
+    if (J >= nb) return;
+    const int h = lane >> 5, c = lane & 31;
+    const float* __restrict__ dnb = dn + (int64_t)b * n_pad;
+    const float dj = dnb[J * PB + c];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        if (!ok[a]) continue;
+        const int I = ig * 4 + a;
+        float v = 0.0f, vt = 0.0f;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int i = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            if (I == J && i == c) continue;
+            const float di = dnb[I * PB + i];
+            const float g = acc[a][reg];
+            const float dd = di * dj;
+            float x = (dd > 0.0f) ? fabsf(g) * rsqrtf(dd) : 0.0f;
+            if (g != g || dd != dd) x = __builtin_nanf("");
+            const float mx = fmaxf(di, dj);
+            float xt = (mx > 0.0f) ? fabsf(g) / mx : 0.0f;
+            if (x != x) xt = x;
+            v = nanmax(v, x);
+            vt = nanmax(vt, xt);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            v = nanmax(v, __shfl_xor(v, o, 64));
+            vt = nanmax(vt, __shfl_xor(vt, o, 64));
+        }
+        if (lane == 0) {
+            if (v != v) {
+                atomicMax(&maxoff_bits[b], 0x7fc00000u);
+            } else {
+                if (v >= tol) {  // a coupling inside a panel is repaired by any visit of that panel: mark its neighbour pair
+                    const int A = (I == J) ? min(I, I ^ 1) : I, Bp = (I == J) ? max(I, I ^ 1) : J;
+                    pflag[((int64_t)b * nb + A) * nb + Bp] = 1;
+                }
+                if (I < kb || J < kb) atomicMax(&maxoff_bits[b], __float_as_uint(vt));
+            }
+        }
     }
 }
 
@@ -1254,7 +1381,7 @@ struct Plan {
     int fused, nchunks_f, rows_per_wg_f;  // upgram path (XOR ordering, power-of-two panel count)
     int64_t panel_stride, batch_stride;
     // workspace offsets in bytes
-    size_t off_x, off_xorig, off_gpart, off_q, off_active, off_sig, off_ina, off_inv, off_perm, off_flags, total;
+    size_t off_x, off_xorig, off_gpart, off_q, off_active, off_sig, off_ina, off_inv, off_perm, off_flags, off_pflag, off_plist, total;
 };
 
 int make_plan(int batch, int64_t m, int64_t n, int want_u, int want_vv, Plan& p) {
@@ -1335,6 +1462,8 @@ int make_plan(int batch, int64_t m, int64_t n, int want_u, int want_vv, Plan& p)
     p.off_inv = take((size_t)batch * p.n_pad * sizeof(float));
     p.off_perm = take((size_t)batch * p.n_pad * sizeof(int));
     p.off_flags = take((size_t)batch * 4 * sizeof(int));  // [maxoff bits | nrot | done | pad] x batch (SoA)
+    p.off_pflag = take((size_t)batch * p.nb * p.nb);      // sparse-sweep pair marks
+    p.off_plist = take((size_t)batch * p.nb * p.nb * sizeof(int));  // per-step lists of marked pairs (bound: steps x nb/2 slots per problem)
     p.total = off;
     return ASVD_OK;
 }
@@ -1530,6 +1659,16 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
             ASVD_HIP_CHECK(hipEventCreateWithFlags(&ev_join[g], hipEventDisableTiming));
         }
     }
+    // ---- sparse-sweep state (see fullcheck_kernel) ----
+    unsigned char* pflag = (unsigned char*)(wb + p.off_pflag);
+    int* plist_dev = (int*)(wb + p.off_plist);
+    float* dnorm = (float*)(wb + p.off_ina);  // squared column norms of the snapshot (finalize overwrites this buffer later)
+    const bool sparse_allowed = pair_order_xor() && !p.fused && p.nb >= 8 && !(getenv("ASVD_SPARSE") && atoi(getenv("ASVD_SPARSE")) == 0);
+    const double sparse_frac = getenv("ASVD_SPARSE_FRAC") ? atof(getenv("ASVD_SPARSE_FRAC")) : 0.5;
+    bool sparse = false;
+    std::vector<unsigned char> hflag;
+    std::vector<int> hlist;
+    std::vector<int> sl_off((size_t)MAXG * (nsteps > 0 ? nsteps : 1), 0), sl_cnt((size_t)MAXG * (nsteps > 0 ? nsteps : 1), 0);
     int* hist_dev = nullptr;
     if (getenv("ASVD_DEBUG_HIST")) { ASVD_HIP_CHECK(hipMalloc(&hist_dev, 10 * sizeof(int))); }
     for (; sweep < max_sweeps; ++sweep) {
@@ -1538,6 +1677,61 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
         for (int g = 0; g < ngroups; ++g) {  // maxoff, nrot of this group's problems
             ASVD_HIP_CHECK(hipMemsetAsync(maxoff + gb0[g], 0, (size_t)gnb[g] * sizeof(int), gst[g]));
             ASVD_HIP_CHECK(hipMemsetAsync(nrot + gb0[g], 0, (size_t)gnb[g] * sizeof(int), gst[g]));
+        }
+        long long marked_total = 0;
+        if (sparse) {
+            // 1. snapshot of all couplings, per stream group
+            for (int g = 0; g < ngroups; ++g) {
+                ProfScope ps(1, gst[g]);
+                const int b0 = gb0[g], nbg = gnb[g];
+                const float* Xg = X + (int64_t)b0 * p.batch_stride;
+                ASVD_HIP_CHECK(hipMemsetAsync(pflag + (size_t)b0 * p.nb * p.nb, 0, (size_t)nbg * p.nb * p.nb, gst[g]));
+                panel_sumsq_kernel<<<dim3(p.nb, nbg), 256, 0, gst[g]>>>(Xg, p.panel_stride, p.batch_stride, p.m_pad, p.n_pad,
+                                                                        dnorm + (size_t)b0 * p.n_pad, done + b0);
+                const unsigned nt = (unsigned)ceil_div64(p.nb, 4);
+                fullcheck_kernel<<<dim3(nt, nt, nbg), 256, 0, gst[g]>>>(Xg, p.panel_stride, p.batch_stride, p.nb, p.m_pad, p.n_pad,
+                                                                        dnorm + (size_t)b0 * p.n_pad, tol, kb,
+                                                                        pflag + (size_t)b0 * p.nb * p.nb, maxoff + b0, done + b0);
+            }
+            if (ngroups >= 2)
+                for (int g = 0; g < ngroups; ++g) {
+                    ASVD_HIP_CHECK(hipEventRecord(ev_join[g], gst[g]));
+                    ASVD_HIP_CHECK(hipStreamWaitEvent(st, ev_join[g], 0));
+                }
+            hflag.resize((size_t)batch * p.nb * p.nb);
+            ASVD_HIP_CHECK(hipMemcpyAsync(hflag.data(), pflag, hflag.size(), hipMemcpyDeviceToHost, st));
+            ASVD_HIP_CHECK(hipStreamSynchronize(st));
+            if (debug) fprintf(stderr, "[asvd_svd]   snapshot + readback %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - sweep_t0).count());
+            // 2. marks -> per-step lists (step d-1 holds the pairs with I ^ J == d: disjoint by construction)
+            hlist.clear();
+            std::vector<std::vector<int>> tmp;  // [b_local * nsteps + step]
+            for (int g = 0; g < ngroups; ++g) {
+                const int b0 = gb0[g], nbg = gnb[g];
+                tmp.assign((size_t)nbg * nsteps, std::vector<int>());
+                for (int bl = 0; bl < nbg; ++bl) {
+                    if (host_done[b0 + bl]) continue;
+                    const unsigned char* f = hflag.data() + (size_t)(b0 + bl) * p.nb * p.nb;
+                    for (int I = 0; I < p.nb; ++I)
+                        for (int J = I + 1; J < p.nb; ++J)
+                            if (f[(size_t)I * p.nb + J]) { tmp[(size_t)bl * nsteps + ((I ^ J) - 1)].push_back((I << 16) | J); ++marked_total; }
+                }
+                for (int step = 0; step < nsteps; ++step) {
+                    size_t mx = 0;
+                    for (int bl = 0; bl < nbg; ++bl) mx = std::max(mx, tmp[(size_t)bl * nsteps + step].size());
+                    sl_cnt[(size_t)g * nsteps + step] = (int)mx;
+                    sl_off[(size_t)g * nsteps + step] = (int)hlist.size();
+                    for (int bl = 0; bl < nbg; ++bl) {
+                        const auto& v = tmp[(size_t)bl * nsteps + step];
+                        for (size_t i = 0; i < mx; ++i) hlist.push_back(i < v.size() ? v[i] : -1);
+                    }
+                }
+            }
+            if (debug) fprintf(stderr, "[asvd_svd]   lists built at %.2f ms (%zu slots)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - sweep_t0).count(), hlist.size());
+            if (!hlist.empty()) ASVD_HIP_CHECK(hipMemcpyAsync(plist_dev, hlist.data(), hlist.size() * sizeof(int), hipMemcpyHostToDevice, st));
+            if (ngroups >= 2) {
+                ASVD_HIP_CHECK(hipEventRecord(ev_fork, st));
+                for (int g = 0; g < ngroups; ++g) ASVD_HIP_CHECK(hipStreamWaitEvent(gst[g], ev_fork, 0));
+            }
         }
         const int gstride = std::max(p.nsplit, p.fused ? p.nchunks_f : 0);  // partial-Gram slots per pair in the buffer
         for (int step = 0; step < nsteps; ++step) {
@@ -1550,17 +1744,49 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
                 int* ag = active + (int64_t)b0 * p.npairs;
                 // fused path: the Gram blocks of this step were produced by the previous step's upgram launch (or by the last one
                 // of the previous sweep); only the very first step of the call needs the stand-alone gram kernel
+                if (sparse) {
+                    const int slots = sl_cnt[(size_t)g * nsteps + step];
+                    if (slots == 0) continue;  // no marked pair of this group meets in this step
+                    const int* pl = plist_dev + sl_off[(size_t)g * nsteps + step];
+                    // few pairs per launch: split the rows further to fill the CUs, within the partial-Gram capacity of a problem
+                    const int64_t chunks = p.m_pad / 32, cap = (int64_t)p.npairs * p.nsplit / slots;
+                    int64_t ns = std::max<int64_t>(p.nsplit, ceil_div64(768, (int64_t)slots * nbg));
+                    ns = std::min<int64_t>(std::min<int64_t>(ns, cap), std::min<int64_t>(chunks, 64));
+                    if (ns < 1) ns = 1;
+                    const int rps = (int)(ceil_div64(chunks, ns) * 32);
+                    const int nsp = (int)ceil_div64(p.m_pad, rps);
+                    const int64_t iters = ceil_div64(p.R_upd, 128);
+                    int64_t nc = std::min<int64_t>(iters, std::max<int64_t>(1, ceil_div64(1024, (int64_t)slots * nbg)));
+                    const int rpw = (int)(ceil_div64(iters, nc) * 128);
+                    const int nch = (int)ceil_div64(p.R_upd, rpw);
+                    {
+                        ProfScope ps(1, s2);
+                        gram_kernel<<<dim3(nsp, slots, nbg), 256, 0, s2>>>(Xg, p.panel_stride, p.batch_stride, p.nb, step, p.m_pad, rps, Gg,
+                                                                           done + b0, pl, slots);
+                    }
+                    {
+                        ProfScope ps(2, s2);
+                        evd_kernel<<<dim3(slots, nbg), 256, 0, s2>>>(Gg, nsp, Qg, ag, maxoff + b0, nrot + b0, done + b0, tol, inner_sweeps,
+                                                                     p.nb, step, kb, hist_dev, pl, slots);
+                    }
+                    {
+                        ProfScope ps(3, s2);
+                        update_kernel<<<dim3(nch, slots, nbg), 256, 0, s2>>>(Xg, p.panel_stride, p.batch_stride, p.nb, step, p.R_upd, rpw, Qg,
+                                                                             ag, done + b0, pl, slots);
+                    }
+                    continue;
+                }
                 const bool gram_here = !p.fused || (sweep == 0 && step == 0);
                 const int ns_here = gram_here ? p.nsplit : p.nchunks_f;
                 if (gram_here) {
                     ProfScope ps(1, s2);
                     gram_kernel<<<dim3(p.nsplit, p.npairs, nbg), 256, 0, s2>>>(Xg, p.panel_stride, p.batch_stride, p.nb, step, p.m_pad,
-                                                                               p.rows_per_split, Gg, done + b0);
+                                                                               p.rows_per_split, Gg, done + b0, nullptr, 0);
                 }
                 {
                     ProfScope ps(2, s2);
                     evd_kernel<<<dim3(p.npairs, nbg), 256, 0, s2>>>(Gg, ns_here, Qg, ag, maxoff + b0, nrot + b0, done + b0, tol,
-                                                                     inner_sweeps, p.nb, step, kb, hist_dev);
+                                                                     inner_sweeps, p.nb, step, kb, hist_dev, nullptr, 0);
                 }
                 {
                     ProfScope ps(3, s2);
@@ -1571,7 +1797,7 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
                                                                                         done + b0);
                     } else {
                         update_kernel<<<dim3(p.nchunks, p.npairs, nbg), 256, 0, s2>>>(Xg, p.panel_stride, p.batch_stride, p.nb, step,
-                                                                                      p.R_upd, p.rows_per_wg, Qg, ag, done + b0);
+                                                                                      p.R_upd, p.rows_per_wg, Qg, ag, done + b0, nullptr, 0);
                     }
                 }
             }
@@ -1595,7 +1821,7 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
             const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - sweep_t0).count();
             long rot = 0;
             for (int b = 0; b < batch; ++b) rot += host_done[b] ? 0 : flags[batch + b];
-            fprintf(stderr, "[asvd_svd] sweep %d wall %.2f ms, rotated pairs (all problems) %ld\n", sweep + 1, ms, rot);
+            fprintf(stderr, "[asvd_svd] sweep %d%s wall %.2f ms, rotated pairs (all problems) %ld, marked %lld\n", sweep + 1, sparse ? " (sparse)" : "", ms, rot, marked_total);
         }
         bool all_done = true;
         bool changed = false;
@@ -1606,7 +1832,7 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
             std::memcpy(&mo, &bits, sizeof(float));
             sweeps_done[b] = sweep + 1;
             last_rot[b] = flags[batch + b];
-            if (g_prof_enabled) { g_prof_pairs[0] += (long long)p.nb * (p.nb - 1) / 2; g_prof_pairs[1] += last_rot[b]; }
+            if (g_prof_enabled) { g_prof_pairs[0] += sparse ? 0 : (long long)p.nb * (p.nb - 1) / 2; g_prof_pairs[1] += last_rot[b]; }
             last_off[b] = mo;
             if (debug) fprintf(stderr, "[asvd_svd] b=%d sweep=%d maxoff=%.3e rotated_pairs=%d\n", b, sweep + 1, mo, last_rot[b]);
             if (mo != mo) { status[b] = ASVD_N_NAN; host_done[b] = 1; changed = true; }
@@ -1619,7 +1845,15 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
             else all_done = false;
             prev_off[b] = mo;
         }
+        if (g_prof_enabled && sparse) g_prof_pairs[0] += marked_total;
         if (all_done) { ++sweep; break; }
+        {
+            // the next sweep is sparse once fewer than half of the pairs of the still-running problems rotated in this one
+            long long rot = 0, tot = 0;
+            for (int b = 0; b < batch; ++b)
+                if (!host_done[b]) { rot += last_rot[b]; tot += (long long)p.nb * (p.nb - 1) / 2; }
+            sparse = sparse_allowed && tot > 0 && (double)rot < sparse_frac * (double)tot;
+        }
         if (changed) {
             ASVD_HIP_CHECK(hipMemcpyAsync(done, host_done.data(), (size_t)batch * sizeof(int), hipMemcpyHostToDevice, st));
             ASVD_HIP_CHECK(hipStreamSynchronize(st));  // host_done may be modified next sweep
