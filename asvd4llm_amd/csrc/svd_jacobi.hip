@@ -1467,8 +1467,8 @@ int make_plan(int batch, int64_t m, int64_t n, int want_u, int want_vv, Plan& p)
 
 // ---- optional per-class timing with HIP events on the call's stream ------------------------------
 bool g_prof_enabled = false;
-float g_prof_ms[5] = {0, 0, 0, 0, 0};
-int g_prof_launches[5] = {0, 0, 0, 0, 0};
+float g_prof_ms[6] = {0, 0, 0, 0, 0, 0};
+int g_prof_launches[6] = {0, 0, 0, 0, 0, 0};
 long long g_prof_pairs[2] = {0, 0};  // {pair visits (gram), rotated pairs (evd + update)} of the last profiled call
 struct ProfRec { int cls; hipEvent_t a, b; };
 std::vector<ProfRec> g_prof_recs;
@@ -1483,7 +1483,7 @@ struct ProfScope {
     }
 };
 void prof_begin() {
-    for (int i = 0; i < 5; ++i) { g_prof_ms[i] = 0; g_prof_launches[i] = 0; }
+    for (int i = 0; i < 6; ++i) { g_prof_ms[i] = 0; g_prof_launches[i] = 0; }
     g_prof_pairs[0] = g_prof_pairs[1] = 0;
     g_prof_recs.clear();
 }
@@ -1527,7 +1527,7 @@ int asvd_svd_get_pair_counts(long long* counts_host) {
 
 int asvd_svd_get_profile(float* ms_host, int* launches_host) {
     if (!ms_host || !launches_host) return ASVD_E_BADARG;
-    for (int i = 0; i < 5; ++i) { ms_host[i] = g_prof_ms[i]; launches_host[i] = g_prof_launches[i]; }
+    for (int i = 0; i < 6; ++i) { ms_host[i] = g_prof_ms[i]; launches_host[i] = g_prof_launches[i]; }
     return ASVD_OK;
 }
 
@@ -1679,7 +1679,7 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
         if (sparse) {
             // 1. snapshot of all couplings, per stream group
             for (int g = 0; g < ngroups; ++g) {
-                ProfScope ps(1, gst[g]);
+                ProfScope ps(5, gst[g]);
                 const int b0 = gb0[g], nbg = gnb[g];
                 const float* Xg = X + (int64_t)b0 * p.batch_stride;
                 ASVD_HIP_CHECK(hipMemsetAsync(pflag + (size_t)b0 * p.nb * p.nb, 0, (size_t)nbg * p.nb * p.nb, gst[g]));

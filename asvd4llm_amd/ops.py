@@ -229,11 +229,11 @@ def svd_profile(enable=None):
     if enable is not None:
         lib.asvd_svd_set_profiling(1 if enable else 0)
         return None
-    ms = (ctypes.c_float * 5)()
-    n = (ctypes.c_int * 5)()
+    ms = (ctypes.c_float * 6)()
+    n = (ctypes.c_int * 6)()
     lib.asvd_svd_get_profile(ms, n)
-    names = ["pack", "gram", "evd", "update", "finalize"]
-    out = {names[i]: {"ms": ms[i], "launches": n[i]} for i in range(5)}
+    names = ["pack", "gram", "evd", "update", "finalize", "snapshot"]
+    out = {names[i]: {"ms": ms[i], "launches": n[i]} for i in range(6)}
     cnt = (ctypes.c_longlong * 2)()
     lib.asvd_svd_get_pair_counts(cnt)
     out["pairs"] = {"visited": int(cnt[0]), "rotated": int(cnt[1])}

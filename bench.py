@@ -113,7 +113,10 @@ def main():
         value = total_svds / dt
         f_svd = svd_flops(m, n)
         pairs_cnt = prof.pop("pairs")
-        dom = max(("gram", "evd", "update"), key=lambda k: prof[k]["ms"])
+        dom_all = max(("gram", "evd", "update"), key=lambda k: prof[k]["ms"])
+        # the eigen-solve is a latency-bound LDS kernel without a byte/flop ceiling; the roofline is reported for the dominant
+        # STREAMING kernel and the class that leads by total time is named next to it
+        dom = max(("gram", "update"), key=lambda k: prof[k]["ms"])
         classes = {k: {"ms_per_step": v["ms"], "launches": v["launches"], "avg_us": (1e3 * v["ms"] / v["launches"]) if v["launches"] else 0.0}
                    for k, v in prof.items()}
         # ALGORITHMIC HBM bytes of the two streaming kernels, from the library's own pair counters of this step:
@@ -162,6 +165,7 @@ def main():
         issued = pair_flops["update"] * pairs_cnt["rotated"] + pair_flops["gram"] * pairs_cnt["visited"]
         roofline["executed_tflops_whole_job"] = {"issued_fp32_mfma_flops_per_step": issued, "achieved": issued / (dt / args.steps) / 1e12,
                                                  "peak": 157.3, "unit": "TFLOP/s"}
+        roofline["dominant_by_total_time"] = dom_all + "_kernel"
         roofline["classes"] = classes
         roofline["sweeps"] = [i.sweeps for i in infos]
         out = {

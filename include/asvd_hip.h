@@ -176,8 +176,8 @@ int asvd_reconstruct_err(const void* W, int w_dtype, int64_t ldw, const void* A,
 
 /* ---------------------------------------------------------------------------------------------
  * Instrumentation: per-kernel-class wall time of the last asvd_svd_batched call, measured with HIP
- * events on the call's stream when enabled.  classes: 0 pack, 1 gram, 2 evd, 3 update, 4 finalize.
- * ms_host: float[5] total milliseconds; launches_host: int[5].  */
+ * events on the call's stream when enabled.  classes: 0 pack, 1 gram, 2 evd, 3 update, 4 finalize, 5 snapshot (the
+ * blocked X^T X pass that opens a sparse sweep).  ms_host: float[6] total milliseconds; launches_host: int[6].  */
 void asvd_svd_set_profiling(int enabled);
 int asvd_svd_get_profile(float* ms_host, int* launches_host);
 /* counts_host: long long[2] = {panel-pair visits (one Gram each), pairs actually rotated (one eigen-solve + one update each)} summed
