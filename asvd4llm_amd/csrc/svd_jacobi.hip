@@ -1951,8 +1951,8 @@ static int tall_layout(int batch, const Plan& p, int want_vectors, int64_t k, Ta
     t.off_fail = take((size_t)batch * sizeof(int));
     t.off_r = take((size_t)p.n_pad * p.n_pad * batch * sizeof(float));
     t.off_vr = take(want_vectors ? (size_t)2 * p.cols * k * batch * sizeof(float) : 0);  // permuted + un-permuted right vectors
-    t.off_part = take(want_vectors ? (size_t)64 * k * sizeof(double) : 0);
-    t.off_inv = take(want_vectors ? (size_t)k * sizeof(float) : 0);
+    t.off_part = take(want_vectors ? (size_t)64 * k * batch * sizeof(double) : 0);  // per problem: the epilogues run on side streams
+    t.off_inv = take(want_vectors ? (size_t)k * batch * sizeof(float) : 0);
     Plan pi;
     int rc = make_plan(batch, p.cols, p.cols, want_vectors, want_vectors, pi);
     if (rc) return rc;
@@ -2060,23 +2060,49 @@ static int svd_tall(int batch, const void* const* a_host, int a_dtype, int64_t m
     if (rc < 0) return rc;
     if (want_vectors) {
         ProfScope ps(4, st);
+        // the per-problem epilogues (un-permute, long-side GEMM, sigma refinement) are independent: spread them over three side
+        // streams so the 1024-workgroup GEMMs overlap each other's tails
+        constexpr int NES = 3;
+        static hipStream_t s_epi[NES] = {nullptr, nullptr, nullptr};
+        hipEvent_t e_fork = nullptr, e_join[NES] = {nullptr, nullptr, nullptr};
+        const int nes = batch >= 2 ? NES : 1;
+        if (nes > 1) {
+            ASVD_HIP_CHECK(hipEventCreateWithFlags(&e_fork, hipEventDisableTiming));
+            ASVD_HIP_CHECK(hipEventRecord(e_fork, st));
+            for (int i = 0; i < nes; ++i) {
+                if (!s_epi[i]) ASVD_HIP_CHECK(hipStreamCreateWithFlags(&s_epi[i], hipStreamNonBlocking));
+                ASVD_HIP_CHECK(hipStreamWaitEvent(s_epi[i], e_fork, 0));
+                ASVD_HIP_CHECK(hipEventCreateWithFlags(&e_join[i], hipEventDisableTiming));
+            }
+        }
         for (int b = 0; b < batch; ++b) {
-            row_unpermute_kernel<<<dim3((unsigned)ceil_div64(k, 256), p.cols), 256, 0, st>>>(vperm[b], cperm + (int64_t)b * p.n_pad, p.cols, (int)k, vr[b]);
+            hipStream_t se = nes > 1 ? s_epi[b % nes] : st;
+            row_unpermute_kernel<<<dim3((unsigned)ceil_div64(k, 256), p.cols), 256, 0, se>>>(vperm[b], cperm + (int64_t)b * p.n_pad, p.cols, (int)k, vr[b]);
             float* long_out = p.transposed ? (V_host ? V_host[b] : nullptr) : (U_host ? U_host[b] : nullptr);
             if (!long_out) continue;
-            nn_gemm_kernel<<<dim3((unsigned)ceil_div64(k, 128), (unsigned)ceil_div64(p.rows, 128)), 256, 0, st>>>(
+            nn_gemm_kernel<<<dim3((unsigned)ceil_div64(k, 128), (unsigned)ceil_div64(p.rows, 128)), 256, 0, se>>>(
                 Xp + (int64_t)b * p.batch_stride, p.panel_stride, p.nb, p.rows, p.cols, vr[b], k, nullptr, (int)k, long_out, k);
             // sigma_j = |X v_j| and unit left vectors
             const int nsp = (int)std::min<int64_t>(64, ceil_div64(p.rows, 256));
             const int rps = (int)ceil_div64(p.rows, nsp);
-            double* part = (double*)(wb + t.off_part);
-            float* invs = (float*)(wb + t.off_inv);
-            colsumsq_kernel<<<dim3((unsigned)ceil_div64(k, 64), nsp), 256, 0, st>>>(long_out, k, p.rows, (int)k, rps, part);
-            colfinish_kernel<<<1, 256, 0, st>>>(part, nsp, (int)k, S_host[b], invs);
-            colscale_kernel<<<dim3((unsigned)ceil_div64(k, 256), (unsigned)ceil_div64(p.rows, 32)), 256, 0, st>>>(long_out, k, p.rows, (int)k, invs);
+            double* part = (double*)(wb + t.off_part) + (size_t)b * 64 * k;
+            float* invs = (float*)(wb + t.off_inv) + (size_t)b * k;
+            colsumsq_kernel<<<dim3((unsigned)ceil_div64(k, 64), nsp), 256, 0, se>>>(long_out, k, p.rows, (int)k, rps, part);
+            colfinish_kernel<<<1, 256, 0, se>>>(part, nsp, (int)k, S_host[b], invs);
+            colscale_kernel<<<dim3((unsigned)ceil_div64(k, 256), (unsigned)ceil_div64(p.rows, 32)), 256, 0, se>>>(long_out, k, p.rows, (int)k, invs);
+        }
+        if (nes > 1) {
+            for (int i = 0; i < nes; ++i) {
+                ASVD_HIP_CHECK(hipEventRecord(e_join[i], s_epi[i]));
+                ASVD_HIP_CHECK(hipStreamWaitEvent(st, e_join[i], 0));
+            }
         }
         ASVD_HIP_CHECK(hipStreamSynchronize(st));
         ASVD_HIP_CHECK(hipGetLastError());
+        if (nes > 1) {
+            (void)hipEventDestroy(e_fork);
+            for (int i = 0; i < nes; ++i) (void)hipEventDestroy(e_join[i]);
+        }
     }
     return rc;
 }
