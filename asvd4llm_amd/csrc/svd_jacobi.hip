@@ -1624,9 +1624,9 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
     const int nsteps = pair_order_xor() ? 2 * p.npairs - 1 : p.nb - 1;
     // panels whose convergence is enforced: those holding the k leading columns, plus one panel of margin
     const int kb = (int)(ceil_div64(k, PB) + 1 < p.nb ? ceil_div64(k, PB) + 1 : p.nb);
-    // two inner sweeps cut the outer sweeps 15 -> 13 at 4096^2 (fewer HBM passes: right for batches); a lone problem is bound
-    // by the eigen-solve latency instead, where one inner sweep is faster end to end
-    const int inner_sweeps = getenv("ASVD_INNER") ? atoi(getenv("ASVD_INNER")) : (batch >= 4 ? 2 : 1);
+    // one inner sweep of the 64x64 eigen-solve per visit: with the XOR schedule a second one no longer saves outer sweeps
+    // (measured 26.3 vs 25.9 SVD/s; under the round-robin order two inner sweeps cut 15 -> 13 outer sweeps)
+    const int inner_sweeps = getenv("ASVD_INNER") ? atoi(getenv("ASVD_INNER")) : 1;
     int sweep = 0;
     // Independent problems of a batch are split into two groups driven on two internal streams: while one group sits in its
     // LDS/VALU-bound evd phase the other streams panels through its HBM-bound gram/update phase (different resources).
