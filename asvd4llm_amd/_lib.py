@@ -39,6 +39,7 @@ SIGNATURES = {
     "asvd_svd_set_profiling": (None, [_i]),
     "asvd_svd_get_profile": (_i, [_c.POINTER(_f), _c.POINTER(_i)]),
     "asvd_svd_get_pair_counts": (_i, [_c.POINTER(_c.c_longlong)]),
+    "asvd_svd_get_sweep_times": (_i, [_c.POINTER(_f), _c.POINTER(_c.c_longlong), _i]),
 }
 
 _lib = None

@@ -1469,7 +1469,9 @@ int make_plan(int batch, int64_t m, int64_t n, int want_u, int want_vv, Plan& p)
 bool g_prof_enabled = false;
 float g_prof_ms[6] = {0, 0, 0, 0, 0, 0};
 int g_prof_launches[6] = {0, 0, 0, 0, 0, 0};
-long long g_prof_pairs[2] = {0, 0};  // {pair visits (gram), rotated pairs (evd + update)} of the last profiled call
+long long g_prof_pairs[2] = {0, 0};
+std::vector<float> g_prof_sweep_ms;       // wall time of every sweep of the last profiled call (all problems of the batch together)
+std::vector<long long> g_prof_sweep_rot;  // pairs rotated in it  // {pair visits (gram), rotated pairs (evd + update)} of the last profiled call
 struct ProfRec { int cls; hipEvent_t a, b; };
 std::vector<ProfRec> g_prof_recs;
 
@@ -1485,6 +1487,8 @@ struct ProfScope {
 void prof_begin() {
     for (int i = 0; i < 6; ++i) { g_prof_ms[i] = 0; g_prof_launches[i] = 0; }
     g_prof_pairs[0] = g_prof_pairs[1] = 0;
+    g_prof_sweep_ms.clear();
+    g_prof_sweep_rot.clear();
     g_prof_recs.clear();
 }
 void prof_end() {
@@ -1518,6 +1522,15 @@ int launch_pack(const void* src, int64_t ld, const void* s, int cs_dtype, const 
 extern "C" {
 
 void asvd_svd_set_profiling(int enabled) { g_prof_enabled = enabled != 0; }
+int asvd_svd_get_sweep_times(float* ms_host, long long* rotated_host, int cap) {
+    const int n = (int)g_prof_sweep_ms.size();
+    for (int i = 0; i < n && i < cap; ++i) {
+        if (ms_host) ms_host[i] = g_prof_sweep_ms[i];
+        if (rotated_host) rotated_host[i] = g_prof_sweep_rot[i];
+    }
+    return n;
+}
+
 int asvd_svd_get_pair_counts(long long* counts_host) {
     if (!counts_host) return ASVD_E_BADARG;
     counts_host[0] = g_prof_pairs[0];
@@ -1828,6 +1841,12 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
             fprintf(stderr, "[asvd_svd] sweep %d pair-measure histogram by decade 1e0..1e-9:", sweep + 1);
             for (int i = 0; i < 10; ++i) fprintf(stderr, " %d", hh[i]);
             fprintf(stderr, "\n");
+        }
+        if (g_prof_enabled) {
+            long long rot = 0;
+            for (int b = 0; b < batch; ++b) rot += host_done[b] ? 0 : flags[batch + b];
+            g_prof_sweep_ms.push_back((float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - sweep_t0).count());
+            g_prof_sweep_rot.push_back(rot);
         }
         if (debug) {
             const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - sweep_t0).count();

@@ -237,4 +237,9 @@ def svd_profile(enable=None):
     cnt = (ctypes.c_longlong * 2)()
     lib.asvd_svd_get_pair_counts(cnt)
     out["pairs"] = {"visited": int(cnt[0]), "rotated": int(cnt[1])}
+    sms = (ctypes.c_float * 64)()
+    srot = (ctypes.c_longlong * 64)()
+    ns = min(64, lib.asvd_svd_get_sweep_times(sms, srot, 64))
+    out["sweep_ms"] = [float(sms[i]) for i in range(ns)]
+    out["sweep_rotated"] = [int(srot[i]) for i in range(ns)]
     return out

@@ -113,6 +113,7 @@ def main():
         value = total_svds / dt
         f_svd = svd_flops(m, n)
         pairs_cnt = prof.pop("pairs")
+        sweep_ms, sweep_rot = prof.pop("sweep_ms"), prof.pop("sweep_rotated")
         dom_all = max(("gram", "evd", "update"), key=lambda k: prof[k]["ms"])
         # the eigen-solve is a latency-bound LDS kernel without a byte/flop ceiling; the roofline is reported for the dominant
         # STREAMING kernel and the class that leads by total time is named next to it
@@ -166,6 +167,21 @@ def main():
         roofline["executed_tflops_whole_job"] = {"issued_fp32_mfma_flops_per_step": issued, "achieved": issued / (dt / args.steps) / 1e12,
                                                  "peak": 157.3, "unit": "TFLOP/s"}
         roofline["dominant_by_total_time"] = dom_all + "_kernel"
+        # whole-GPU view of the hot loop: in the first sweep every pair rotates, so the pairwise kernels of all stream groups together
+        # move (gram 1x + update 2x) the panels of every visited pair and issue gram (3 blocks) + update (4 blocks) MFMAs per pair
+        if sweep_ms:
+            P2 = 1
+            while P2 < cols_pad // 32: P2 *= 2
+            dup = max(0, min(7, P2 // 16 - 1))
+            nb_ = cols_pad // 32
+            visits = B * (nb_ * (nb_ - 1) // 2 + sum(sum(1 for i in range(nb_) if i < (i ^ d) < nb_) for d in range(1, dup + 1)))
+            t1 = sweep_ms[0] * 1e-3
+            roofline["first_sweep_aggregate"] = {
+                "wall_ms": sweep_ms[0], "pair_visits": visits, "GBps": 3.0 * pair_bytes * visits / t1 / 1e9, "frac_of_8TBps": 3.0 * pair_bytes * visits / t1 / 8e12,
+                "TFLOPs_fp32_mfma": (pair_flops["gram"] + pair_flops["update"]) * visits / t1 / 1e12,
+                "frac_of_157TF": (pair_flops["gram"] + pair_flops["update"]) * visits / t1 / 157.3e12}
+        roofline["sweep_wall_ms"] = sweep_ms
+        roofline["sweep_rotated_pairs"] = sweep_rot
         roofline["classes"] = classes
         roofline["sweeps"] = [i.sweeps for i in infos]
         out = {

@@ -183,6 +183,9 @@ int asvd_svd_get_profile(float* ms_host, int* launches_host);
 /* counts_host: long long[2] = {panel-pair visits (one Gram each), pairs actually rotated (one eigen-solve + one update each)} summed
  * over the sweeps and problems of the last profiled call: the algorithmic byte counts of the streaming kernels follow from these. */
 int asvd_svd_get_pair_counts(long long* counts_host);
+/* host wall time (ms) and rotated pairs of every Jacobi sweep of the last profiled call, whole batch together (the call
+ * synchronises once per sweep).  Fills at most `cap` entries; returns the number of sweeps. */
+int asvd_svd_get_sweep_times(float* ms_host, long long* rotated_host, int cap);
 
 #ifdef __cplusplus
 }
