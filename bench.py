@@ -36,7 +36,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=16, help="matrices factorised concurrently per step and GPU")
+    ap.add_argument("--batch", type=int, default=16, help="matrices factorised concurrently per step and GPU (6+5+5 per stream group; 32 measured +3 % at best but with large run-to-run variance)")
     ap.add_argument("--m", type=int, default=4096)
     ap.add_argument("--n", type=int, default=4096)
     ap.add_argument("--rank", type=int, default=512)
