@@ -1265,25 +1265,41 @@ __global__ __launch_bounds__(256) void nn_gemm_kernel(const float* __restrict__ 
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = (f32x16){0};
     float* my = At[w];
-    for (int p = 0; p < nb; ++p) {
+    // the next panel's A rows (4 x 16 B per lane) and B rows (16 floats per thread) are prefetched into registers while the
+    // current panel is in the matrix pipe
+    f32x4 pa[4];
+    float pb[16];
+    auto fetch = [&](int p) {
         const float* P = X + (int64_t)p * panel_stride;
-        // A tile: rows r0..r0+31 of panel p (contiguous 4 KiB; rows >= rows_pad never read: the panel has m_pad rows)
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int idx = it * 256 + lane * 4;
             const int row = idx >> 5, col = idx & 31;
-            f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (r0 + row < rows) v = *(const f32x4*)(P + (int64_t)(r0 + row) * PB + col);
-            *(f32x4*)(my + row * 36 + col) = v;
+            pa[it] = (r0 + row < rows) ? *(const f32x4*)(P + (int64_t)(r0 + row) * PB + col) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         }
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
             const int idx = it * 256 + tid;
             const int kr = idx >> 7, cc = idx & 127;
             const int vr = p * PB + kr, vc = c0 + cc;
-            Bt[kr * NBLD + cc] = (vr < cols && vc < k) ? Vr[(int64_t)vr * ldv + vc] : 0.0f;
+            pb[it] = (vr < cols && vc < k) ? Vr[(int64_t)vr * ldv + vc] : 0.0f;
+        }
+    };
+    fetch(0);
+    for (int p = 0; p < nb; ++p) {
+        __syncthreads();  // previous panel's Bt fully consumed
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int idx = it * 256 + lane * 4;
+            *(f32x4*)(my + (idx >> 5) * 36 + (idx & 31)) = pa[it];
+        }
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int idx = it * 256 + tid;
+            Bt[(idx >> 7) * NBLD + (idx & 127)] = pb[it];
         }
         __syncthreads();
+        if (p + 1 < nb) fetch(p + 1);
         float a[16];
 #pragma unroll
         for (int t4 = 0; t4 < 4; ++t4) {
@@ -1296,7 +1312,6 @@ __global__ __launch_bounds__(256) void nn_gemm_kernel(const float* __restrict__ 
             for (int tl = 0; tl < 4; ++tl)
                 acc[tl] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], Bt[(h * 16 + t) * NBLD + tl * 32 + c], acc[tl], 0, 0, 0);
         }
-        __syncthreads();
     }
 #pragma unroll
     for (int tl = 0; tl < 4; ++tl) {
