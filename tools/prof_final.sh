@@ -2,7 +2,7 @@
 set -x
 cd /tmp; export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$R/gpurun_out/prof_l; mkdir -p $OUT
+OUT=$R/gpurun_out/prof_m; mkdir -p $OUT
 cd $R
 rocprofv3 --kernel-trace --stats -d $OUT/kt -- python bench.py --no_cpu_baseline > $OUT/bench_under_rocprof.json 2> $OUT/kt.log
 DB=$(find $OUT/kt -name "*.db" | head -1)
