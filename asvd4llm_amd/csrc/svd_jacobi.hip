@@ -279,6 +279,9 @@ __global__ __launch_bounds__(256, 4) void evd_kernel(const float* __restrict__ G
 
     const int pair = blockIdx.x, b = blockIdx.y, npairs = gridDim.x;
     if (done[b]) return;
+    // the eigen-solve is a dependent chain of short VALU/LDS phases on every group's critical path: let its waves win the issue
+    // arbitration against the matrix-pipe-bound gram/update waves of the other stream groups that share the SIMD
+    __builtin_amdgcn_s_setprio(3);
     const int tid = threadIdx.x;
     int I, J;
     if (!get_pair(plist, list_stride, b, nb, step, pair, I, J)) {  // padding pair / empty slot: nothing to rotate

@@ -40,7 +40,7 @@ def main():
     ap.add_argument("--m", type=int, default=4096)
     ap.add_argument("--n", type=int, default=4096)
     ap.add_argument("--rank", type=int, default=512)
-    ap.add_argument("--prewarm_s", type=float, default=3.0, help="seconds of untimed identical work before the warm-up steps (0 disables)")
+    ap.add_argument("--prewarm_s", type=float, default=5.0, help="seconds of untimed identical work before the warm-up steps (0 disables)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--cpu_reps", type=int, default=1, help="timed repetitions of the CPU oracle pipeline (about 15-25 s each on the GPU box host)")
     args = ap.parse_args()
