@@ -70,15 +70,21 @@ def main(args):
             ranks = save_asvd_repo(model, args.save_repo, tokenizer if hasattr(tokenizer, "save_pretrained") else None)
             print(f"saved ASVD repo with {len(ranks)} factorised layers to {args.save_repo}")
 
+    if args.dist and int(os.environ.get("RANK", "0")) != 0 and args.gather_factors != "all":
+        # only rank 0 holds the complete compressed model (factors gathered point-to-point): it alone evaluates and reports
+        import torch.distributed as dist
+        dist.destroy_process_group()  # no collective follows the factor exchange
+        return
     eval_ids = torch.cat([_["input_ids"] for _ in calib_loader], 0) if (not args.raw_model and args.calib_dataset == "synthetic") else None
     result = evaluate_model(model, tokenizer, args.model_id, "mmlu" if args.eval_mmlu else args.eval_tasks, eval_ppl=args.eval_ppl, limit=-1,
                             use_bos=args.use_bos, eval_ids=eval_ids)
     print(result)
-    if not os.path.exists("output"):
-        os.makedirs("output")
-    with open("output/result.txt", "a+") as f:
-        f.write(f"{args}\n")
-        f.write(f"{result}\n")
+    if not args.dist or int(os.environ.get("RANK", "0")) == 0:
+        if not os.path.exists("output"):
+            os.makedirs("output")
+        with open("output/result.txt", "a+") as f:
+            f.write(f"{args}\n")
+            f.write(f"{result}\n")
     if args.dist:
         import torch.distributed as dist
         if dist.is_initialized():
@@ -117,6 +123,9 @@ def build_parser():
     parser.add_argument("--save_repo", type=str, default="", help="write the compressed model in the exported HF-repo layout of the reference (truncation_ranks in config.json)")
     parser.add_argument("--no_fused_sweep", dest="fused_sweep", action="store_false",
                         help="evaluate every (layer, ratio) with full model forwards as the reference does (default: prefix-cached evaluator, same values)")
+    parser.add_argument("--gather_factors", type=str, default="rank0", choices=["rank0", "all", "none"],
+                        help="--dist: after the sharded decomposition send every layer's A/B factors to rank 0 (point-to-point), to all ranks "
+                             "(broadcast), or nowhere")
     parser.add_argument("--dist", action="store_true", help="torchrun launch: one rank per GPU, layers sharded, RCCL all-gather of sensitivities")
     return parser
 

@@ -113,14 +113,17 @@ def binary_search_truncation_rank(model, sensitivity_dict, calib_loader, args):
         uses[id(prm)] = uses.get(id(prm), 0) + 1
 
     st = time.time()
+    exchange_items = []
     for layername, param_ratio in tqdm(layers_min_ratio.items(), disable=(rank != 0)):
         raw_linear = module_dict[layername]
         info = linear_info[raw_linear]
         if param_ratio == default_param_ratio:
             svd_linear = raw_linear
         elif shard and owner[layername] != rank:
-            svd_linear = raw_linear  # another rank owns this layer's factors
+            svd_linear = raw_linear  # another rank owns this layer's factors: they arrive in exchange_factors below
+            exchange_items.append((layername, info["father"], info["name"], raw_linear))
         else:
+            exchange_items.append((layername, info["father"], info["name"], raw_linear))
             svd_linear = SVDLinear.from_linear(
                 raw_linear,
                 param_ratio=param_ratio,
@@ -137,5 +140,16 @@ def binary_search_truncation_rank(model, sensitivity_dict, calib_loader, args):
         torch.cuda.synchronize()
     ed = time.time()
     print(f"decompose time: {ed-st}")
+    if shard:
+        # complete the model: every owner hands its factors to rank 0 (default) or to everybody — without this only ~1/ws of the
+        # layers of any one replica would be factorised and an export / evaluation would silently miss the target
+        mode = getattr(args, "gather_factors", "rank0")
+        t0 = time.time()
+        got = parallel.exchange_factors(exchange_items, owner, mode)
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        model._asvd_factor_exchange = {"mode": mode, "received": got, "seconds": time.time() - t0}
+        if rank == 0:
+            print(f"factor exchange ({mode}): received {got} layers in {time.time() - t0:.2f} s")
     model._asvd_layers_min_ratio = layers_min_ratio
     model._asvd_decompose_time = ed - st

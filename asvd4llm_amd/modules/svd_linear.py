@@ -117,6 +117,16 @@ class SVDLinear(nn.Module):
         U, S, V, info = ops.svd(wc, s, k=k)
         if info.status == 2:
             raise FloatingPointError("nan in svd")
+        if info.status == 1:
+            # ASVD_N_NOCONV: the sweeps stopped at max_sweeps.  Never cache an unconverged factorisation silently: one retry with a
+            # generous sweep budget, then strict mode raises and the default path warns (results of the retry are still returned).
+            U, S, V, info = ops.svd(wc, s, k=k, max_sweeps=60)
+            if info.status == 2:
+                raise FloatingPointError("nan in svd")
+            if info.status == 1:
+                if _strict():
+                    raise ArithmeticError(f"block-Jacobi SVD of {tuple(wc.shape)} did not converge in 60 sweeps")
+                print(f"warning: SVD of {linear} not converged after 60 sweeps (last rotated pairs {info.last_rotated_pairs})")
         linear._asvd_factor_cache = (key, (U, S, V, s))
         linear._asvd_svd_info = info
         return U, S, V, s
@@ -145,8 +155,8 @@ class SVDLinear(nn.Module):
                 scs = None if chunk[0][3] is None else [it[3] for it in chunk]
                 U, S, V, infos = ops.svd_batched([it[2] for it in chunk], scs, k=k)
                 for j, (lin, key, wc, s, _) in enumerate(chunk):
-                    if infos[j].status == 2:
-                        continue  # from_linear will hit the NaN path itself
+                    if infos[j].status != 0:
+                        continue  # NaN / not converged: from_linear -> factorize handles it (retry, strict raise, or NaN fallback)
                     lin._asvd_factor_cache = (key, (U[j], S[j], V[j], s))
                     lin._asvd_svd_info = infos[j]
 

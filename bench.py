@@ -31,6 +31,33 @@ def synth(size_m, size_n, seed, n_calib=32):
     return W.float(), scal.to(torch.float16)
 
 
+def dry_run(args, rank, world):
+    """CPU/gloo exercise of everything around the kernels: rank binding, rendezvous, barrier-bracketed timing, MAX over ranks, one
+    JSON line on rank 0.  No SVD runs (the product path has no CPU fallback), so value is null."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo")
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pass
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt, float(rank)], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        assert world == 1 or int(t[1].item()) == world - 1
+        print(json.dumps({"metric": "weight-matrix SVDs/sec (4096x4096 fp32)", "value": None, "unit": "SVD/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                          "data": "synthetic", "dry_run": True,
+                          "config": {"workload": "dry run: launch plumbing only", "batch_per_gpu": args.batch, "parallelism": f"independent matrices x{world}"}}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -43,7 +70,22 @@ def main():
     ap.add_argument("--prewarm_s", type=float, default=5.0, help="seconds of untimed identical work before the warm-up steps (0 disables)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--cpu_reps", type=int, default=1, help="timed repetitions of the CPU oracle pipeline (about 15-25 s each on the GPU box host)")
+    ap.add_argument("--dry_run", action="store_true", help="launch plumbing only (CPU, gloo): spawn/bind ranks, barrier, max-reduce, JSON line; no kernels, value = null")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` without a torchrun environment: launch the N ranks ourselves (one process per GPU, RCCL rendezvous on
+    # 127.0.0.1) and let rank 0 of the children print the JSON line.  Under the driver's own `python -m torch.distributed.run ...`
+    # WORLD_SIZE is already set and this branch is skipped.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        sys.exit(subprocess.call(cmd, env=env))
 
     import torch
     import torch.distributed as dist
@@ -53,9 +95,13 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus and rank == 0:
+        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: reporting n_gpus={world} (the ranks that actually run)", file=sys.stderr)
+    if args.dry_run:
+        return dry_run(args, rank, world)
     if world > 1:
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     _lib.load(require_device=True)  # fails loudly without the HIP library / a gfx950 device
 

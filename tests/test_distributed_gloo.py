@@ -141,3 +141,97 @@ def test_sharded_sweep_equals_single_process(tmp_path):
         assert list(sens.keys()) == list(ref.keys())
         for name in ref:
             assert sens[name] == ref[name]  # bit-identical floats through the fp64 wire format
+
+
+def _oracle_svdlinear(linear, param_ratio, act_aware=False, ic_split=1, oc_split=1, alpha=1, sigma_fuse="UV", rank_align=1):
+    """CPU stand-in that returns a real SVDLinear (ALinear/BLinear modules) built from oracle factors"""
+    from oracle import asvd_oracle as O
+    from asvd4llm_amd.modules.svd_linear import SVDLinear
+    o = O.from_linear_oracle(linear.weight.data, getattr(linear, "scaling_diag_matrix", None), param_ratio, alpha=alpha, act_aware=act_aware,
+                             sigma_fuse=sigma_fuse, rank_align=rank_align)
+    bias = linear.bias.data if linear.bias is not None else None
+    return SVDLinear._from_factors(o["A"].to(linear.weight.dtype), o["B"].to(linear.weight.dtype), bias, o["rank"])
+
+
+def _dist_pipeline_worker(rank, ws, port, q, tmpdir, mode):
+    import contextlib, io, os as _os
+    _os.chdir(tmpdir)
+    if ws > 1:
+        _os.environ["MASTER_ADDR"] = "127.0.0.1"
+        _os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=ws)
+    try:
+        from asvd4llm_amd import binary_search, sensitivity
+        from asvd4llm_amd.modules.svd_linear import SVDLinear
+        from tests.tiny_lm import TinyLM, default_args
+        SVDLinear.from_linear = staticmethod(_oracle_svdlinear)
+        SVDLinear.drop_factor_cache = staticmethod(lambda l: None)
+        model = TinyLM()
+        g = torch.Generator().manual_seed(5)
+        calib = [{"input_ids": torch.randint(0, 50, (1, 16), generator=g)} for _ in range(3)]
+        for n, m in model.named_modules():
+            if isinstance(m, torch.nn.Linear):
+                m.scaling_diag_matrix = torch.rand(m.in_features, generator=g) + 0.1
+        args = default_args(keep_svd_cache=False, prefactorize=False, fused_sweep=False, param_ratio_target=0.7, gather_factors=mode,
+                            offload_raw_to_cpu=False)
+        with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+            sens = sensitivity.calib_sensitivity_ppl(model, calib, args, use_cache=False)
+            binary_search.binary_search_truncation_rank(model, sens, calib, args)
+        state = {k: v.detach().float().numpy().copy() for k, v in model.state_dict().items()}  # numpy: no shared-memory handles through the queue
+        kinds = {n: type(m).__name__ for n, m in model.named_modules() if n in model._asvd_layers_min_ratio}
+        q.put((rank, model._asvd_layers_min_ratio, kinds, state))
+    finally:
+        if ws > 1:
+            dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("mode", ["rank0", "all"])
+def test_sharded_decomposition_completes_the_model(tmp_path, mode):
+    """world_size 2 (gloo) through sweep + search + sharded decomposition + factor exchange: the saving rank (rank 0; every rank with
+    mode 'all') holds EVERY selected layer as an SVDLinear, with exactly the factors a single process produces."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    (tmp_path / "w1").mkdir()
+    p = ctx.Process(target=_dist_pipeline_worker, args=(0, 1, 0, q, str(tmp_path / "w1"), mode))
+    p.start()
+    _, ratios1, kinds1, state1 = q.get(timeout=300)
+    p.join(30)
+    assert sum(1 for k in kinds1.values() if k == "SVDLinear") >= 3
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        (tmp_path / f"w2_{r}").mkdir()
+        procs.append(ctx.Process(target=_dist_pipeline_worker, args=(r, 2, port, q, str(tmp_path / f"w2_{r}"), mode)))
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    for rk, ratios, kinds, state in res:
+        assert ratios == ratios1
+        if rk == 0 or mode == "all":
+            assert kinds == kinds1, f"rank {rk} does not hold the complete compressed model"
+            assert state.keys() == state1.keys()
+            for k in state1:
+                assert (state[k] == state1[k]).all(), k
+        else:
+            n_svd = sum(1 for k in kinds.values() if k == "SVDLinear")
+            assert 0 < n_svd < sum(1 for k in kinds1.values() if k == "SVDLinear")  # a shard only
+
+
+@pytest.mark.timeout(300)
+def test_bench_gpus2_dry_run_spawns_two_ranks():
+    """`python bench.py --gpus 2` with no torchrun environment must launch two ranks itself and report n_gpus = 2 (CPU/gloo dry run:
+    launch plumbing only — no kernels run without a GPU)."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry_run", "--steps", "2"], env=env, capture_output=True,
+                         text=True, timeout=240)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1  # exactly one JSON line, from rank 0
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["dry_run"] is True and rec["scaling"] == "weak"

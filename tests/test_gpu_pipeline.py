@@ -333,3 +333,36 @@ def test_from_linear_vs_reference_mid_size_fixtures(gpu, golden):
         y = (m.ALinear.weight.data.float() @ (m.BLinear.weight.data.float() @ X.to(gpu))).cpu()
         y_ref, wx = torch.from_numpy(g[f"m{ci}_probe_y"]), torch.from_numpy(g[f"m{ci}_probe_wx"])
         assert ((y - y_ref).norm() / wx.norm()).item() <= 1e-3, (ci, ((y - y_ref).norm() / wx.norm()).item())
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_rccl_world1_allgather_and_exchange():
+    """The nccl (= RCCL) branch on the MI355X: a world-size-1 process group pushes the sensitivity all-gather
+    (all_gather_into_tensor on a CUDA fp64 buffer) and the factor broadcast through RCCL."""
+    import torch.distributed as dist
+    from asvd4llm_amd import parallel
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(29000 + os.getpid() % 2000)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        names = ["a", "b", "c"]
+        ratios = [0.4, 0.9]
+        local = {"a": {0.4: 1.25, 0.9: float("nan")}, "b": {0.4: float("inf"), 0.9: 3.000000123}, "c": {0.4: -1.0, 0.9: 0.0}}
+        full = parallel.allgather_sensitivities(local, names, ratios, [0, 0, 0])
+        assert list(full) == names
+        for n in names:
+            for r in ratios:
+                a, b = full[n][r], local[n][r]
+                assert (a != a and b != b) or a == b
+        # broadcast path of exchange_factors with the only rank as owner: nothing to receive, but the RCCL broadcasts run
+        lin = torch.nn.Linear(64, 48, bias=True).half().cuda()
+        from asvd4llm_amd.modules.svd_linear import SVDLinear
+        father = torch.nn.Module()
+        father.x = SVDLinear._from_factors(torch.randn(48, 8, device="cuda").half(), torch.randn(8, 64, device="cuda").half(), lin.bias.data, 8)
+        got = parallel.exchange_factors([("x", father, "x", lin)], {"x": 0}, mode="all")
+        torch.cuda.synchronize()
+        assert got == 0 and isinstance(father.x, SVDLinear)
+    finally:
+        dist.destroy_process_group()
