@@ -264,11 +264,25 @@ __device__ __forceinline__ int pcol(int c) { return ((c & 1) << 5) | (c >> 1); }
 // Thread (g, tx): column pair tx, row pairs 4g..4g+3 (4 blocks of G), rows 8g..8g+7 of Q's column pair tx.
 // Each lane computes the rotation of ITS column pair from a small side array (diagonal + pivot off-diagonals, ping-ponged);
 // the four row-pair rotations are the ones lanes 4g..4g+3 of the same half-wave just computed -> fetched with ds_bpermute.
+// Two-level extensions (twolevel.h):
+//   * inner mode (tw.G128 != nullptr): the workgroup solves sub-pair (slot & 1) of super-pair (slot >> 1) of super-step `step`
+//     (inner step tw.inner_t); the 64x64 matrix is gathered from the pair's 128x128 Gram matrix, Q is ALWAYS written (identity when
+//     nothing rotates: gupdate multiplies by it unconditionally) and the activity flag goes to tw.subact;
+//   * tw.gd_out != nullptr (single-level mode, the internal step d = 1): the transformed matrix Q^T G Q, sorted like Q's columns,
+//     is stored as the carried diagonal block of super-panel `pair`.
+struct EvdTwoLevel {
+    const float* G128;
+    int inner_t, ns;
+    int* subact;
+    float* gd_out;
+};
+__device__ __forceinline__ void sub_blocks(int t, int sp, int& a, int& b);
+
 __global__ __launch_bounds__(256, 4) void evd_kernel(const float* __restrict__ Gpart, int nsplit, float* __restrict__ Qbuf,
                                                    int* __restrict__ active, unsigned* __restrict__ maxoff_bits,
                                                    int* __restrict__ nrot, const int* __restrict__ done, float tol,
                                                    int inner_sweeps, int nb, int step, int kb, int* __restrict__ hist,
-                                                   const int* __restrict__ plist, int list_stride) {
+                                                   const int* __restrict__ plist, int list_stride, EvdTwoLevel tw) {
     __shared__ float G[PW * PW];
     __shared__ float Q[PW * PW];
     __shared__ float sdiag[2][PW];
@@ -277,20 +291,51 @@ __global__ __launch_bounds__(256, 4) void evd_kernel(const float* __restrict__ G
     __shared__ float cscale[PW];
     __shared__ int rnk[PW];
 
-    const int pair = blockIdx.x, b = blockIdx.y, npairs = gridDim.x;
+    const bool inner = tw.G128 != nullptr;
+    const int pair = inner ? (blockIdx.x >> 1) : blockIdx.x, b = blockIdx.y, npairs = inner ? (gridDim.x >> 1) : gridDim.x;
     if (done[b]) return;
     // the eigen-solve is a dependent chain of short VALU/LDS phases on every group's critical path: let its waves win the issue
     // arbitration against the matrix-pipe-bound gram/update waves of the other stream groups that share the SIMD
     __builtin_amdgcn_s_setprio(3);
     const int tid = threadIdx.x;
     int I, J;
-    if (!get_pair(plist, list_stride, b, nb, step, pair, I, J)) {  // padding pair / empty slot: nothing to rotate
-        if (tid == 0) active[b * npairs + pair] = 0;
-        return;
+    int* act_flag;   // where this solve reports whether it rotated
+    float* qo;       // its 64x64 Q
+    if (inner) {
+        const int sp = blockIdx.x & 1;
+        const int64_t slot = (int64_t)b * npairs + pair;
+        act_flag = tw.subact + slot * 4 + tw.inner_t * 2 + sp;
+        qo = Qbuf + (slot * 2 + sp) * (PW * PW);
+        int S, T;
+        rr_pair(tw.ns, step, pair, S, T);
+        if (T >= tw.ns) {  // padding super-pair
+            if (tid == 0) *act_flag = 0;
+            return;
+        }
+        int ba, bb;
+        sub_blocks(tw.inner_t, sp, ba, bb);
+        I = 2 * S + ba;
+        J = 2 * T + (bb - 2);
+        const float* __restrict__ g = tw.G128 + slot * (128 * 128);
+#pragma unroll 4
+        for (int q = 0; q < 16; ++q) {
+            const int e = tid + 256 * q, i = e >> 6, j = e & 63;
+            const float v = g[(32 * (i < 32 ? ba : bb) + (i & 31)) * 128 + 32 * (j < 32 ? ba : bb) + (j & 31)];
+            G[i * PW + pcol(j)] = v;
+            if (i == j) sdiag[0][i] = v;
+            if (j == i + 1 && (i & 1) == 0) sb[0][i >> 1] = v;
+        }
+    } else {
+        act_flag = active + b * npairs + pair;
+        qo = Qbuf + ((int64_t)b * npairs + pair) * (PW * PW);
+        if (!get_pair(plist, list_stride, b, nb, step, pair, I, J)) {  // padding pair / empty slot: nothing to rotate
+            if (tid == 0) *act_flag = 0;
+            return;
+        }
     }
     const float* gp = Gpart + ((int64_t)b * npairs + pair) * nsplit * 3072;
 
-    {
+    if (!inner) {
         // sum the row-split partials in fixed order: the three stored 32x32 blocks (II, IJ, JJ) are read fully coalesced (12
         // independent elements per thread keep 12+ loads in flight per split); the JI block is the mirror of IJ, written to LDS twice
         float acc[12];
@@ -370,11 +415,18 @@ __global__ __launch_bounds__(256, 4) void evd_kernel(const float* __restrict__ G
     }
     if (tid == 0) atomicMax(&maxoff_bits[b], is_nan ? 0x7fc00000u : __float_as_uint(offt));
     if (is_nan || off0 < tol) {
-        if (tid == 0) active[b * npairs + pair] = 0;
+        if (tid == 0) *act_flag = 0;
+        if (inner) {  // gupdate multiplies by Q unconditionally
+            for (int e = tid; e < PW * PW; e += 256) qo[e] = ((e >> 6) == (e & 63)) ? 1.0f : 0.0f;
+        }
+        if (tw.gd_out) {  // carried diagonal block of the super-panel = the matrix itself
+            float* gd = tw.gd_out + ((int64_t)b * tw.ns + pair) * (PW * PW);
+            for (int e = tid; e < PW * PW; e += 256) gd[e] = G[(e >> 6) * PW + pcol(e & 63)];
+        }
         return;
     }
     if (tid == 0) {
-        active[b * npairs + pair] = 1;
+        *act_flag = 1;
         if (offt >= tol) atomicAdd(&nrot[b], 1);
     }
 
@@ -517,10 +569,16 @@ __global__ __launch_bounds__(256, 4) void evd_kernel(const float* __restrict__ G
         rnk[tid] = cnt;
     }
     __syncthreads();
-    float* qo = Qbuf + ((int64_t)b * npairs + pair) * (PW * PW);
     for (int e = tid; e < PW * PW; e += 256) {
         const int r = e >> 6, c = e & 63;
         qo[r * PW + rnk[c]] = Q[r * PW + pcol(c)] * cscale[c];
+    }
+    if (tw.gd_out) {  // Q^T G Q (what the rotations left in LDS), in the order and scaling of Q's columns
+        float* gd = tw.gd_out + ((int64_t)b * tw.ns + pair) * (PW * PW);
+        for (int e = tid; e < PW * PW; e += 256) {
+            const int r = e >> 6, c = e & 63;
+            gd[rnk[r] * PW + rnk[c]] = G[r * PW + pcol(c)] * cscale[r] * cscale[c];
+        }
     }
 }
 
@@ -593,6 +651,8 @@ __global__ __launch_bounds__(256) void update_kernel(float* __restrict__ X, int6
         }
     }
 }
+
+#include "twolevel.h"
 
 // --------------------------------------------------------------------------------------------------
 // Sparse sweeps.  Once fewer than half of the pairs still rotate, most of a sweep is Gram passes that only confirm convergence
@@ -1394,6 +1454,9 @@ struct Plan {
     int m_pad, n_pad, nb, npairs, R, R_upd, want_v, vmode;  // vmode: 0 none, 1 accumulate V in the sweeps, 2 backsolve at the end
     int nsplit, rows_per_split, rows_per_wg, nchunks;
     int fused, nchunks_f, rows_per_wg_f;  // upgram path (XOR ordering, power-of-two panel count)
+    // two-level dense sweeps (twolevel.h): ns super-panels of 64 columns, npairs_s pair slots per super-step (power-of-two padded)
+    int two, ns, npairs_s, nsplit_s, rows_per_split_s, nchunks_s, rows_per_wg_s;
+    size_t off_gd, off_gx, off_g128, off_qacc, off_qfin, off_qsub, off_subact, off_active_s;
     int64_t panel_stride, batch_stride;
     // workspace offsets in bytes
     size_t off_x, off_xorig, off_gpart, off_q, off_active, off_sig, off_ina, off_inv, off_perm, off_flags, off_pflag, off_plist, total;
@@ -1463,6 +1526,35 @@ int make_plan(int batch, int64_t m, int64_t n, int want_u, int want_vv, Plan& p)
         p.rows_per_wg_f = (int)(ceil_div64(iters, want) * 128);
         p.nchunks_f = (int)ceil_div64(p.R_upd, p.rows_per_wg_f);
     }
+    {
+        // two-level dense sweeps: default for >= 8 panels under the XOR ordering (ASVD_TWOLEVEL=0 restores the single-level sweep)
+        const char* e2 = getenv("ASVD_TWOLEVEL");
+        p.ns = p.nb / 2;
+        int pw2 = 2;
+        while (pw2 < p.ns) pw2 <<= 1;
+        p.npairs_s = pw2 / 2;
+        p.two = (pair_order_xor() && p.nb >= 8 && !p.fused && !(e2 && atoi(e2) == 0)) ? 1 : 0;
+        const int launch_batch = (int)ceil_div64(batch, stream_groups_for(batch));
+        // sgram: 2 workgroups (64 KiB LDS each) per CU -> 512 slots; same cost model as the single-level Gram
+        const int64_t nchunk_total = p.m_pad / 32;
+        int64_t best_ns = 1;
+        double best_cost = 1e300;
+        for (int64_t ns = 1; ns <= nchunk_total && ns <= 64; ++ns) {
+            const int64_t wgs = ns * p.npairs_s * launch_batch;
+            const int64_t rounds = ceil_div64(wgs, 512);
+            const int64_t chunks_wave = ceil_div64(ceil_div64(nchunk_total, ns), 4);
+            const double cost = (double)rounds * ((double)chunks_wave + 1.5) + 0.02 * ns;
+            if (cost < best_cost) { best_cost = cost; best_ns = ns; }
+        }
+        p.rows_per_split_s = (int)(ceil_div64(nchunk_total, best_ns) * 32);
+        p.nsplit_s = (int)ceil_div64(p.m_pad, p.rows_per_split_s);
+        // supdate: 32-row tiles; aim for >= 1024 workgroups per launch and >= 4 tiles per workgroup
+        const int64_t tiles = ceil_div64(p.R_upd, 32);
+        int64_t wantc = ceil_div64(1024, (int64_t)p.npairs_s * launch_batch);
+        int64_t nc = std::max<int64_t>(1, std::min<int64_t>(wantc, ceil_div64(tiles, 4)));
+        p.rows_per_wg_s = (int)(ceil_div64(tiles, nc) * 32);
+        p.nchunks_s = (int)ceil_div64(p.R_upd, p.rows_per_wg_s);
+    }
     p.panel_stride = (int64_t)p.R * PB;
     p.batch_stride = p.panel_stride * p.nb;
     size_t off = 0;
@@ -1479,6 +1571,15 @@ int make_plan(int batch, int64_t m, int64_t n, int want_u, int want_vv, Plan& p)
     p.off_flags = take((size_t)batch * 4 * sizeof(int));  // [maxoff bits | nrot | done | pad] x batch (SoA)
     p.off_pflag = take((size_t)batch * p.nb * p.nb);      // sparse-sweep pair marks
     p.off_plist = take((size_t)batch * p.nb * p.nb * sizeof(int));  // per-step lists of marked pairs (bound: steps x nb/2 slots per problem)
+    const size_t t2 = p.two ? 1 : 0;
+    p.off_gd = take(t2 * batch * p.ns * SW * SW * sizeof(float));
+    p.off_gx = take(t2 * batch * p.npairs_s * p.nsplit_s * SW * SW * sizeof(float));
+    p.off_g128 = take(t2 * batch * p.npairs_s * SP * SP * sizeof(float));
+    p.off_qacc = take(t2 * batch * p.npairs_s * SP * SP * sizeof(float));
+    p.off_qfin = take(t2 * batch * p.npairs_s * SP * SP * sizeof(float));
+    p.off_qsub = take(t2 * batch * p.npairs_s * 2 * SW * SW * sizeof(float));
+    p.off_subact = take(t2 * batch * p.npairs_s * 4 * sizeof(int));
+    p.off_active_s = take(t2 * batch * p.npairs_s * sizeof(int));
     p.total = off;
     return ASVD_OK;
 }
@@ -1775,13 +1876,17 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
             }
         }
         const int gstride = std::max(p.nsplit, p.fused ? p.nchunks_f : 0);  // partial-Gram slots per pair in the buffer
-        const int nsched = sparse ? nsteps : (int)sched.size();
+        // two-level dense sweep: only the internal step d = 1 runs through the single-level kernels (it also refreshes the carried
+        // diagonal blocks); the super-steps follow below
+        const bool two_now = p.two && !sparse;
+        const int nsched = sparse ? nsteps : (two_now ? 1 : (int)sched.size());
         for (int si = 0; si < nsched; ++si) {
-            const int step = sparse ? si : sched[si];
+            const int step = sparse ? si : (two_now ? 0 : sched[si]);
             for (int g = 0; g < ngroups; ++g) {
                 const int b0 = gb0[g], nbg = gnb[g];
                 hipStream_t s2 = gst[g];
                 float* Xg = X + (int64_t)b0 * p.batch_stride;
+                float* Gdg = (float*)(wb + p.off_gd) + (int64_t)b0 * p.ns * SW * SW;
                 float* Gg = Gpart + (int64_t)b0 * p.npairs * gstride * 3072;
                 float* Qg = Qbuf + (int64_t)b0 * p.npairs * PW * PW;
                 int* ag = active + (int64_t)b0 * p.npairs;
@@ -1810,7 +1915,7 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
                     {
                         ProfScope ps(2, s2);
                         evd_kernel<<<dim3(slots, nbg), 256, 0, s2>>>(Gg, nsp, Qg, ag, maxoff + b0, nrot + b0, done + b0, tol, inner_sweeps,
-                                                                     p.nb, step, kb, hist_dev, pl, slots);
+                                                                     p.nb, step, kb, hist_dev, pl, slots, EvdTwoLevel{nullptr, 0, 0, nullptr, nullptr});
                     }
                     {
                         ProfScope ps(3, s2);
@@ -1829,7 +1934,8 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
                 {
                     ProfScope ps(2, s2);
                     evd_kernel<<<dim3(p.npairs, nbg), 256, 0, s2>>>(Gg, ns_here, Qg, ag, maxoff + b0, nrot + b0, done + b0, tol,
-                                                                     inner_sweeps, p.nb, step, kb, hist_dev, nullptr, 0);
+                                                                     inner_sweeps, p.nb, step, kb, hist_dev, nullptr, 0,
+                                                                     EvdTwoLevel{nullptr, 0, p.ns, nullptr, (two_now && step == 0) ? Gdg : nullptr});
                 }
                 {
                     ProfScope ps(3, s2);
@@ -1841,6 +1947,53 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
                     } else {
                         update_kernel<<<dim3(p.nchunks, p.npairs, nbg), 256, 0, s2>>>(Xg, p.panel_stride, p.batch_stride, p.nb, step,
                                                                                       p.R_upd, p.rows_per_wg, Qg, ag, done + b0, nullptr, 0);
+                    }
+                }
+            }
+        }
+        if (two_now) {
+            const int nsuper = 2 * p.npairs_s - 1;
+            const bool split_bf16 = getenv("ASVD_SPLIT") && atoi(getenv("ASVD_SPLIT")) == 1;
+            // local super-levels D = 1..L run twice at the start of the sweep (the two-level form of ASVD_DUP; ASVD_DUP2=L)
+            const int dup2 = std::min(nsuper, getenv("ASVD_DUP2") ? atoi(getenv("ASVD_DUP2")) : 0);
+            for (int di = 0; di < nsuper + dup2; ++di) {
+                const int D = di < dup2 ? di + 1 : di - dup2 + 1;
+                for (int g = 0; g < ngroups; ++g) {
+                    const int b0 = gb0[g], nbg = gnb[g];
+                    hipStream_t s2 = gst[g];
+                    float* Xg = X + (int64_t)b0 * p.batch_stride;
+                    float* Gdg = (float*)(wb + p.off_gd) + (int64_t)b0 * p.ns * SW * SW;
+                    float* Gxg = (float*)(wb + p.off_gx) + (int64_t)b0 * p.npairs_s * p.nsplit_s * SW * SW;
+                    float* G128g = (float*)(wb + p.off_g128) + (int64_t)b0 * p.npairs_s * SP * SP;
+                    float* Qaccg = (float*)(wb + p.off_qacc) + (int64_t)b0 * p.npairs_s * SP * SP;
+                    float* Qfing = (float*)(wb + p.off_qfin) + (int64_t)b0 * p.npairs_s * SP * SP;
+                    float* Qsubg = (float*)(wb + p.off_qsub) + (int64_t)b0 * p.npairs_s * 2 * SW * SW;
+                    int* subg = (int*)(wb + p.off_subact) + (int64_t)b0 * p.npairs_s * 4;
+                    int* actsg = (int*)(wb + p.off_active_s) + (int64_t)b0 * p.npairs_s;
+                    {
+                        ProfScope ps(1, s2);
+                        sgram_kernel<<<dim3(p.nsplit_s, p.npairs_s, nbg), 256, 0, s2>>>(Xg, p.panel_stride, p.batch_stride, p.ns, D, p.m_pad,
+                                                                                       p.rows_per_split_s, Gxg, done + b0);
+                    }
+                    {
+                        ProfScope ps(2, s2);
+                        sassemble_kernel<<<dim3(p.npairs_s, nbg), 256, 0, s2>>>(Gxg, p.nsplit_s, Gdg, p.ns, D, G128g, done + b0);
+                        for (int t = 0; t < 2; ++t) {
+                            evd_kernel<<<dim3(2 * p.npairs_s, nbg), 256, 0, s2>>>(nullptr, 0, Qsubg, nullptr, maxoff + b0, nrot + b0, done + b0, tol,
+                                                                                 inner_sweeps, p.nb, D - 1, kb, hist_dev, nullptr, 0,
+                                                                                 EvdTwoLevel{G128g, t, p.ns, subg, nullptr});
+                            gupdate_kernel<<<dim3(6, p.npairs_s, nbg), 256, 0, s2>>>(G128g, Qaccg, Qsubg, subg, p.ns, D, t, t == 0 ? 1 : 0, done + b0);
+                        }
+                        sfinish_kernel<<<dim3(p.npairs_s, nbg), 256, 0, s2>>>(G128g, Qaccg, Qfing, Gdg, subg, actsg, p.ns, D, done + b0);
+                    }
+                    {
+                        ProfScope ps(3, s2);
+                        if (split_bf16)
+                            supdate_split_kernel<<<dim3(p.nchunks_s, p.npairs_s, nbg), 256, 0, s2>>>(Xg, p.panel_stride, p.batch_stride, p.ns, D,
+                                                                                                    p.R_upd, p.rows_per_wg_s, Qfing, actsg, done + b0);
+                        else
+                            supdate_kernel<<<dim3(p.nchunks_s, p.npairs_s, nbg), 256, 0, s2>>>(Xg, p.panel_stride, p.batch_stride, p.ns, D, p.R_upd,
+                                                                                              p.rows_per_wg_s, Qfing, actsg, done + b0);
                     }
                 }
             }

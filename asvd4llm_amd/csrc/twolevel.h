@@ -1,0 +1,470 @@
+// twolevel.h — kernels of the TWO-LEVEL dense sweep (included by svd_jacobi.hip inside its anonymous namespace, after rr_pair).
+//
+// Why: at panel width 32 a sweep moves (nb-1) x 3 panel passes through HBM and sits on the roofline ridge.  The
+// two-level sweep works on SUPER-PANELS of 64 columns (two adjacent 32-column panels, layout unchanged) under the same XOR
+// schedule, now over ns = nb/2 super-panels.  Per super-pair (S, T) and step:
+//   sgram     one pass over the four panels: the 64x64 CROSS block X_S^T X_T only (fp32 MFMA, row-split partials).  The two
+//             diagonal blocks are CARRIED: every solve leaves G' = Q^T G Q behind, whose diagonal blocks are the Gram blocks of the
+//             updated super-panels; they are refreshed from the data once per sweep (internal step, below).
+//   sassemble G (128x128) = [carried G_SS, cross; cross^T, carried G_TT]
+//   2 inner steps on G alone (no pass over X): 64x64 eigen-solves (evd_kernel, inner mode) of the sub-pairs (S0,T0),(S1,T1) then
+//             (S0,T1),(S1,T0), each followed by gupdate: G <- Q^T G Q, Qacc <- Qacc Q (fp32 MFMA, a few MFLOP)
+//   sfinish   sort the 128 columns by decreasing diagonal (large columns migrate to the lower super-panel), renormalise Qacc's
+//             columns (fp64 norms), store Qfin and the two new carried diagonal blocks
+//   supdate   one pass: [X_S X_T] <- [X_S X_T] Qfin   (128x128, fp32 MFMA, K = 128)
+// The pairs INSIDE a super-panel (2S, 2S+1) are the d = 1 step of the single-level schedule: it runs first in every sweep with the
+// single-level kernels (full 3-block Gram from the data) and its eigen-solve emits the fresh carried block of every super-panel.
+// HBM passes per sweep: 3 (nb/2 - 1) + 3 instead of 3 (nb - 1); MFMA flops 5 R n^2 instead of 7 R n^2 (one cross block per pair
+// instead of three); the number of 64x64 eigen-solves is unchanged (every 32-panel pair still meets exactly once per sweep).
+// CPU prototype (tools/proto_two_level.py, n = 1024): same sweep count as the single-level schedule, slightly ahead per sweep.
+
+constexpr int SW = 64;       // super-panel width
+constexpr int SP = 2 * SW;   // super-pair width
+
+// inner step t, sub-pair sp -> the two 32-blocks (a in {0,1} = S0,S1;  b in {2,3} = T0,T1):  t = 0: (0,2),(1,3);  t = 1: (0,3),(1,2)
+__device__ __forceinline__ void sub_blocks(int t, int sp, int& a, int& b) { a = sp; b = 2 + (sp ^ t); }
+
+// --------------------------------------------------------------------------------------------------
+// sgram: partial cross Gram of a super-pair, Gx[split] (64x64 row-major) = X_S[rows]^T X_T[rows].  Same streaming structure as
+// gram_kernel (register prefetch of the next 32-row chunk, wave-private LDS image, one ds_read_b32 per MFMA operand); four panels
+// and four accumulators per wave.
+__global__ __launch_bounds__(256) void sgram_kernel(const float* __restrict__ X, int64_t panel_stride, int64_t batch_stride, int ns, int D,
+                                                    int m_pad, int rows_per_split, float* __restrict__ Gx, const int* __restrict__ done) {
+    const int split = blockIdx.x, pair = blockIdx.y, b = blockIdx.z;
+    const int nsplit = gridDim.x, npairs = gridDim.y;
+    if (done[b]) return;
+    int S, T;
+    rr_pair(ns, D - 1, pair, S, T);
+    if (T >= ns) return;
+    const float* __restrict__ Xb = X + (int64_t)b * batch_stride;
+    const float* __restrict__ P0 = Xb + (int64_t)(2 * S) * panel_stride;
+    const float* __restrict__ P1 = Xb + (int64_t)(2 * S + 1) * panel_stride;
+    const float* __restrict__ P2 = Xb + (int64_t)(2 * T) * panel_stride;
+    const float* __restrict__ P3 = Xb + (int64_t)(2 * T + 1) * panel_stride;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r_begin = split * rows_per_split;
+    const int r_end = min(r_begin + rows_per_split, m_pad);
+    const int nchunks = (r_end - r_begin) / GCH;
+
+    __shared__ __attribute__((aligned(16))) float stage[4][4 * GCH * PB];  // per wave: 32 rows of the four panels (16 KiB)
+    float* s = stage[w];
+    f32x16 a00 = {0}, a01 = {0}, a10 = {0}, a11 = {0};
+    {
+        f32x4 p0[GCH / 8], p1[GCH / 8], p2[GCH / 8], p3[GCH / 8];
+        auto fetch = [&](int ch) {
+            const int64_t r0 = r_begin + (int64_t)ch * GCH;
+#pragma unroll
+            for (int it = 0; it < GCH / 8; ++it) {
+                const int64_t o = (r0 + it * 8) * PB + lane * 4;
+                p0[it] = *(const f32x4*)(P0 + o);
+                p1[it] = *(const f32x4*)(P1 + o);
+                p2[it] = *(const f32x4*)(P2 + o);
+                p3[it] = *(const f32x4*)(P3 + o);
+            }
+        };
+        if (w < nchunks) fetch(w);
+        for (int ch = w; ch < nchunks; ch += 4) {
+#pragma unroll
+            for (int it = 0; it < GCH / 8; ++it) {
+                *(f32x4*)(s + 0 * 1024 + it * 256 + lane * 4) = p0[it];
+                *(f32x4*)(s + 1 * 1024 + it * 256 + lane * 4) = p1[it];
+                *(f32x4*)(s + 2 * 1024 + it * 256 + lane * 4) = p2[it];
+                *(f32x4*)(s + 3 * 1024 + it * 256 + lane * 4) = p3[it];
+            }
+            if (ch + 4 < nchunks) fetch(ch + 4);
+#pragma unroll
+            for (int u = 0; u < GCH / 2; ++u) {
+                const float x0 = s[0 * 1024 + u * 64 + lane], x1 = s[1 * 1024 + u * 64 + lane];
+                const float y0 = s[2 * 1024 + u * 64 + lane], y1 = s[3 * 1024 + u * 64 + lane];
+                a00 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, y0, a00, 0, 0, 0);
+                a01 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, y1, a01, 0, 0, 0);
+                a10 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, y0, a10, 0, 0, 0);
+                a11 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, y1, a11, 0, 0, 0);
+            }
+        }
+    }
+    // cross-wave reduction in a fixed order ((w0 + w2) + (w1 + w3)) through the staging memory (4 x 16 KiB), coalesced store
+    __syncthreads();
+    float* red = &stage[0][0];
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        red[w * 4096 + (0 * 16 + reg) * 64 + lane] = a00[reg];
+        red[w * 4096 + (1 * 16 + reg) * 64 + lane] = a01[reg];
+        red[w * 4096 + (2 * 16 + reg) * 64 + lane] = a10[reg];
+        red[w * 4096 + (3 * 16 + reg) * 64 + lane] = a11[reg];
+    }
+    __syncthreads();
+    float* __restrict__ out = Gx + (((int64_t)b * npairs + pair) * nsplit + split) * (SW * SW);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int p = tid + 256 * q;
+        const float v = (red[p] + red[2 * 4096 + p]) + (red[4096 + p] + red[3 * 4096 + p]);
+        const int rg = p >> 6, ln = p & 63;
+        const int tile = rg >> 4, reg = rg & 15;
+        const int i = (reg & 3) + 8 * (reg >> 2) + 4 * (ln >> 5), j = ln & 31;
+        out[(32 * (tile >> 1) + i) * SW + 32 * (tile & 1) + j] = v;
+    }
+}
+
+// sassemble: G (128x128, row-major) of every super-pair of the step from the carried diagonal blocks and the summed cross partials
+__global__ __launch_bounds__(256) void sassemble_kernel(const float* __restrict__ Gx, int nsplit, const float* __restrict__ Gd, int ns, int D,
+                                                        float* __restrict__ G128, const int* __restrict__ done) {
+    const int pair = blockIdx.x, b = blockIdx.y, npairs = gridDim.x, tid = threadIdx.x;
+    if (done[b]) return;
+    int S, T;
+    rr_pair(ns, D - 1, pair, S, T);
+    if (T >= ns) return;
+    __shared__ float xt[SW][SW + 1];
+    const float* __restrict__ gx = Gx + ((int64_t)b * npairs + pair) * nsplit * (SW * SW);
+    float* __restrict__ G = G128 + ((int64_t)b * npairs + pair) * (SP * SP);
+    const float* __restrict__ dS = Gd + ((int64_t)b * ns + S) * (SW * SW);
+    const float* __restrict__ dT = Gd + ((int64_t)b * ns + T) * (SW * SW);
+#pragma unroll 4
+    for (int q = 0; q < 16; ++q) {
+        const int e = tid + 256 * q, r = e >> 6, c = e & 63;
+        float v = 0.0f;
+        for (int sp = 0; sp < nsplit; ++sp) v += gx[(int64_t)sp * (SW * SW) + e];
+        xt[r][c] = v;
+        G[r * SP + SW + c] = v;
+        G[r * SP + c] = dS[e];
+        G[(SW + r) * SP + SW + c] = dT[e];
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int q = 0; q < 16; ++q) {
+        const int e = tid + 256 * q, r = e >> 6, c = e & 63;
+        G[(SW + r) * SP + c] = xt[c][r];
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
+// gupdate: after the two eigen-solves of inner step t (Q_0, Q_1 of the sub-pairs), apply them to the 128x128 Gram matrix and to
+// the accumulated transformation.  grid.x = 6: x < 4 -> tile (px, py) of G: G[I_px, I_py] <- Q_px^T G[I_px, I_py] Q_py (gathered
+// 64x64, two 64^3 products, in place: a tile depends only on itself); x = 4, 5 -> Qacc[:, I_px] <- Qacc[:, I_px] Q_px (128x64;
+// `first`: Qacc is the identity and is written from scratch).  One 32x32 output block per wave, fp32 MFMA, operands from LDS.
+constexpr int GLD = 68;
+__global__ __launch_bounds__(256) void gupdate_kernel(float* __restrict__ G128, float* __restrict__ Qacc, const float* __restrict__ Qsub,
+                                                      const int* __restrict__ subact, int ns, int D, int inner_t, int first,
+                                                      const int* __restrict__ done) {
+    const int x = blockIdx.x, pair = blockIdx.y, b = blockIdx.z, npairs = gridDim.y;
+    if (done[b]) return;
+    int S, T;
+    rr_pair(ns, D - 1, pair, S, T);
+    if (T >= ns) return;
+    const int* sa = subact + ((int64_t)b * npairs + pair) * 4 + inner_t * 2;
+    const bool act[2] = {sa[0] != 0, sa[1] != 0};
+    __shared__ float M[SW * GLD], QX[SW * GLD], QY[SW * GLD], T1[SW * GLD];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, c = lane & 31;
+    const int wi = w >> 1, wj = w & 1;
+    const int64_t slot = (int64_t)b * npairs + pair;
+    if (x < 4) {
+        const int px = x >> 1, py = x & 1;
+        if (!act[px] && !act[py]) return;  // both factors are the identity
+        int ax, bx, ay, by;
+        sub_blocks(inner_t, px, ax, bx);
+        sub_blocks(inner_t, py, ay, by);
+        float* __restrict__ G = G128 + slot * (SP * SP);
+        const float* __restrict__ qx = Qsub + (slot * 2 + px) * (SW * SW);
+        const float* __restrict__ qy = Qsub + (slot * 2 + py) * (SW * SW);
+#pragma unroll 4
+        for (int q = 0; q < 16; ++q) {
+            const int e = tid + 256 * q, r = e >> 6, cc = e & 63;
+            const int gr = 32 * (r < 32 ? ax : bx) + (r & 31), gc = 32 * (cc < 32 ? ay : by) + (cc & 31);
+            M[r * GLD + cc] = G[gr * SP + gc];
+            QX[r * GLD + cc] = qx[e];
+            QY[r * GLD + cc] = qy[e];
+        }
+        __syncthreads();
+        f32x16 acc = {0};
+#pragma unroll 8
+        for (int k2 = 0; k2 < 32; ++k2) {
+            const int k = 2 * k2 + h;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(M[(32 * wi + c) * GLD + k], QY[k * GLD + 32 * wj + c], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int i = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            T1[(32 * wi + i) * GLD + 32 * wj + c] = acc[reg];
+        }
+        __syncthreads();
+        acc = (f32x16){0};
+#pragma unroll 8
+        for (int k2 = 0; k2 < 32; ++k2) {
+            const int k = 2 * k2 + h;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(QX[k * GLD + 32 * wi + c], T1[k * GLD + 32 * wj + c], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int i = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            const int r = 32 * wi + i, cc = 32 * wj + c;
+            const int gr = 32 * (r < 32 ? ax : bx) + (r & 31), gc = 32 * (cc < 32 ? ay : by) + (cc & 31);
+            G[gr * SP + gc] = acc[reg];
+        }
+    } else {
+        const int px = x - 4;
+        if (!act[px] && !first) return;
+        int ax, bx;
+        sub_blocks(inner_t, px, ax, bx);
+        float* __restrict__ Qa = Qacc + slot * (SP * SP);
+        const float* __restrict__ qx = Qsub + (slot * 2 + px) * (SW * SW);
+#pragma unroll 4
+        for (int q = 0; q < 16; ++q) {
+            const int e = tid + 256 * q, r = e >> 6, cc = e & 63;
+            QX[r * GLD + cc] = qx[e];
+        }
+        for (int rh = 0; rh < 2; ++rh) {
+            __syncthreads();  // QX loaded / previous half's M consumed
+#pragma unroll 4
+            for (int q = 0; q < 16; ++q) {
+                const int e = tid + 256 * q, r = e >> 6, cc = e & 63;
+                const int gc = 32 * (cc < 32 ? ax : bx) + (cc & 31);
+                M[r * GLD + cc] = first ? ((64 * rh + r == gc) ? 1.0f : 0.0f) : Qa[(64 * rh + r) * SP + gc];
+            }
+            __syncthreads();
+            f32x16 acc = {0};
+#pragma unroll 8
+            for (int k2 = 0; k2 < 32; ++k2) {
+                const int k = 2 * k2 + h;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(M[(32 * wi + c) * GLD + k], QX[k * GLD + 32 * wj + c], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int i = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                const int cc = 32 * wj + c;
+                const int gc = 32 * (cc < 32 ? ax : bx) + (cc & 31);
+                Qa[(64 * rh + 32 * wi + i) * SP + gc] = acc[reg];
+            }
+        }
+    }
+}
+
+// sfinish: sort by decreasing diagonal, renormalise the accumulated transformation, emit Qfin and the carried diagonal blocks
+__global__ __launch_bounds__(256) void sfinish_kernel(const float* __restrict__ G128, const float* __restrict__ Qacc, float* __restrict__ Qfin,
+                                                      float* __restrict__ Gd, const int* __restrict__ subact, int* __restrict__ active_s, int ns,
+                                                      int D, const int* __restrict__ done) {
+    const int pair = blockIdx.x, b = blockIdx.y, npairs = gridDim.x, tid = threadIdx.x;
+    if (done[b]) return;
+    int S, T;
+    rr_pair(ns, D - 1, pair, S, T);
+    const int64_t slot = (int64_t)b * npairs + pair;
+    if (T >= ns) { if (tid == 0) active_s[slot] = 0; return; }
+    const int* sa = subact + slot * 4;
+    if (!(sa[0] | sa[1] | sa[2] | sa[3])) { if (tid == 0) active_s[slot] = 0; return; }  // nothing rotated: X and the carried blocks stay
+    __shared__ float d[SP], cs[SP];
+    __shared__ int rnk[SP];
+    __shared__ double part[2][SP];
+    const float* __restrict__ G = G128 + slot * (SP * SP);
+    const float* __restrict__ Qa = Qacc + slot * (SP * SP);
+    if (tid < SP) d[tid] = G[tid * SP + tid];
+    {
+        const int col = tid & (SP - 1), half = tid >> 7;
+        double acc = 0.0;
+        for (int r = 0; r < 64; ++r) { const double v = Qa[(64 * half + r) * SP + col]; acc += v * v; }
+        part[half][col] = acc;
+    }
+    __syncthreads();
+    if (tid < SP) {
+        const double sq = part[0][tid] + part[1][tid];
+        cs[tid] = sq > 0.0 ? (float)(1.0 / sqrt(sq)) : 1.0f;
+        const float me = d[tid];
+        int cnt = 0;
+        for (int i = 0; i < SP; ++i) { const float o = d[i]; cnt += (o > me || (o == me && i < tid)) ? 1 : 0; }
+        rnk[tid] = cnt;
+    }
+    __syncthreads();
+    float* __restrict__ Qf = Qfin + slot * (SP * SP);
+    float* __restrict__ gS = Gd + ((int64_t)b * ns + S) * (SW * SW);
+    float* __restrict__ gT = Gd + ((int64_t)b * ns + T) * (SW * SW);
+    for (int q = 0; q < 64; ++q) {
+        const int e = tid + 256 * q, r = e >> 7, cc = e & 127;
+        const int rr = rnk[r], rc = rnk[cc];
+        Qf[r * SP + rc] = Qa[e] * cs[cc];
+        const float v = G[e] * cs[r] * cs[cc];
+        if (rr < SW && rc < SW) gS[rr * SW + rc] = v;
+        else if (rr >= SW && rc >= SW) gT[(rr - SW) * SW + rc - SW] = v;
+    }
+    if (tid == 0) active_s[slot] = 1;
+}
+
+// --------------------------------------------------------------------------------------------------
+// supdate: [X_S X_T] <- [X_S X_T] * Qfin over the rows of this chunk.  The 32 x 128 tile is shared by the four waves through a
+// double-buffered padded LDS image (next tile prefetched into registers while the current one is in the matrix pipe, one barrier
+// per tile); wave w owns output panel w: its 128 x 32 slice of Qfin sits in 64 VGPRs, 64 MFMAs per tile.
+constexpr int ULD = SP + 4;  // LDS row stride in floats (528 B: conflict-free b128 row-per-lane reads)
+__global__ __launch_bounds__(256, 2) void supdate_kernel(float* __restrict__ X, int64_t panel_stride, int64_t batch_stride, int ns, int D,
+                                                         int R, int rows_per_wg, const float* __restrict__ Qfin,
+                                                         const int* __restrict__ active_s, const int* __restrict__ done) {
+    const int chunk = blockIdx.x, pair = blockIdx.y, b = blockIdx.z, npairs = gridDim.y;
+    if (done[b] || !active_s[(int64_t)b * npairs + pair]) return;
+    int S, T;
+    rr_pair(ns, D - 1, pair, S, T);
+    if (T >= ns) return;
+    float* __restrict__ Xb = X + (int64_t)b * batch_stride;
+    float* __restrict__ P0 = Xb + (int64_t)(2 * S) * panel_stride;
+    float* __restrict__ P1 = Xb + (int64_t)(2 * S + 1) * panel_stride;
+    float* __restrict__ P2 = Xb + (int64_t)(2 * T) * panel_stride;
+    float* __restrict__ P3 = Xb + (int64_t)(2 * T + 1) * panel_stride;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, c = lane & 31;
+    const float* __restrict__ Qp = Qfin + ((int64_t)b * npairs + pair) * (SP * SP);
+    float q[64];
+#pragma unroll
+    for (int t = 0; t < 64; ++t) q[t] = Qp[(h * 64 + t) * SP + 32 * w + c];
+    float* __restrict__ Pw = (w == 0) ? P0 : (w == 1) ? P1 : (w == 2) ? P2 : P3;
+
+    __shared__ __attribute__((aligned(16))) float tile[2][32 * ULD];
+    const int r_begin = chunk * rows_per_wg;
+    const int r_end = min(r_begin + rows_per_wg, R);
+    if (r_begin >= r_end) return;
+    f32x4 pre0, pre1, pre2, pre3;
+    auto fetch = [&](int r0) {
+        const int64_t o = (int64_t)r0 * PB + tid * 4;
+        pre0 = *(const f32x4*)(P0 + o);
+        pre1 = *(const f32x4*)(P1 + o);
+        pre2 = *(const f32x4*)(P2 + o);
+        pre3 = *(const f32x4*)(P3 + o);
+    };
+    auto stash = [&](float* t) {
+        float* dst = t + (tid >> 3) * ULD + (tid & 7) * 4;
+        *(f32x4*)(dst + 0) = pre0;
+        *(f32x4*)(dst + 32) = pre1;
+        *(f32x4*)(dst + 64) = pre2;
+        *(f32x4*)(dst + 96) = pre3;
+    };
+    int cur = 0;
+    fetch(r_begin);
+    stash(tile[0]);
+    __syncthreads();
+    for (int r0 = r_begin; r0 < r_end; r0 += 32) {  // R and rows_per_wg are multiples of 32
+        const bool more = r0 + 32 < r_end;
+        if (more) fetch(r0 + 32);
+        const float* my = tile[cur] + c * ULD + h * 64;
+        f32x16 acc = {0};
+#pragma unroll
+        for (int t4 = 0; t4 < 16; ++t4) {
+            const f32x4 v = *(const f32x4*)(my + t4 * 4);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v[0], q[4 * t4 + 0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v[1], q[4 * t4 + 1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v[2], q[4 * t4 + 2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v[3], q[4 * t4 + 3], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int i = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            Pw[(int64_t)(r0 + i) * PB + c] = acc[reg];
+        }
+        if (more) stash(tile[cur ^ 1]);
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
+// supdate with split-bf16 arithmetic.  Every fp32 value is written EXACTLY as the sum of three bf16 numbers (truncation split:
+// 8 + 8 + 8 significant bits), x = x1 + x2 + x3, and the product X Q is evaluated on the bf16 matrix pipe as
+//   X1 Q1 + (X1 Q2 + X2 Q1) + (X2 Q2 + X1 Q3 + X3 Q1)           (the dropped terms are <= 2^-24 |x| |q|: fp32 rounding level)
+// with fp32 accumulation: 6 x 8 = 48 v_mfma_f32_32x32x16_bf16 (32 cycles each) per 32x128 tile and wave instead of 64
+// v_mfma_f32_32x32x2_f32 (64 cycles each): 2.7x less matrix-pipe time for the kernel that holds 4/5 of the sweep's flops.
+// Bitwise it is not the fp32 MFMA result (different summation tree), numerically it is equivalent (tests compare both with fp64).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split3(float x0, float x1, unsigned& p1, unsigned& p2, unsigned& p3) {
+    const unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
+    p1 = __builtin_amdgcn_perm(u1, u0, 0x07060302u);  // {hi16(x1) : hi16(x0)}
+    const float r0 = x0 - __uint_as_float(u0 & 0xffff0000u), r1 = x1 - __uint_as_float(u1 & 0xffff0000u);  // exact
+    const unsigned v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
+    p2 = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+    const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u), s1 = r1 - __uint_as_float(v1 & 0xffff0000u);  // exact, <= 8 bits left
+    p3 = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+}
+
+__global__ __launch_bounds__(256, 2) void supdate_split_kernel(float* __restrict__ X, int64_t panel_stride, int64_t batch_stride, int ns,
+                                                               int D, int R, int rows_per_wg, const float* __restrict__ Qfin,
+                                                               const int* __restrict__ active_s, const int* __restrict__ done) {
+    const int chunk = blockIdx.x, pair = blockIdx.y, b = blockIdx.z, npairs = gridDim.y;
+    if (done[b] || !active_s[(int64_t)b * npairs + pair]) return;
+    int S, T;
+    rr_pair(ns, D - 1, pair, S, T);
+    if (T >= ns) return;
+    float* __restrict__ Xb = X + (int64_t)b * batch_stride;
+    float* __restrict__ P0 = Xb + (int64_t)(2 * S) * panel_stride;
+    float* __restrict__ P1 = Xb + (int64_t)(2 * S + 1) * panel_stride;
+    float* __restrict__ P2 = Xb + (int64_t)(2 * T) * panel_stride;
+    float* __restrict__ P3 = Xb + (int64_t)(2 * T + 1) * panel_stride;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, c = lane & 31;
+    const float* __restrict__ Qp = Qfin + ((int64_t)b * npairs + pair) * (SP * SP);
+    // B operand of k-step s: lane (j = c, group h) holds Q[16 s + 8 h + e][32 w + c], e = 0..7, in three bf16 parts
+    u32x4 q1[8], q2[8], q3[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = Qp[(16 * s + 8 * h + e) * SP + 32 * w + c];
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2) {
+            unsigned a, bb, cc;
+            split3(v[2 * e2], v[2 * e2 + 1], a, bb, cc);
+            q1[s][e2] = a; q2[s][e2] = bb; q3[s][e2] = cc;
+        }
+    }
+    float* __restrict__ Pw = (w == 0) ? P0 : (w == 1) ? P1 : (w == 2) ? P2 : P3;
+
+    __shared__ __attribute__((aligned(16))) float tile[2][32 * ULD];
+    const int r_begin = chunk * rows_per_wg;
+    const int r_end = min(r_begin + rows_per_wg, R);
+    if (r_begin >= r_end) return;
+    f32x4 pre0, pre1, pre2, pre3;
+    auto fetch = [&](int r0) {
+        const int64_t o = (int64_t)r0 * PB + tid * 4;
+        pre0 = *(const f32x4*)(P0 + o);
+        pre1 = *(const f32x4*)(P1 + o);
+        pre2 = *(const f32x4*)(P2 + o);
+        pre3 = *(const f32x4*)(P3 + o);
+    };
+    auto stash = [&](float* t) {
+        float* dst = t + (tid >> 3) * ULD + (tid & 7) * 4;
+        *(f32x4*)(dst + 0) = pre0;
+        *(f32x4*)(dst + 32) = pre1;
+        *(f32x4*)(dst + 64) = pre2;
+        *(f32x4*)(dst + 96) = pre3;
+    };
+    int cur = 0;
+    fetch(r_begin);
+    stash(tile[0]);
+    __syncthreads();
+    for (int r0 = r_begin; r0 < r_end; r0 += 32) {
+        const bool more = r0 + 32 < r_end;
+        if (more) fetch(r0 + 32);
+        const float* my = tile[cur] + c * ULD + 8 * h;
+        f32x16 accA = {0}, accB = {0};  // leading term / correction terms
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const f32x4 v0 = *(const f32x4*)(my + 16 * s);
+            const f32x4 v1 = *(const f32x4*)(my + 16 * s + 4);
+            u32x4 a1, a2, a3;
+            {
+                unsigned x, y, z;
+                split3(v0[0], v0[1], x, y, z); a1[0] = x; a2[0] = y; a3[0] = z;
+                split3(v0[2], v0[3], x, y, z); a1[1] = x; a2[1] = y; a3[1] = z;
+                split3(v1[0], v1[1], x, y, z); a1[2] = x; a2[2] = y; a3[2] = z;
+                split3(v1[2], v1[3], x, y, z); a1[3] = x; a2[3] = y; a3[3] = z;
+            }
+            const bf16x8 A1 = __builtin_bit_cast(bf16x8, a1), A2 = __builtin_bit_cast(bf16x8, a2), A3 = __builtin_bit_cast(bf16x8, a3);
+            const bf16x8 B1 = __builtin_bit_cast(bf16x8, q1[s]), B2 = __builtin_bit_cast(bf16x8, q2[s]), B3 = __builtin_bit_cast(bf16x8, q3[s]);
+            accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B1, accA, 0, 0, 0);
+            accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B2, accB, 0, 0, 0);
+            accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, B1, accB, 0, 0, 0);
+            accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, B2, accB, 0, 0, 0);
+            accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B3, accB, 0, 0, 0);
+            accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A3, B1, accB, 0, 0, 0);
+        }
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int i = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            Pw[(int64_t)(r0 + i) * PB + c] = accA[reg] + accB[reg];
+        }
+        if (more) stash(tile[cur ^ 1]);
+        __syncthreads();
+        cur ^= 1;
+    }
+}
