@@ -278,13 +278,17 @@ struct EvdTwoLevel {
 };
 __device__ __forceinline__ void sub_blocks(int t, int sp, int& a, int& b);
 
+// KEEPG = 0: the eigenvector image re-uses G's LDS after the last phase (18 KiB per workgroup instead of 34: more eigen-solves
+// co-reside with the streaming kernels of the other stream groups); KEEPG = 1 keeps G for the carried-block output (tw.gd_out).
+template <int KEEPG>
 __global__ __launch_bounds__(256, 4) void evd_kernel(const float* __restrict__ Gpart, int nsplit, float* __restrict__ Qbuf,
                                                    int* __restrict__ active, unsigned* __restrict__ maxoff_bits,
                                                    int* __restrict__ nrot, const int* __restrict__ done, float tol,
                                                    int inner_sweeps, int nb, int step, int kb, int* __restrict__ hist,
                                                    const int* __restrict__ plist, int list_stride, EvdTwoLevel tw) {
     __shared__ float G[PW * PW];
-    __shared__ float Q[PW * PW];
+    __shared__ float Qs[KEEPG ? PW * PW : 1];
+    float* Q = KEEPG ? Qs : G;
     __shared__ float sdiag[2][PW];
     __shared__ float sb[2][32];
     __shared__ float redmax[4];
@@ -686,6 +690,7 @@ __device__ __forceinline__ float nanmax(float a, float b) { return (b != b) ? b 
 // grid (ceil(nb/4), ceil(nb/4), batch); upper-triangular tiles only.  Wave w owns panel J = 4*jg + w against panels I = 4*ig + a.
 // 32-row chunks of the eight panels are staged in LDS (coalesced 16-B loads, next chunk prefetched into registers while the
 // current one is in the matrix pipe); every wave reads its operands from LDS as conflict-free 256-B rows.
+template <int SPLIT>
 __global__ __launch_bounds__(256) void fullcheck_kernel(const float* __restrict__ X, int64_t panel_stride, int64_t batch_stride, int nb,
                                                         int m_pad, int n_pad, const float* __restrict__ dn, float tol, int kb,
                                                         unsigned char* __restrict__ pflag, unsigned* __restrict__ maxoff_bits,
@@ -721,11 +726,45 @@ __global__ __launch_bounds__(256) void fullcheck_kernel(const float* __restrict_
         for (int q = 0; q < 8; ++q) *(f32x4*)(&stage[q][tid * 4]) = pre[q];
         __syncthreads();
         if (r0 + 32 < m_pad) fetch(r0 + 32);
+        if constexpr (SPLIT) {
+            // split-bf16 (twolevel.h): each fp32 operand = three bf16 exactly, six products per fp32 product on the bf16 matrix pipe
+            // (2.7x less pipe time; the dropped terms are at fp32 rounding level, which a coupling test against tol = 1e-6 needs).
+            // Operand of k-step ks: lane (i = c, group h) holds rows 16 ks + 8 h + e, e = 0..7, of column c of its panel.
+            const int hh = lane >> 5, cc = lane & 31;
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const float bf = stage[4 + w][u * 64 + lane];
+            for (int ks = 0; ks < 2; ++ks) {
+                auto operand = [&](const float* pnl, bf16x8& o1, bf16x8& o2, bf16x8& o3) {
+                    const float* src = pnl + (16 * ks + 8 * hh) * PB + cc;
+                    u32x4 p1, p2, p3;
 #pragma unroll
-            for (int a = 0; a < 4; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(stage[a][u * 64 + lane], bf, acc[a], 0, 0, 0);
+                    for (int e2 = 0; e2 < 4; ++e2) {
+                        unsigned x, y, z;
+                        split3(src[(2 * e2) * PB], src[(2 * e2 + 1) * PB], x, y, z);
+                        p1[e2] = x; p2[e2] = y; p3[e2] = z;
+                    }
+                    o1 = __builtin_bit_cast(bf16x8, p1); o2 = __builtin_bit_cast(bf16x8, p2); o3 = __builtin_bit_cast(bf16x8, p3);
+                };
+                bf16x8 B1, B2, B3;
+                operand(stage[4 + w], B1, B2, B3);
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    bf16x8 A1, A2, A3;
+                    operand(stage[a], A1, A2, A3);
+                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A3, B1, acc[a], 0, 0, 0);
+                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B3, acc[a], 0, 0, 0);
+                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, B2, acc[a], 0, 0, 0);
+                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, B1, acc[a], 0, 0, 0);
+                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B2, acc[a], 0, 0, 0);
+                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B1, acc[a], 0, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const float bf = stage[4 + w][u * 64 + lane];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(stage[a][u * 64 + lane], bf, acc[a], 0, 0, 0);
+            }
         }
     }
     if (J >= nb) return;
@@ -1535,14 +1574,14 @@ int make_plan(int batch, int64_t m, int64_t n, int want_u, int want_vv, Plan& p)
         p.npairs_s = pw2 / 2;
         p.two = (pair_order_xor() && p.nb >= 8 && !p.fused && !(e2 && atoi(e2) == 0)) ? 1 : 0;
         const int launch_batch = (int)ceil_div64(batch, stream_groups_for(batch));
-        // sgram: 2 workgroups (64 KiB LDS each) per CU -> 512 slots; same cost model as the single-level Gram
+        // sgram: 4 workgroups (32 KiB LDS, 112 VGPRs) per CU -> 1024 slots; 16-row chunks, same cost model as the single-level Gram
         const int64_t nchunk_total = p.m_pad / 32;
         int64_t best_ns = 1;
         double best_cost = 1e300;
         for (int64_t ns = 1; ns <= nchunk_total && ns <= 64; ++ns) {
             const int64_t wgs = ns * p.npairs_s * launch_batch;
-            const int64_t rounds = ceil_div64(wgs, 512);
-            const int64_t chunks_wave = ceil_div64(ceil_div64(nchunk_total, ns), 4);
+            const int64_t rounds = ceil_div64(wgs, 1024);
+            const int64_t chunks_wave = ceil_div64(2 * ceil_div64(nchunk_total, ns), 4);
             const double cost = (double)rounds * ((double)chunks_wave + 1.5) + 0.02 * ns;
             if (cost < best_cost) { best_cost = cost; best_ns = ns; }
         }
@@ -1808,6 +1847,7 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
     const bool sparse_allowed = pair_order_xor() && p.nb >= 8 && !(getenv("ASVD_SPARSE") && atoi(getenv("ASVD_SPARSE")) == 0);
     const double sparse_frac = getenv("ASVD_SPARSE_FRAC") ? atof(getenv("ASVD_SPARSE_FRAC")) : 0.5;
     bool sparse = false;
+    const bool split_check = getenv("ASVD_SPLIT") && atoi(getenv("ASVD_SPLIT")) == 1;
     std::vector<unsigned char> hflag;
     std::vector<int> hlist;
     std::vector<int> sl_off((size_t)MAXG * (nsteps > 0 ? nsteps : 1), 0), sl_cnt((size_t)MAXG * (nsteps > 0 ? nsteps : 1), 0);
@@ -1831,9 +1871,14 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
                 panel_sumsq_kernel<<<dim3(p.nb, nbg), 256, 0, gst[g]>>>(Xg, p.panel_stride, p.batch_stride, p.m_pad, p.n_pad,
                                                                         dnorm + (size_t)b0 * p.n_pad, done + b0);
                 const unsigned nt = (unsigned)ceil_div64(p.nb, 4);
-                fullcheck_kernel<<<dim3(nt, nt, nbg), 256, 0, gst[g]>>>(Xg, p.panel_stride, p.batch_stride, p.nb, p.m_pad, p.n_pad,
-                                                                        dnorm + (size_t)b0 * p.n_pad, tol, kb,
-                                                                        pflag + (size_t)b0 * p.nb * p.nb, maxoff + b0, done + b0);
+                if (split_check)
+                    fullcheck_kernel<1><<<dim3(nt, nt, nbg), 256, 0, gst[g]>>>(Xg, p.panel_stride, p.batch_stride, p.nb, p.m_pad, p.n_pad,
+                                                                               dnorm + (size_t)b0 * p.n_pad, tol, kb,
+                                                                               pflag + (size_t)b0 * p.nb * p.nb, maxoff + b0, done + b0);
+                else
+                    fullcheck_kernel<0><<<dim3(nt, nt, nbg), 256, 0, gst[g]>>>(Xg, p.panel_stride, p.batch_stride, p.nb, p.m_pad, p.n_pad,
+                                                                               dnorm + (size_t)b0 * p.n_pad, tol, kb,
+                                                                               pflag + (size_t)b0 * p.nb * p.nb, maxoff + b0, done + b0);
             }
             if (ngroups >= 2)
                 for (int g = 0; g < ngroups; ++g) {
@@ -1914,7 +1959,7 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
                     }
                     {
                         ProfScope ps(2, s2);
-                        evd_kernel<<<dim3(slots, nbg), 256, 0, s2>>>(Gg, nsp, Qg, ag, maxoff + b0, nrot + b0, done + b0, tol, inner_sweeps,
+                        evd_kernel<0><<<dim3(slots, nbg), 256, 0, s2>>>(Gg, nsp, Qg, ag, maxoff + b0, nrot + b0, done + b0, tol, inner_sweeps,
                                                                      p.nb, step, kb, hist_dev, pl, slots, EvdTwoLevel{nullptr, 0, 0, nullptr, nullptr});
                     }
                     {
@@ -1933,9 +1978,14 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
                 }
                 {
                     ProfScope ps(2, s2);
-                    evd_kernel<<<dim3(p.npairs, nbg), 256, 0, s2>>>(Gg, ns_here, Qg, ag, maxoff + b0, nrot + b0, done + b0, tol,
-                                                                     inner_sweeps, p.nb, step, kb, hist_dev, nullptr, 0,
-                                                                     EvdTwoLevel{nullptr, 0, p.ns, nullptr, (two_now && step == 0) ? Gdg : nullptr});
+                    if (two_now && step == 0)
+                        evd_kernel<1><<<dim3(p.npairs, nbg), 256, 0, s2>>>(Gg, ns_here, Qg, ag, maxoff + b0, nrot + b0, done + b0, tol,
+                                                                            inner_sweeps, p.nb, step, kb, hist_dev, nullptr, 0,
+                                                                            EvdTwoLevel{nullptr, 0, p.ns, nullptr, Gdg});
+                    else
+                        evd_kernel<0><<<dim3(p.npairs, nbg), 256, 0, s2>>>(Gg, ns_here, Qg, ag, maxoff + b0, nrot + b0, done + b0, tol,
+                                                                            inner_sweeps, p.nb, step, kb, hist_dev, nullptr, 0,
+                                                                            EvdTwoLevel{nullptr, 0, p.ns, nullptr, nullptr});
                 }
                 {
                     ProfScope ps(3, s2);
@@ -1979,7 +2029,7 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
                         ProfScope ps(2, s2);
                         sassemble_kernel<<<dim3(p.npairs_s, nbg), 256, 0, s2>>>(Gxg, p.nsplit_s, Gdg, p.ns, D, G128g, done + b0);
                         for (int t = 0; t < 2; ++t) {
-                            evd_kernel<<<dim3(2 * p.npairs_s, nbg), 256, 0, s2>>>(nullptr, 0, Qsubg, nullptr, maxoff + b0, nrot + b0, done + b0, tol,
+                            evd_kernel<0><<<dim3(2 * p.npairs_s, nbg), 256, 0, s2>>>(nullptr, 0, Qsubg, nullptr, maxoff + b0, nrot + b0, done + b0, tol,
                                                                                  inner_sweeps, p.nb, D - 1, kb, hist_dev, nullptr, 0,
                                                                                  EvdTwoLevel{G128g, t, p.ns, subg, nullptr});
                             gupdate_kernel<<<dim3(6, p.npairs_s, nbg), 256, 0, s2>>>(G128g, Qaccg, Qsubg, subg, p.ns, D, t, t == 0 ? 1 : 0, done + b0);

@@ -44,17 +44,19 @@ __global__ __launch_bounds__(256) void sgram_kernel(const float* __restrict__ X,
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int r_begin = split * rows_per_split;
     const int r_end = min(r_begin + rows_per_split, m_pad);
-    const int nchunks = (r_end - r_begin) / GCH;
+    constexpr int SCH = 16;  // rows per staged chunk: 8 KiB per wave, 32 KiB per workgroup (co-residency with the eigen-solves matters
+                             // more than a deeper per-wave pipeline: several workgroups per CU hide the latency)
+    const int nchunks = (r_end - r_begin) / SCH;  // m_pad and rows_per_split are multiples of 32
 
-    __shared__ __attribute__((aligned(16))) float stage[4][4 * GCH * PB];  // per wave: 32 rows of the four panels (16 KiB)
+    __shared__ __attribute__((aligned(16))) float stage[4][4 * SCH * PB];  // per wave: 16 rows of the four panels
     float* s = stage[w];
     f32x16 a00 = {0}, a01 = {0}, a10 = {0}, a11 = {0};
     {
-        f32x4 p0[GCH / 8], p1[GCH / 8], p2[GCH / 8], p3[GCH / 8];
+        f32x4 p0[SCH / 8], p1[SCH / 8], p2[SCH / 8], p3[SCH / 8];
         auto fetch = [&](int ch) {
-            const int64_t r0 = r_begin + (int64_t)ch * GCH;
+            const int64_t r0 = r_begin + (int64_t)ch * SCH;
 #pragma unroll
-            for (int it = 0; it < GCH / 8; ++it) {
+            for (int it = 0; it < SCH / 8; ++it) {
                 const int64_t o = (r0 + it * 8) * PB + lane * 4;
                 p0[it] = *(const f32x4*)(P0 + o);
                 p1[it] = *(const f32x4*)(P1 + o);
@@ -65,17 +67,17 @@ __global__ __launch_bounds__(256) void sgram_kernel(const float* __restrict__ X,
         if (w < nchunks) fetch(w);
         for (int ch = w; ch < nchunks; ch += 4) {
 #pragma unroll
-            for (int it = 0; it < GCH / 8; ++it) {
-                *(f32x4*)(s + 0 * 1024 + it * 256 + lane * 4) = p0[it];
-                *(f32x4*)(s + 1 * 1024 + it * 256 + lane * 4) = p1[it];
-                *(f32x4*)(s + 2 * 1024 + it * 256 + lane * 4) = p2[it];
-                *(f32x4*)(s + 3 * 1024 + it * 256 + lane * 4) = p3[it];
+            for (int it = 0; it < SCH / 8; ++it) {
+                *(f32x4*)(s + 0 * (SCH * PB) + it * 256 + lane * 4) = p0[it];
+                *(f32x4*)(s + 1 * (SCH * PB) + it * 256 + lane * 4) = p1[it];
+                *(f32x4*)(s + 2 * (SCH * PB) + it * 256 + lane * 4) = p2[it];
+                *(f32x4*)(s + 3 * (SCH * PB) + it * 256 + lane * 4) = p3[it];
             }
             if (ch + 4 < nchunks) fetch(ch + 4);
 #pragma unroll
-            for (int u = 0; u < GCH / 2; ++u) {
-                const float x0 = s[0 * 1024 + u * 64 + lane], x1 = s[1 * 1024 + u * 64 + lane];
-                const float y0 = s[2 * 1024 + u * 64 + lane], y1 = s[3 * 1024 + u * 64 + lane];
+            for (int u = 0; u < SCH / 2; ++u) {
+                const float x0 = s[0 * (SCH * PB) + u * 64 + lane], x1 = s[1 * (SCH * PB) + u * 64 + lane];
+                const float y0 = s[2 * (SCH * PB) + u * 64 + lane], y1 = s[3 * (SCH * PB) + u * 64 + lane];
                 a00 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, y0, a00, 0, 0, 0);
                 a01 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, y1, a01, 0, 0, 0);
                 a10 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, y0, a10, 0, 0, 0);
@@ -83,26 +85,28 @@ __global__ __launch_bounds__(256) void sgram_kernel(const float* __restrict__ X,
             }
         }
     }
-    // cross-wave reduction in a fixed order ((w0 + w2) + (w1 + w3)) through the staging memory (4 x 16 KiB), coalesced store
-    __syncthreads();
+    // cross-wave reduction in a fixed order ((w0 + w2) + (w1 + w3)) through the staging memory, two 32x32 tiles per round
+    // (4 waves x 2 tiles x 4 KiB = 32 KiB), coalesced store
     float* red = &stage[0][0];
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-        red[w * 4096 + (0 * 16 + reg) * 64 + lane] = a00[reg];
-        red[w * 4096 + (1 * 16 + reg) * 64 + lane] = a01[reg];
-        red[w * 4096 + (2 * 16 + reg) * 64 + lane] = a10[reg];
-        red[w * 4096 + (3 * 16 + reg) * 64 + lane] = a11[reg];
-    }
-    __syncthreads();
     float* __restrict__ out = Gx + (((int64_t)b * npairs + pair) * nsplit + split) * (SW * SW);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int p = tid + 256 * q;
-        const float v = (red[p] + red[2 * 4096 + p]) + (red[4096 + p] + red[3 * 4096 + p]);
-        const int rg = p >> 6, ln = p & 63;
-        const int tile = rg >> 4, reg = rg & 15;
-        const int i = (reg & 3) + 8 * (reg >> 2) + 4 * (ln >> 5), j = ln & 31;
-        out[(32 * (tile >> 1) + i) * SW + 32 * (tile & 1) + j] = v;
+    for (int half = 0; half < 2; ++half) {
+        __syncthreads();
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            red[w * 2048 + (0 * 16 + reg) * 64 + lane] = half ? a10[reg] : a00[reg];
+            red[w * 2048 + (1 * 16 + reg) * 64 + lane] = half ? a11[reg] : a01[reg];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int p = tid + 256 * q;
+            const float v = (red[p] + red[2 * 2048 + p]) + (red[2048 + p] + red[3 * 2048 + p]);
+            const int rg = p >> 6, ln = p & 63;
+            const int tile = 2 * half + (rg >> 4), reg = rg & 15;
+            const int i = (reg & 3) + 8 * (reg >> 2) + 4 * (ln >> 5), j = ln & 31;
+            out[(32 * (tile >> 1) + i) * SW + 32 * (tile & 1) + j] = v;
+        }
     }
 }
 

@@ -203,3 +203,70 @@ def test_fused_update_gram_path_matches_default(gpu):
         assert ib[b].status == 0
         ref = torch.linalg.svdvals(m.cpu().double())
         assert ((Sb[b].cpu().double() - ref).abs().max() / ref[0]).item() <= 1e-5
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Parity at the sizes of BASELINE.json's model configs (Llama-2-13B layer shapes, the lm_head shapes).  The oracle's FULL SVD at
+# these sizes costs minutes of CPU, so the checks are: sigma top-r against CPU `svdvals` (the contract's 1e-4), plus size-
+# independent properties that pin the vectors without oracle vectors — orthonormality of a column subsample, the triplet
+# residuals |Ws v_j - sigma_j u_j| and |Ws^T u_j - sigma_j v_j| on sampled triplets, and the Eckart-Young identity
+# |Ws - U_r S_r V_r^T|_F^2 = sum_{j>r} sigma_j^2 (a rank-r reconstruction with the optimal error IS the oracle's reconstruction
+# whenever sigma_r > sigma_{r+1}; the distance to it is bounded by the excess error).
+def check_svd_large(gpu, W, s, r, n_sample=192, seed=5):
+    from asvd4llm_amd import ops
+    Wd, sd = W.to(gpu), (None if s is None else s.to(gpu))
+    U, S, V, info = ops.svd(Wd, sd)
+    assert info.status == 0, info
+    Ws = O.scaled_weight(W, s)
+    So = torch.linalg.svdvals(Ws)  # CPU fp32 LAPACK, the oracle's spectrum
+    Sc = S.cpu()
+    assert bool((Sc[:-1] >= Sc[1:]).all())
+    assert O.sigma_rel_err(Sc, So, r) <= SIG_TOL
+    assert ((Sc.double() - So.double()).abs().max() / So[0].double()).item() <= SIG_TOL
+    g = torch.Generator().manual_seed(seed)
+    idx = torch.sort(torch.randperm(r, generator=g)[:min(n_sample, r)]).values.to(gpu)
+    Wsd = Ws.to(gpu).double()
+    Us, Vs, Ss = U[:, idx].double(), V[:, idx].double(), S[idx].double()
+    eye = torch.eye(idx.numel(), dtype=torch.float64, device=gpu)
+    assert (Us.T @ Us - eye).abs().max().item() <= 1e-3
+    assert (Vs.T @ Vs - eye).abs().max().item() <= 1e-3
+    s1 = S[0].double()
+    res_u = ((Wsd @ Vs - Us * Ss).norm(dim=0) / s1).max().item()
+    res_v = ((Wsd.T @ Us - Vs * Ss).norm(dim=0) / s1).max().item()
+    assert res_u <= 2e-5 and res_v <= 2e-5, (res_u, res_v)
+    # Eckart-Young: the rank-r error equals the discarded spectrum (fp64 on the device: plain torch matmul as the CHECKER)
+    Rg = (U[:, :r].double() * S[:r].double()) @ V[:, :r].double().T
+    err2 = ((Wsd - Rg) ** 2).sum().item()
+    tail2 = (So[r:].double() ** 2).sum().item()
+    tot2 = (So.double() ** 2).sum().item()
+    assert abs(err2 - tail2) <= (REC_TOL ** 2) * tot2, (err2, tail2, tot2)
+    return info
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("shape", [(5120, 5120), (13824, 5120), (5120, 13824)])
+def test_svd_llama13b_shapes(gpu, shape):
+    """Llama-2-13B q/k/v/o, gate/up and down shapes: 160 panels padded to a 256-wide XOR schedule (80 super-panels -> 128)."""
+    m, n = shape
+    W, s = llm_like(m, n, seed=13)
+    info = check_svd_large(gpu, W, s, O.rank_from_ratio(m, n, 0.9))
+    assert info.sweeps <= 20
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("shape", [(32000, 4096), (50272, 768)])
+def test_svd_lm_head_shapes(gpu, shape):
+    """lm_head of Llama-2-7B and of opt-125m (the reference hooks, sweeps and compresses lm_head too)."""
+    m, n = shape
+    W, s = llm_like(m, n, seed=17)
+    check_svd_large(gpu, W, s, O.rank_from_ratio(m, n, 0.9))
+
+
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize("shape", [(11008, 4096), (4096, 11008)])
+def test_svd_llama_mlp_shapes_full_vectors(gpu, shape):
+    """Llama-2-7B gate/up and down: full-vector parity against the oracle's own vectors (the tall path's long-side GEMM and the
+    row un-permutation run here), not just sigma."""
+    m, n = shape
+    W, s = llm_like(m, n, seed=29)
+    check_svd(gpu, W, s, O.rank_from_ratio(m, n, 0.9))

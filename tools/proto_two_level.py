@@ -54,13 +54,16 @@ def sweep_single(A, stats, dup=0):
                 pair_step(A, i, i ^ d, stats)
 
 
+NB = int(sys.argv[4]) if len(sys.argv) > 4 else 2  # panels per super-panel
+
+
 def super_pair(A, S, T, stats, full):
-    blocks = [2 * S, 2 * S + 1, 2 * T, 2 * T + 1]
+    blocks = [NB * S + i for i in range(NB)] + [NB * T + i for i in range(NB)]
     cols = np.concatenate([np.arange(b * B, (b + 1) * B) for b in blocks])
     Pn = A[:, cols]
     G = (Pn.T @ Pn).astype(np.float32)  # device: carried diagonal blocks + one cross-Gram pass
-    Qacc = np.eye(4 * B, dtype=np.float32)
-    steps = [[(0, 2), (1, 3)], [(0, 3), (1, 2)]]
+    Qacc = np.eye(2 * NB * B, dtype=np.float32)
+    steps = [[(a, NB + (a + t) % NB) for a in range(NB)] for t in range(NB)]
     if full:
         steps.append([(0, 1), (2, 3)])
     rotated = False
@@ -81,9 +84,11 @@ def super_pair(A, S, T, stats, full):
 
 
 def sweep_two(A, stats, full):
-    ps = nb // 2
-    for S in range(ps):  # internal pairs (the d = 1 step of the single-level schedule)
-        pair_step(A, 2 * S, 2 * S + 1, stats)
+    ps = nb // NB
+    for d in range(1, NB):  # internal pairs (the d < NB steps of the single-level schedule)
+        for i in range(nb):
+            if i < (i ^ d):
+                pair_step(A, i, i ^ d, stats)
     for D in range(1, ps):
         for S in range(ps):
             if S < (S ^ D):
