@@ -62,6 +62,19 @@ template <> struct elem<ASVD_BF16> {
 static inline size_t dtype_size(int dt) { return dt == ASVD_F32 ? 4 : 2; }
 static inline bool dtype_ok(int dt) { return dt == ASVD_F32 || dt == ASVD_F16 || dt == ASVD_BF16; }
 
+// ---- cache maintenance at kernel boundaries --------------------------------------------------------
+// The sweeps CAN run independent problem groups on several HIP streams at once (ASVD_GROUPS > 1; default 1 since round 2).
+// Measured on MI355X / ROCm 7.2: with kernels of OTHER streams in flight, data a kernel leaves in its XCD's L2 (small buffers that
+// are re-written every step: carried Gram blocks, 64x64 Q's, flags) was not reliably visible to the next kernel of the SAME stream
+// when that ran on another XCD — nondeterministic stale reads (the Jacobi iteration absorbs them as extra sweeps, which is how they
+// were found), never with a single stream.  With more than one stream group every kernel of the sweeps therefore starts with an
+// agent-scope acquire (invalidate this CU's L1) and ends with an agent-scope release (write back the XCD L2's dirty lines); either
+// fence alone was not enough.  The release costs a full L2 write-back per workgroup (the streaming kernels run 2x slower with
+// it), which is more than the 5-9 % the overlap of stream groups buys: one stream group, no fences, is the default.
+static __constant__ int c_fence = 0;
+#define ASVD_KERNEL_ACQUIRE() do { if (c_fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); } while (0)
+#define ASVD_KERNEL_RELEASE() do { if (c_fence) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); } while (0)
+
 // ---- wave / block reductions ---------------------------------------------------------------
 __device__ __forceinline__ float wave_reduce_max(float v) {
 #pragma unroll

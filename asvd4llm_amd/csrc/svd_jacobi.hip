@@ -137,6 +137,7 @@ __global__ __launch_bounds__(256) void gram_kernel(const float* __restrict__ X, 
                                                    const int* __restrict__ plist, int list_stride) {
     const int split = blockIdx.x, pair = blockIdx.y, b = blockIdx.z;
     const int nsplit = gridDim.x, npairs = gridDim.y;
+    ASVD_KERNEL_ACQUIRE();
     if (done[b]) return;
     int I, J;
     if (!get_pair(plist, list_stride, b, nb, step, pair, I, J)) return;
@@ -225,6 +226,7 @@ __global__ __launch_bounds__(256) void gram_kernel(const float* __restrict__ X, 
             out[2 * 1024 + i * 32 + c] = ajj[reg] + red[(32 + reg) * 64 + lane];
         }
     }
+    ASVD_KERNEL_RELEASE();
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -264,30 +266,51 @@ __device__ __forceinline__ int pcol(int c) { return ((c & 1) << 5) | (c >> 1); }
 // Thread (g, tx): column pair tx, row pairs 4g..4g+3 (4 blocks of G), rows 8g..8g+7 of Q's column pair tx.
 // Each lane computes the rotation of ITS column pair from a small side array (diagonal + pivot off-diagonals, ping-ponged);
 // the four row-pair rotations are the ones lanes 4g..4g+3 of the same half-wave just computed -> fetched with ds_bpermute.
-// Two-level extensions (twolevel.h):
-//   * inner mode (tw.G128 != nullptr): the workgroup solves sub-pair (slot & 1) of super-pair (slot >> 1) of super-step `step`
-//     (inner step tw.inner_t); the 64x64 matrix is gathered from the pair's 128x128 Gram matrix, Q is ALWAYS written (identity when
-//     nothing rotates: gupdate multiplies by it unconditionally) and the activity flag goes to tw.subact;
-//   * tw.gd_out != nullptr (single-level mode, the internal step d = 1): the transformed matrix Q^T G Q, sorted like Q's columns,
-//     is stored as the carried diagonal block of super-panel `pair`.
-struct EvdTwoLevel {
-    const float* G128;
-    int inner_t, ns;
-    int* subact;
-    float* gd_out;
+// Two-level sweeps (twolevel.h) run the same solver in two more modes; one workgroup per sub-pair of a super-pair (S, T) whose four
+// 32-blocks are numbered S0, S1, T0, T1 = 0..3:
+//   MODE 1 (inner step 0, sub-pairs (0,2) and (1,3)): the 64x64 matrix is assembled from the carried 32x32 diagonal blocks of the two
+//           panels (v3.Gd32) and the summed cross tile of sgram6; outputs Q0 (sorted, normalised; identity when nothing rotates), the
+//           two transformed diagonal blocks (v3.D0) and the activity flag;
+//   MODE 2 (inner step 1, sub-pairs (0,3) and (1,2)): the diagonal blocks come from D0, the cross block is the transformed tile
+//           Q0_a[:, :32]^T G[{0,2},{1,3}] Q0_b[:, 32:] (or its mirror), computed here with fp32 MFMA from sgram6's tiles; outputs the new
+//           carried diagonal blocks of both panels (Gd32) and this sub-pair's 128x64 column block of Qfin = Q^(0) Q^(1), the matrix
+//           supdate applies.  No 128x128 matrix is ever materialised and nothing else runs between the Gram pass and the update.
+//   MODE 0 is the single-level solve (Gram partials of gram_kernel); with v3.Gd32 set (internal step d = 1 of a two-level sweep) it
+//           also stores the two transformed diagonal blocks as the fresh carried blocks of its panels.
+// A solve that does not rotate (all couplings below tol) leaves everything in place: identity Q, no sort.
+struct EvdV3 {
+    int ns;               // super-panels per problem
+    int nbpan;            // 32-column panels per problem (stride of Gd32)
+    const float* Gx6;     // sgram6 partials [slot][nsplit][6][32*32]
+    int nsplit6;
+    float* Gd32;          // carried diagonal blocks [problem][panel][32*32]
+    float* Q0;            // [slot][2][64*64]
+    float* D0;            // [slot][4][32*32]
+    float* Qfin;          // [slot][128*128]
+    int* subact;          // [slot][4]: step 0 sub-pairs 0,1; step 1 sub-pairs 0,1
 };
-__device__ __forceinline__ void sub_blocks(int t, int sp, int& a, int& b);
 
-// KEEPG = 0: the eigenvector image re-uses G's LDS after the last phase (18 KiB per workgroup instead of 34: more eigen-solves
-// co-reside with the streaming kernels of the other stream groups); KEEPG = 1 keeps G for the carried-block output (tw.gd_out).
-template <int KEEPG>
+// transformed diagonal 32x32 blocks of the (sorted, rescaled) matrix left in LDS: block h = sorted positions 32h..32h+31
+__device__ __forceinline__ void store_diag_blocks(const float* G, const int* rnk, const float* cscale, float* d0, float* d1, int tid) {
+    for (int e = tid; e < PW * PW; e += 256) {
+        const int r = e >> 6, c = e & 63;
+        const int rr = rnk[r], rc = rnk[c];
+        if ((rr >> 5) == (rc >> 5)) {
+            float* dst = (rr >> 5) ? d1 : d0;
+            dst[(rr & 31) * 32 + (rc & 31)] = G[r * PW + pcol(c)] * cscale[r] * cscale[c];
+        }
+    }
+}
+
+template <int MODE, int KEEPG>
 __global__ __launch_bounds__(256, 4) void evd_kernel(const float* __restrict__ Gpart, int nsplit, float* __restrict__ Qbuf,
                                                    int* __restrict__ active, unsigned* __restrict__ maxoff_bits,
                                                    int* __restrict__ nrot, const int* __restrict__ done, float tol,
                                                    int inner_sweeps, int nb, int step, int kb, int* __restrict__ hist,
-                                                   const int* __restrict__ plist, int list_stride, EvdTwoLevel tw) {
-    __shared__ float G[PW * PW];
-    __shared__ float Qs[KEEPG ? PW * PW : 1];
+                                                   const int* __restrict__ plist, int list_stride, EvdV3 v3) {
+    static_assert(MODE == 0 || KEEPG == 1, "the two-level modes read G after the solve");
+    __shared__ __attribute__((aligned(16))) float G[PW * PW];
+    __shared__ __attribute__((aligned(16))) float Qs[KEEPG ? PW * PW : 4];
     float* Q = KEEPG ? Qs : G;
     __shared__ float sdiag[2][PW];
     __shared__ float sb[2][32];
@@ -295,60 +318,36 @@ __global__ __launch_bounds__(256, 4) void evd_kernel(const float* __restrict__ G
     __shared__ float cscale[PW];
     __shared__ int rnk[PW];
 
-    const bool inner = tw.G128 != nullptr;
-    const int pair = inner ? (blockIdx.x >> 1) : blockIdx.x, b = blockIdx.y, npairs = inner ? (gridDim.x >> 1) : gridDim.x;
+    const int pair = MODE ? (blockIdx.x >> 1) : blockIdx.x, b = blockIdx.y, npairs = MODE ? (gridDim.x >> 1) : gridDim.x;
+    ASVD_KERNEL_ACQUIRE();
     if (done[b]) return;
     // the eigen-solve is a dependent chain of short VALU/LDS phases on every group's critical path: let its waves win the issue
     // arbitration against the matrix-pipe-bound gram/update waves of the other stream groups that share the SIMD
     __builtin_amdgcn_s_setprio(3);
-    const int tid = threadIdx.x;
-    int I, J;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int sp = MODE ? (blockIdx.x & 1) : 0;
+    const int64_t slot = (int64_t)b * npairs + pair;
+    int I, J;        // the two 32-column panels of this solve
     int* act_flag;   // where this solve reports whether it rotated
-    float* qo;       // its 64x64 Q
-    if (inner) {
-        const int sp = blockIdx.x & 1;
-        const int64_t slot = (int64_t)b * npairs + pair;
-        act_flag = tw.subact + slot * 4 + tw.inner_t * 2 + sp;
-        qo = Qbuf + (slot * 2 + sp) * (PW * PW);
-        int S, T;
-        rr_pair(tw.ns, step, pair, S, T);
-        if (T >= tw.ns) {  // padding super-pair
-            if (tid == 0) *act_flag = 0;
-            return;
-        }
-        int ba, bb;
-        sub_blocks(tw.inner_t, sp, ba, bb);
-        I = 2 * S + ba;
-        J = 2 * T + (bb - 2);
-        const float* __restrict__ g = tw.G128 + slot * (128 * 128);
-#pragma unroll 4
-        for (int q = 0; q < 16; ++q) {
-            const int e = tid + 256 * q, i = e >> 6, j = e & 63;
-            const float v = g[(32 * (i < 32 ? ba : bb) + (i & 31)) * 128 + 32 * (j < 32 ? ba : bb) + (j & 31)];
-            G[i * PW + pcol(j)] = v;
-            if (i == j) sdiag[0][i] = v;
-            if (j == i + 1 && (i & 1) == 0) sb[0][i >> 1] = v;
-        }
-    } else {
+    float* qo;       // its 64x64 Q (MODE 0, 1)
+    int S = 0, T = 0;
+    if constexpr (MODE == 0) {
         act_flag = active + b * npairs + pair;
-        qo = Qbuf + ((int64_t)b * npairs + pair) * (PW * PW);
+        qo = Qbuf + slot * (PW * PW);
         if (!get_pair(plist, list_stride, b, nb, step, pair, I, J)) {  // padding pair / empty slot: nothing to rotate
             if (tid == 0) *act_flag = 0;
             return;
         }
-    }
-    const float* gp = Gpart + ((int64_t)b * npairs + pair) * nsplit * 3072;
-
-    if (!inner) {
+        const float* gp = Gpart + slot * nsplit * 3072;
         // sum the row-split partials in fixed order: the three stored 32x32 blocks (II, IJ, JJ) are read fully coalesced (12
         // independent elements per thread keep 12+ loads in flight per split); the JI block is the mirror of IJ, written to LDS twice
         float acc[12];
 #pragma unroll
         for (int q = 0; q < 12; ++q) acc[q] = 0.0f;
 #pragma unroll 2
-        for (int sp = 0; sp < nsplit; ++sp) {
+        for (int s2 = 0; s2 < nsplit; ++s2) {
 #pragma unroll
-            for (int q = 0; q < 12; ++q) acc[q] += gp[(int64_t)sp * 3072 + tid + 256 * q];
+            for (int q = 0; q < 12; ++q) acc[q] += gp[(int64_t)s2 * 3072 + tid + 256 * q];
         }
 #pragma unroll
         for (int q = 0; q < 12; ++q) {
@@ -357,10 +356,113 @@ __global__ __launch_bounds__(256, 4) void evd_kernel(const float* __restrict__ G
             const int i = ii + (t == 2 ? 32 : 0), j = jj + (t == 0 ? 0 : 32);
             G[i * PW + pcol(j)] = acc[q];
             if (t == 1) G[j * PW + pcol(i)] = acc[q];
-            if (i == j) sdiag[0][i] = acc[q];
-            if (j == i + 1 && (i & 1) == 0) sb[0][i >> 1] = acc[q];  // phase A pivots G[2k][2k+1]
+        }
+    } else {
+        act_flag = v3.subact + slot * 4 + (MODE - 1) * 2 + sp;
+        qo = v3.Q0 + (slot * 2 + sp) * (PW * PW);
+        rr_pair(v3.ns, step, pair, S, T);
+        if (T >= v3.ns) {  // padding super-pair
+            if (tid == 0) *act_flag = 0;
+            return;
+        }
+        // blocks (a, b) of this solve: step 0: (0,2),(1,3); step 1: (0,3),(1,2)
+        const int ba = sp, bb = (MODE == 1) ? 2 + sp : 3 - sp;
+        I = 2 * S + ba;
+        J = 2 * T + (bb - 2);
+        const float* __restrict__ gx = v3.Gx6 + slot * v3.nsplit6 * (6 * 1024);
+        const float *dA, *dB;  // the two diagonal blocks
+        if constexpr (MODE == 1) {
+            dA = v3.Gd32 + ((int64_t)b * v3.nbpan + I) * 1024;
+            dB = v3.Gd32 + ((int64_t)b * v3.nbpan + J) * 1024;
+            // cross block = summed tile [0,2] (tile 0) or [1,3] (tile 3)
+            const int tile = sp ? 3 : 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int e = tid + 256 * q, i = e >> 5, j = e & 31;
+                float v = 0.0f;
+                for (int s2 = 0; s2 < v3.nsplit6; ++s2) v += gx[(int64_t)s2 * 6144 + tile * 1024 + e];
+                G[i * PW + pcol(32 + j)] = v;
+                G[(32 + j) * PW + pcol(i)] = v;
+            }
+        } else {
+            dA = v3.D0 + (slot * 4 + ba) * 1024;
+            dB = v3.D0 + (slot * 4 + bb) * 1024;
+            // cross block C = QA[:, :32]^T MM QB[:, 32:], MM = M = G[{0,2},{1,3}] (sp 0, QA = Q0_0, QB = Q0_1) or M^T (sp 1, swapped).
+            // LDS: MMt (the transpose of MM, 64x64) in Qs; QAh (64x32) and QBh (64x32) in G; T = MM QBh goes over MMt.
+            float* MMt = Qs;
+            float* QAh = G;
+            float* QBh = G + 2048;
+            const float* __restrict__ qa = v3.Q0 + (slot * 2 + sp) * (PW * PW);
+            const float* __restrict__ qb = v3.Q0 + (slot * 2 + (sp ^ 1)) * (PW * PW);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int e = tid + 256 * q, k = e >> 5, i = e & 31;
+                QAh[e] = qa[k * PW + i];
+                QBh[e] = qb[k * PW + 32 + i];
+            }
+            // M blocks from the summed tiles: [0,1] = tile 4, [0,3] = tile 1, [2,1] = tile 2 ^T, [2,3] = tile 5
+#pragma unroll 4
+            for (int q = 0; q < 16; ++q) {
+                const int e = tid + 256 * q, k = e >> 6, i = e & 63;  // MMt[k][i]
+                // sp 0: MMt[k][i] = M[i][k] (i: rows = blocks 0,2; k: columns = blocks 1,3);  sp 1: MMt[k][i] = M[k][i]
+                const int mr = sp ? k : i, mc = sp ? i : k;
+                const int rb = mr >> 5, cb = mc >> 5, ri = mr & 31, ci = mc & 31;
+                int off;
+                if (rb == 0 && cb == 0) off = 4 * 1024 + ri * 32 + ci;
+                else if (rb == 0) off = 1 * 1024 + ri * 32 + ci;
+                else if (cb == 0) off = 2 * 1024 + ci * 32 + ri;  // [2,1] = [1,2]^T
+                else off = 5 * 1024 + ri * 32 + ci;
+                float v = 0.0f;
+                for (int s2 = 0; s2 < v3.nsplit6; ++s2) v += gx[(int64_t)s2 * 6144 + off];
+                MMt[k * PW + i] = v;
+            }
+            __syncthreads();
+            const int hh = lane >> 5, cc = lane & 31;
+            f32x16 acc = {0};
+            if (wv < 2) {  // T[32 wv + i][j] = sum_k MM[32 wv + i][k] QBh[k][j]
+#pragma unroll 8
+                for (int k2 = 0; k2 < 32; ++k2) {
+                    const int k = 2 * k2 + hh;
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(MMt[k * PW + 32 * wv + cc], QBh[k * 32 + cc], acc, 0, 0, 0);
+                }
+            }
+            __syncthreads();  // MMt fully consumed
+            if (wv < 2) {
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int i = (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+                    MMt[(32 * wv + i) * 32 + cc] = acc[reg];  // T, row-major 64 x 32
+                }
+            }
+            __syncthreads();
+            acc = (f32x16){0};
+            if (wv == 0) {  // C[i][j] = sum_k QAh[k][i] T[k][j]
+#pragma unroll 8
+                for (int k2 = 0; k2 < 32; ++k2) {
+                    const int k = 2 * k2 + hh;
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(QAh[k * 32 + cc], MMt[k * 32 + cc], acc, 0, 0, 0);
+                }
+            }
+            __syncthreads();  // QAh / QBh (the G region) are free now
+            if (wv == 0) {
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int i = (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+                    G[i * PW + pcol(32 + cc)] = acc[reg];
+                    G[(32 + cc) * PW + pcol(i)] = acc[reg];
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + 256 * q, i = e >> 5, j = e & 31;
+            G[i * PW + pcol(j)] = dA[e];
+            G[(32 + i) * PW + pcol(32 + j)] = dB[e];
         }
     }
+    __syncthreads();
+    if (tid < PW) sdiag[0][tid] = G[tid * PW + pcol(tid)];
+    if (tid < 32) sb[0][tid] = G[(2 * tid) * PW + pcol(2 * tid + 1)];  // phase A pivots G[2k][2k+1]
     __syncthreads();
 
     // scaled off-diagonal measure: max |g_ij| / sqrt(g_ii g_jj), NaN propagating.
@@ -418,20 +520,25 @@ __global__ __launch_bounds__(256, 4) void evd_kernel(const float* __restrict__ G
         atomicAdd(&hist[bk < 0 ? 0 : (bk > 9 ? 9 : bk)], 1);
     }
     if (tid == 0) atomicMax(&maxoff_bits[b], is_nan ? 0x7fc00000u : __float_as_uint(offt));
-    if (is_nan || off0 < tol) {
-        if (tid == 0) *act_flag = 0;
-        if (inner) {  // gupdate multiplies by Q unconditionally
-            for (int e = tid; e < PW * PW; e += 256) qo[e] = ((e >> 6) == (e & 63)) ? 1.0f : 0.0f;
-        }
-        if (tw.gd_out) {  // carried diagonal block of the super-panel = the matrix itself
-            float* gd = tw.gd_out + ((int64_t)b * tw.ns + pair) * (PW * PW);
-            for (int e = tid; e < PW * PW; e += 256) gd[e] = G[(e >> 6) * PW + pcol(e & 63)];
-        }
-        return;
-    }
+    const bool rotate = !(is_nan || off0 < tol);
     if (tid == 0) {
-        *act_flag = 1;
-        if (offt >= tol) atomicAdd(&nrot[b], 1);
+        *act_flag = rotate ? 1 : 0;
+        if (rotate && offt >= tol) atomicAdd(&nrot[b], 1);
+    }
+    if constexpr (MODE == 0) {
+        if (!rotate) {
+            if (v3.Gd32) {  // carried diagonal blocks of the two panels = the blocks of the matrix itself
+                float* d0 = v3.Gd32 + ((int64_t)b * v3.nbpan + I) * 1024;
+                float* d1 = v3.Gd32 + ((int64_t)b * v3.nbpan + J) * 1024;
+                for (int e = tid; e < 1024; e += 256) {
+                    const int i = e >> 5, j = e & 31;
+                    d0[e] = G[i * PW + pcol(j)];
+                    d1[e] = G[(32 + i) * PW + pcol(32 + j)];
+                }
+            }
+            ASVD_KERNEL_RELEASE();
+            return;
+        }
     }
 
     const int g = tid >> 5, tx = tid & 31;
@@ -535,7 +642,7 @@ __global__ __launch_bounds__(256, 4) void evd_kernel(const float* __restrict__ G
         __syncthreads();
         cur = nxt;
     };
-    for (int ph2 = 0; ph2 < nsw * (PW / 2); ++ph2) {
+    for (int ph2 = 0; ph2 < (rotate ? nsw * (PW / 2) : 0); ++ph2) {
         phase(std::integral_constant<int, 0>{});
         phase(std::integral_constant<int, 1>{});
     }
@@ -559,10 +666,10 @@ __global__ __launch_bounds__(256, 4) void evd_kernel(const float* __restrict__ G
         }
         acc += __shfl_xor(acc, 1, 64);
         acc += __shfl_xor(acc, 2, 64);
-        if (part == 0) cscale[cpos] = (acc > 0.0) ? (float)(1.0 / sqrt(acc)) : 1.0f;
+        if (part == 0) cscale[cpos] = (rotate && acc > 0.0) ? (float)(1.0 / sqrt(acc)) : 1.0f;
     }
-    __syncthreads();
-    // sort eigenvalues descending (ties by index): the column at position c goes to output column rnk[c]
+    // sort eigenvalues descending (ties by index): the column at position c goes to output column rnk[c]; nothing moves when the
+    // solve did not rotate
     if (tid < PW) {
         const float me = sdiag[cur][tid];
         int cnt = 0;
@@ -570,20 +677,69 @@ __global__ __launch_bounds__(256, 4) void evd_kernel(const float* __restrict__ G
             const float o = sdiag[cur][i];
             cnt += (o > me || (o == me && i < tid)) ? 1 : 0;
         }
-        rnk[tid] = cnt;
+        rnk[tid] = rotate ? cnt : tid;
     }
     __syncthreads();
-    for (int e = tid; e < PW * PW; e += 256) {
-        const int r = e >> 6, c = e & 63;
-        qo[r * PW + rnk[c]] = Q[r * PW + pcol(c)] * cscale[c];
-    }
-    if (tw.gd_out) {  // Q^T G Q (what the rotations left in LDS), in the order and scaling of Q's columns
-        float* gd = tw.gd_out + ((int64_t)b * tw.ns + pair) * (PW * PW);
+    if constexpr (MODE <= 1) {
         for (int e = tid; e < PW * PW; e += 256) {
             const int r = e >> 6, c = e & 63;
-            gd[rnk[r] * PW + rnk[c]] = G[r * PW + pcol(c)] * cscale[r] * cscale[c];
+            qo[r * PW + rnk[c]] = Q[r * PW + pcol(c)] * cscale[c];
         }
     }
+    if constexpr (MODE == 0) {
+        if (v3.Gd32)  // Q^T G Q (what the rotations left in LDS), in the order and scaling of Q's columns
+            store_diag_blocks(G, rnk, cscale, v3.Gd32 + ((int64_t)b * v3.nbpan + I) * 1024, v3.Gd32 + ((int64_t)b * v3.nbpan + J) * 1024, tid);
+    } else if constexpr (MODE == 1) {
+        const int ba = sp, bb = 2 + sp;
+        store_diag_blocks(G, rnk, cscale, v3.D0 + (slot * 4 + ba) * 1024, v3.D0 + (slot * 4 + bb) * 1024, tid);
+    } else {
+        const int ba = sp, bb = 3 - sp;
+        store_diag_blocks(G, rnk, cscale, v3.Gd32 + ((int64_t)b * v3.nbpan + I) * 1024, v3.Gd32 + ((int64_t)b * v3.nbpan + J) * 1024, tid);
+        __syncthreads();  // G consumed
+        // Qfin[:, columns of blocks (a, b)] = Q^(0)[:, {a, b}] Q1:  rows of blocks {a, a+2} get Q0_a[:, :32] Q1[:32, :], rows of blocks
+        // {b-2, b} get Q0_(b-2)[:, 32:] Q1[32:, :].  Q1 (sorted, rescaled) goes row-major into G's LDS, the two Q0 halves TRANSPOSED
+        // (k-major, so that the MFMA A operand reads are contiguous) over Qs once Q has been consumed.
+        float* Q1s = G;
+        for (int e = tid; e < PW * PW; e += 256) {
+            const int r = e >> 6, c = e & 63;
+            Q1s[r * PW + rnk[c]] = Q[r * PW + pcol(c)] * cscale[c];
+        }
+        __syncthreads();
+        float* At0 = Qs;          // At0[k][i] = Q0_a[i][k],        k < 32, i < 64
+        float* At1 = Qs + 2048;   // At1[k][i] = Q0_(b-2)[i][32 + k]
+        const float* __restrict__ q0a = v3.Q0 + (slot * 2 + ba) * (PW * PW);
+        const float* __restrict__ q0b = v3.Q0 + (slot * 2 + (bb - 2)) * (PW * PW);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int e = tid + 256 * q, i = e >> 5, k = e & 31;
+            At0[k * PW + i] = q0a[i * PW + k];
+            At1[k * PW + i] = q0b[i * PW + 32 + k];
+        }
+        __syncthreads();
+        const int hh = lane >> 5, cc = lane & 31;
+        float* __restrict__ qf = v3.Qfin + slot * (128 * 128);
+        // 8 output tiles (2 products x 2 x 2 tiles of 32 x 32, K = 32): wave wv does product wv >> 1, row tile wv & 1, both column tiles
+        const int prod = wv >> 1, ti = wv & 1;
+        const float* At = prod ? At1 : At0;
+        const float* Bm = Q1s + (prod ? 32 * PW : 0);
+        f32x16 c0 = {0}, c1 = {0};
+#pragma unroll 8
+        for (int k2 = 0; k2 < 16; ++k2) {
+            const int k = 2 * k2 + hh;
+            const float a = At[k * PW + 32 * ti + cc];
+            c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Bm[k * PW + cc], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Bm[k * PW + 32 + cc], c1, 0, 0, 0);
+        }
+        // row block of local row tile ti: product 0 -> blocks {a, a+2}[ti]; product 1 -> blocks {b-2, b}[ti]
+        const int rblk = prod ? (ti ? bb : bb - 2) : (ti ? ba + 2 : ba);
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int i = (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+            qf[(32 * rblk + i) * 128 + 32 * ba + cc] = c0[reg];
+            qf[(32 * rblk + i) * 128 + 32 * bb + cc] = c1[reg];
+        }
+    }
+    ASVD_KERNEL_RELEASE();
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -597,6 +753,7 @@ __global__ __launch_bounds__(256) void update_kernel(float* __restrict__ X, int6
                                                      const float* __restrict__ Qbuf, const int* __restrict__ active,
                                                      const int* __restrict__ done, const int* __restrict__ plist, int list_stride) {
     const int chunk = blockIdx.x, pair = blockIdx.y, b = blockIdx.z, npairs = gridDim.y;
+    ASVD_KERNEL_ACQUIRE();
     if (done[b] || !active[b * npairs + pair]) return;
     int I, J;
     if (!get_pair(plist, list_stride, b, nb, step, pair, I, J)) return;
@@ -654,6 +811,7 @@ __global__ __launch_bounds__(256) void update_kernel(float* __restrict__ X, int6
             }
         }
     }
+    ASVD_KERNEL_RELEASE();
 }
 
 #include "twolevel.h"
@@ -670,6 +828,7 @@ __global__ __launch_bounds__(256) void update_kernel(float* __restrict__ X, int6
 __global__ __launch_bounds__(256) void panel_sumsq_kernel(const float* __restrict__ X, int64_t panel_stride, int64_t batch_stride,
                                                           int m_pad, int n_pad, float* __restrict__ dn, const int* __restrict__ done) {
     const int I = blockIdx.x, b = blockIdx.y, c = threadIdx.x & 31, g = threadIdx.x >> 5;
+    ASVD_KERNEL_ACQUIRE();
     if (done[b]) return;
     const float* __restrict__ P = X + (int64_t)b * batch_stride + (int64_t)I * panel_stride;
     float s = 0.0f;
@@ -683,6 +842,7 @@ __global__ __launch_bounds__(256) void panel_sumsq_kernel(const float* __restric
         for (int i = 0; i < 8; ++i) t += red[i][c];
         dn[(int64_t)b * n_pad + I * PB + c] = t;
     }
+    ASVD_KERNEL_RELEASE();
 }
 
 __device__ __forceinline__ float nanmax(float a, float b) { return (b != b) ? b : ((a != a) ? a : fmaxf(a, b)); }
@@ -697,6 +857,7 @@ __global__ __launch_bounds__(256) void fullcheck_kernel(const float* __restrict_
                                                         const int* __restrict__ done) {
     const int ig = blockIdx.x, jg = blockIdx.y, b = blockIdx.z;
     if (ig > jg || done[b]) return;
+    ASVD_KERNEL_ACQUIRE();
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int J = jg * 4 + w;
     bool ok[4];
@@ -767,7 +928,7 @@ __global__ __launch_bounds__(256) void fullcheck_kernel(const float* __restrict_
             }
         }
     }
-    if (J >= nb) return;
+    if (J >= nb) { ASVD_KERNEL_RELEASE(); return; }
     const int h = lane >> 5, c = lane & 31;
     const float* __restrict__ dnb = dn + (int64_t)b * n_pad;
     const float dj = dnb[J * PB + c];
@@ -808,6 +969,7 @@ __global__ __launch_bounds__(256) void fullcheck_kernel(const float* __restrict_
             }
         }
     }
+    ASVD_KERNEL_RELEASE();
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -1478,7 +1640,15 @@ __global__ void colscale_kernel(float* __restrict__ Y, int64_t ldy, int rows, in
 }
 
 // --------------------------------------------------------------------------------------------------
-static int stream_groups_for(int batch) { return batch >= 12 ? 3 : (batch >= 8 ? 2 : 1); }
+// stream groups of the sweeps: 1 unless ASVD_GROUPS asks for more (see common.h "cache maintenance": several groups need fences that
+// cost more than the overlap gains)
+static int stream_groups_for(int batch) {
+    const char* e = getenv("ASVD_GROUPS");
+    int g = e ? atoi(e) : 1;
+    if (g < 1) g = 1;
+    if (g > 4) g = 4;
+    return g > batch ? batch : g;
+}
 
 static bool pair_order_xor() {
     const char* e = getenv("ASVD_ORDER");
@@ -1495,7 +1665,7 @@ struct Plan {
     int fused, nchunks_f, rows_per_wg_f;  // upgram path (XOR ordering, power-of-two panel count)
     // two-level dense sweeps (twolevel.h): ns super-panels of 64 columns, npairs_s pair slots per super-step (power-of-two padded)
     int two, ns, npairs_s, nsplit_s, rows_per_split_s, nchunks_s, rows_per_wg_s;
-    size_t off_gd, off_gx, off_g128, off_qacc, off_qfin, off_qsub, off_subact, off_active_s;
+    size_t off_gd32, off_gx6, off_q0, off_d0, off_qfin, off_subact;
     int64_t panel_stride, batch_stride;
     // workspace offsets in bytes
     size_t off_x, off_xorig, off_gpart, off_q, off_active, off_sig, off_ina, off_inv, off_perm, off_flags, off_pflag, off_plist, total;
@@ -1568,19 +1738,19 @@ int make_plan(int batch, int64_t m, int64_t n, int want_u, int want_vv, Plan& p)
     {
         // two-level dense sweeps: default for >= 8 panels under the XOR ordering (ASVD_TWOLEVEL=0 restores the single-level sweep)
         const char* e2 = getenv("ASVD_TWOLEVEL");
+        p.two = (pair_order_xor() && p.nb >= 8 && !p.fused && !(e2 && atoi(e2) == 0)) ? 1 : 0;
         p.ns = p.nb / 2;
         int pw2 = 2;
         while (pw2 < p.ns) pw2 <<= 1;
         p.npairs_s = pw2 / 2;
-        p.two = (pair_order_xor() && p.nb >= 8 && !p.fused && !(e2 && atoi(e2) == 0)) ? 1 : 0;
         const int launch_batch = (int)ceil_div64(batch, stream_groups_for(batch));
-        // sgram: 4 workgroups (32 KiB LDS, 112 VGPRs) per CU -> 1024 slots; 16-row chunks, same cost model as the single-level Gram
+        // sgram6: 3 workgroups (32 KiB LDS, ~150 VGPRs) per CU -> 768 slots; 16-row chunks per wave, same cost model as the single-level Gram
         const int64_t nchunk_total = p.m_pad / 32;
         int64_t best_ns = 1;
         double best_cost = 1e300;
         for (int64_t ns = 1; ns <= nchunk_total && ns <= 64; ++ns) {
             const int64_t wgs = ns * p.npairs_s * launch_batch;
-            const int64_t rounds = ceil_div64(wgs, 1024);
+            const int64_t rounds = ceil_div64(wgs, 768);
             const int64_t chunks_wave = ceil_div64(2 * ceil_div64(nchunk_total, ns), 4);
             const double cost = (double)rounds * ((double)chunks_wave + 1.5) + 0.02 * ns;
             if (cost < best_cost) { best_cost = cost; best_ns = ns; }
@@ -1611,14 +1781,12 @@ int make_plan(int batch, int64_t m, int64_t n, int want_u, int want_vv, Plan& p)
     p.off_pflag = take((size_t)batch * p.nb * p.nb);      // sparse-sweep pair marks
     p.off_plist = take((size_t)batch * p.nb * p.nb * sizeof(int));  // per-step lists of marked pairs (bound: steps x nb/2 slots per problem)
     const size_t t2 = p.two ? 1 : 0;
-    p.off_gd = take(t2 * batch * p.ns * SW * SW * sizeof(float));
-    p.off_gx = take(t2 * batch * p.npairs_s * p.nsplit_s * SW * SW * sizeof(float));
-    p.off_g128 = take(t2 * batch * p.npairs_s * SP * SP * sizeof(float));
-    p.off_qacc = take(t2 * batch * p.npairs_s * SP * SP * sizeof(float));
-    p.off_qfin = take(t2 * batch * p.npairs_s * SP * SP * sizeof(float));
-    p.off_qsub = take(t2 * batch * p.npairs_s * 2 * SW * SW * sizeof(float));
+    p.off_gd32 = take(t2 * batch * p.nb * 1024 * sizeof(float));                          // carried 32x32 diagonal blocks, one per panel
+    p.off_gx6 = take(t2 * batch * p.npairs_s * p.nsplit_s * 6 * 1024 * sizeof(float));    // sgram6 partial tiles
+    p.off_q0 = take(t2 * batch * p.npairs_s * 2 * PW * PW * sizeof(float));               // Q of the two step-0 solves
+    p.off_d0 = take(t2 * batch * p.npairs_s * 4 * 1024 * sizeof(float));                  // diagonal blocks after step 0
+    p.off_qfin = take(t2 * batch * p.npairs_s * SP * SP * sizeof(float));                 // Q^(0) Q^(1) of every super-pair
     p.off_subact = take(t2 * batch * p.npairs_s * 4 * sizeof(int));
-    p.off_active_s = take(t2 * batch * p.npairs_s * sizeof(int));
     p.total = off;
     return ASVD_OK;
 }
@@ -1791,6 +1959,8 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
     {
         const int order = pair_order_xor() ? 1 : 0;
         ASVD_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_pair_order), &order, sizeof(int), 0, hipMemcpyHostToDevice));
+        const int fence = stream_groups_for(batch) > 1 ? 1 : 0;
+        ASVD_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_fence), &fence, sizeof(int), 0, hipMemcpyHostToDevice));
     }
     const int nsteps = pair_order_xor() ? 2 * p.npairs - 1 : p.nb - 1;
     // panels whose convergence is enforced: those holding the k leading columns, plus one panel of margin
@@ -1802,8 +1972,7 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
     // Independent problems of a batch are split into two groups driven on two internal streams: while one group sits in its
     // LDS/VALU-bound evd phase the other streams panels through its HBM-bound gram/update phase (different resources).
     constexpr int MAXG = 4;
-    int ngroups = stream_groups_for(batch);  // measured at 4096^2: 16 problems as 6/5/5 +3 % over 8/8; 4 groups lose
-    if (getenv("ASVD_GROUPS")) ngroups = atoi(getenv("ASVD_GROUPS"));
+    int ngroups = stream_groups_for(batch);
     if (ngroups < 1) ngroups = 1;
     if (ngroups > MAXG) ngroups = MAXG;
     if (ngroups > batch) ngroups = batch;
@@ -1924,14 +2093,14 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
         // two-level dense sweep: only the internal step d = 1 runs through the single-level kernels (it also refreshes the carried
         // diagonal blocks); the super-steps follow below
         const bool two_now = p.two && !sparse;
-        const int nsched = sparse ? nsteps : (two_now ? 1 : (int)sched.size());
+        const int nsched = sparse ? nsteps : (two_now ? 1 : (int)sched.size());  // two-level: only the step d = 1 inside the super-panels
         for (int si = 0; si < nsched; ++si) {
-            const int step = sparse ? si : (two_now ? 0 : sched[si]);
+            const int step = sparse ? si : (two_now ? si : sched[si]);
             for (int g = 0; g < ngroups; ++g) {
                 const int b0 = gb0[g], nbg = gnb[g];
                 hipStream_t s2 = gst[g];
                 float* Xg = X + (int64_t)b0 * p.batch_stride;
-                float* Gdg = (float*)(wb + p.off_gd) + (int64_t)b0 * p.ns * SW * SW;
+                float* Gd32g = (float*)(wb + p.off_gd32) + (int64_t)b0 * p.nb * 1024;
                 float* Gg = Gpart + (int64_t)b0 * p.npairs * gstride * 3072;
                 float* Qg = Qbuf + (int64_t)b0 * p.npairs * PW * PW;
                 int* ag = active + (int64_t)b0 * p.npairs;
@@ -1959,8 +2128,8 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
                     }
                     {
                         ProfScope ps(2, s2);
-                        evd_kernel<0><<<dim3(slots, nbg), 256, 0, s2>>>(Gg, nsp, Qg, ag, maxoff + b0, nrot + b0, done + b0, tol, inner_sweeps,
-                                                                     p.nb, step, kb, hist_dev, pl, slots, EvdTwoLevel{nullptr, 0, 0, nullptr, nullptr});
+                        evd_kernel<0, 0><<<dim3(slots, nbg), 256, 0, s2>>>(Gg, nsp, Qg, ag, maxoff + b0, nrot + b0, done + b0, tol, inner_sweeps,
+                                                                           p.nb, step, kb, hist_dev, pl, slots, EvdV3{});
                     }
                     {
                         ProfScope ps(3, s2);
@@ -1978,14 +2147,17 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
                 }
                 {
                     ProfScope ps(2, s2);
-                    if (two_now && step == 0)
-                        evd_kernel<1><<<dim3(p.npairs, nbg), 256, 0, s2>>>(Gg, ns_here, Qg, ag, maxoff + b0, nrot + b0, done + b0, tol,
-                                                                            inner_sweeps, p.nb, step, kb, hist_dev, nullptr, 0,
-                                                                            EvdTwoLevel{nullptr, 0, p.ns, nullptr, Gdg});
-                    else
-                        evd_kernel<0><<<dim3(p.npairs, nbg), 256, 0, s2>>>(Gg, ns_here, Qg, ag, maxoff + b0, nrot + b0, done + b0, tol,
-                                                                            inner_sweeps, p.nb, step, kb, hist_dev, nullptr, 0,
-                                                                            EvdTwoLevel{nullptr, 0, p.ns, nullptr, nullptr});
+                    if (two_now) {  // internal step: also emits the fresh carried diagonal blocks of both panels of every pair
+                        EvdV3 v3{};
+                        v3.ns = p.ns;
+                        v3.nbpan = p.nb;
+                        v3.Gd32 = Gd32g;
+                        evd_kernel<0, 1><<<dim3(p.npairs, nbg), 256, 0, s2>>>(Gg, ns_here, Qg, ag, maxoff + b0, nrot + b0, done + b0, tol,
+                                                                               inner_sweeps, p.nb, step, kb, hist_dev, nullptr, 0, v3);
+                    } else {
+                        evd_kernel<0, 0><<<dim3(p.npairs, nbg), 256, 0, s2>>>(Gg, ns_here, Qg, ag, maxoff + b0, nrot + b0, done + b0, tol,
+                                                                               inner_sweeps, p.nb, step, kb, hist_dev, nullptr, 0, EvdV3{});
+                    }
                 }
                 {
                     ProfScope ps(3, s2);
@@ -2004,6 +2176,7 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
         if (two_now) {
             const int nsuper = 2 * p.npairs_s - 1;
             const bool split_bf16 = getenv("ASVD_SPLIT") && atoi(getenv("ASVD_SPLIT")) == 1;
+            const int dbg_sync = getenv("ASVD_DBG_SYNC") ? atoi(getenv("ASVD_DBG_SYNC")) : 0;
             // local super-levels D = 1..L run twice at the start of the sweep (the two-level form of ASVD_DUP; ASVD_DUP2=L)
             const int dup2 = std::min(nsuper, getenv("ASVD_DUP2") ? atoi(getenv("ASVD_DUP2")) : 0);
             for (int di = 0; di < nsuper + dup2; ++di) {
@@ -2012,39 +2185,42 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
                     const int b0 = gb0[g], nbg = gnb[g];
                     hipStream_t s2 = gst[g];
                     float* Xg = X + (int64_t)b0 * p.batch_stride;
-                    float* Gdg = (float*)(wb + p.off_gd) + (int64_t)b0 * p.ns * SW * SW;
-                    float* Gxg = (float*)(wb + p.off_gx) + (int64_t)b0 * p.npairs_s * p.nsplit_s * SW * SW;
-                    float* G128g = (float*)(wb + p.off_g128) + (int64_t)b0 * p.npairs_s * SP * SP;
-                    float* Qaccg = (float*)(wb + p.off_qacc) + (int64_t)b0 * p.npairs_s * SP * SP;
-                    float* Qfing = (float*)(wb + p.off_qfin) + (int64_t)b0 * p.npairs_s * SP * SP;
-                    float* Qsubg = (float*)(wb + p.off_qsub) + (int64_t)b0 * p.npairs_s * 2 * SW * SW;
-                    int* subg = (int*)(wb + p.off_subact) + (int64_t)b0 * p.npairs_s * 4;
-                    int* actsg = (int*)(wb + p.off_active_s) + (int64_t)b0 * p.npairs_s;
+                    EvdV3 v3{};
+                    v3.ns = p.ns;
+                    v3.nbpan = p.nb;
+                    v3.nsplit6 = p.nsplit_s;
+                    float* Gx6g = (float*)(wb + p.off_gx6) + (int64_t)b0 * p.npairs_s * p.nsplit_s * 6 * 1024;
+                    v3.Gx6 = Gx6g;
+                    v3.Gd32 = (float*)(wb + p.off_gd32) + (int64_t)b0 * p.nb * 1024;
+                    v3.Q0 = (float*)(wb + p.off_q0) + (int64_t)b0 * p.npairs_s * 2 * PW * PW;
+                    v3.D0 = (float*)(wb + p.off_d0) + (int64_t)b0 * p.npairs_s * 4 * 1024;
+                    v3.Qfin = (float*)(wb + p.off_qfin) + (int64_t)b0 * p.npairs_s * SP * SP;
+                    v3.subact = (int*)(wb + p.off_subact) + (int64_t)b0 * p.npairs_s * 4;
                     {
                         ProfScope ps(1, s2);
-                        sgram_kernel<<<dim3(p.nsplit_s, p.npairs_s, nbg), 256, 0, s2>>>(Xg, p.panel_stride, p.batch_stride, p.ns, D, p.m_pad,
-                                                                                       p.rows_per_split_s, Gxg, done + b0);
+                        sgram6_kernel<<<dim3(p.nsplit_s, p.npairs_s, nbg), 256, 0, s2>>>(Xg, p.panel_stride, p.batch_stride, p.ns, D, p.m_pad,
+                                                                                        p.rows_per_split_s, Gx6g, done + b0);
                     }
+                    if (dbg_sync & 4) (void)hipStreamSynchronize(s2);
                     {
                         ProfScope ps(2, s2);
-                        sassemble_kernel<<<dim3(p.npairs_s, nbg), 256, 0, s2>>>(Gxg, p.nsplit_s, Gdg, p.ns, D, G128g, done + b0);
-                        for (int t = 0; t < 2; ++t) {
-                            evd_kernel<0><<<dim3(2 * p.npairs_s, nbg), 256, 0, s2>>>(nullptr, 0, Qsubg, nullptr, maxoff + b0, nrot + b0, done + b0, tol,
-                                                                                 inner_sweeps, p.nb, D - 1, kb, hist_dev, nullptr, 0,
-                                                                                 EvdTwoLevel{G128g, t, p.ns, subg, nullptr});
-                            gupdate_kernel<<<dim3(6, p.npairs_s, nbg), 256, 0, s2>>>(G128g, Qaccg, Qsubg, subg, p.ns, D, t, t == 0 ? 1 : 0, done + b0);
-                        }
-                        sfinish_kernel<<<dim3(p.npairs_s, nbg), 256, 0, s2>>>(G128g, Qaccg, Qfing, Gdg, subg, actsg, p.ns, D, done + b0);
+                        evd_kernel<1, 1><<<dim3(2 * p.npairs_s, nbg), 256, 0, s2>>>(nullptr, 0, nullptr, nullptr, maxoff + b0, nrot + b0, done + b0, tol,
+                                                                                   inner_sweeps, p.nb, D - 1, kb, hist_dev, nullptr, 0, v3);
+                        if (dbg_sync & 8) (void)hipStreamSynchronize(s2);
+                        evd_kernel<2, 1><<<dim3(2 * p.npairs_s, nbg), 256, 0, s2>>>(nullptr, 0, nullptr, nullptr, maxoff + b0, nrot + b0, done + b0, tol,
+                                                                                   inner_sweeps, p.nb, D - 1, kb, hist_dev, nullptr, 0, v3);
                     }
+                    if (dbg_sync & 2) (void)hipStreamSynchronize(s2);
                     {
                         ProfScope ps(3, s2);
                         if (split_bf16)
                             supdate_split_kernel<<<dim3(p.nchunks_s, p.npairs_s, nbg), 256, 0, s2>>>(Xg, p.panel_stride, p.batch_stride, p.ns, D,
-                                                                                                    p.R_upd, p.rows_per_wg_s, Qfing, actsg, done + b0);
+                                                                                                    p.R_upd, p.rows_per_wg_s, v3.Qfin, v3.subact, done + b0);
                         else
                             supdate_kernel<<<dim3(p.nchunks_s, p.npairs_s, nbg), 256, 0, s2>>>(Xg, p.panel_stride, p.batch_stride, p.ns, D, p.R_upd,
-                                                                                              p.rows_per_wg_s, Qfing, actsg, done + b0);
+                                                                                              p.rows_per_wg_s, v3.Qfin, v3.subact, done + b0);
                     }
+                    if (dbg_sync & 1) (void)hipStreamSynchronize(s2);
                 }
             }
         }
@@ -2305,7 +2481,7 @@ static int svd_tall(int batch, const void* const* a_host, int a_dtype, int64_t m
         constexpr int NES = 3;
         static hipStream_t s_epi[NES] = {nullptr, nullptr, nullptr};
         hipEvent_t e_fork = nullptr, e_join[NES] = {nullptr, nullptr, nullptr};
-        const int nes = batch >= 2 ? NES : 1;
+        const int nes = (batch >= 2 && getenv("ASVD_EPI_STREAMS") && atoi(getenv("ASVD_EPI_STREAMS")) > 1) ? NES : 1;  // one stream by default: see common.h
         if (nes > 1) {
             ASVD_HIP_CHECK(hipEventCreateWithFlags(&e_fork, hipEventDisableTiming));
             ASVD_HIP_CHECK(hipEventRecord(e_fork, st));
@@ -2345,6 +2521,23 @@ static int svd_tall(int batch, const void* const* a_host, int a_dtype, int64_t m
         }
     }
     return rc;
+}
+
+// Debug / test hook (tests/test_gpu_kernels_twolevel.py): one launch of the two-level update kernel on caller-built panels.
+// X: [batch][nb][R][32] fp32 panels; Qfin: [batch][npairs][128*128]; subact: [batch][npairs][4]; done: [batch] ints (device).
+int asvd_dbg_supdate(int split, float* X, int64_t panel_stride, int64_t batch_stride, int ns, int D, int R, int rows_per_wg, const float* Qfin,
+                     const int* subact, const int* done, int nchunks, int npairs, int batch, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    {
+        const int order = 1;
+        ASVD_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_pair_order), &order, sizeof(int), 0, hipMemcpyHostToDevice));
+    }
+    if (split)
+        supdate_split_kernel<<<dim3(nchunks, npairs, batch), 256, 0, st>>>(X, panel_stride, batch_stride, ns, D, R, rows_per_wg, Qfin, subact, done);
+    else
+        supdate_kernel<<<dim3(nchunks, npairs, batch), 256, 0, st>>>(X, panel_stride, batch_stride, ns, D, R, rows_per_wg, Qfin, subact, done);
+    ASVD_HIP_CHECK(hipGetLastError());
+    return ASVD_OK;
 }
 
 int asvd_svd_batched(int batch, const void* const* a_host, int a_dtype, int64_t m, int64_t n, int64_t lda,

@@ -1,37 +1,41 @@
-// twolevel.h — kernels of the TWO-LEVEL dense sweep (included by svd_jacobi.hip inside its anonymous namespace, after rr_pair).
+// twolevel.h — kernels of the TWO-LEVEL dense sweep (included by svd_jacobi.hip inside its anonymous namespace, after evd_kernel).
 //
 // Why: at panel width 32 a sweep moves (nb-1) x 3 panel passes through HBM and sits on the roofline ridge.  The
 // two-level sweep works on SUPER-PANELS of 64 columns (two adjacent 32-column panels, layout unchanged) under the same XOR
-// schedule, now over ns = nb/2 super-panels.  Per super-pair (S, T) and step:
-//   sgram     one pass over the four panels: the 64x64 CROSS block X_S^T X_T only (fp32 MFMA, row-split partials).  The two
-//             diagonal blocks are CARRIED: every solve leaves G' = Q^T G Q behind, whose diagonal blocks are the Gram blocks of the
-//             updated super-panels; they are refreshed from the data once per sweep (internal step, below).
-//   sassemble G (128x128) = [carried G_SS, cross; cross^T, carried G_TT]
-//   2 inner steps on G alone (no pass over X): 64x64 eigen-solves (evd_kernel, inner mode) of the sub-pairs (S0,T0),(S1,T1) then
-//             (S0,T1),(S1,T0), each followed by gupdate: G <- Q^T G Q, Qacc <- Qacc Q (fp32 MFMA, a few MFLOP)
-//   sfinish   sort the 128 columns by decreasing diagonal (large columns migrate to the lower super-panel), renormalise Qacc's
-//             columns (fp64 norms), store Qfin and the two new carried diagonal blocks
-//   supdate   one pass: [X_S X_T] <- [X_S X_T] Qfin   (128x128, fp32 MFMA, K = 128)
+// schedule, now over ns = nb/2 super-panels.  The four 32-blocks of a super-pair (S, T) are S0, S1, T0, T1 = 0..3.  Per step:
+//   sgram6   ONE pass over the four panels: the four cross tiles [0,2] [0,3] [1,2] [1,3] and the two within tiles [0,1] [2,3]
+//            (fp32 MFMA, row-split partials).  The 32x32 DIAGONAL blocks of the panels are CARRIED: every 64x64 eigen-solve leaves
+//            Q^T G Q behind, whose diagonal blocks are the Gram blocks of the two updated panels; they are refreshed from the data
+//            once per sweep (internal step, below).
+//   evd<1>   inner step 0: sub-pairs (0,2) and (1,3), assembled from the carried blocks and the summed cross tiles
+//   evd<2>   inner step 1: sub-pairs (0,3) and (1,2); their cross blocks are the tile G[{0,2},{1,3}] transformed by the two Q's of
+//            step 0 (two small fp32-MFMA products in the kernel's prologue); the epilogue emits the sub-pair's 128x64 column
+//            block of Qfin = Q^(0) Q^(1) and the new carried diagonal blocks.  No 128x128 Gram matrix is ever formed.
+//   supdate  ONE pass: [X_S X_T] <- [X_S X_T] Qfin   (128x128; split-bf16 or fp32 MFMA, K = 128)
 // The pairs INSIDE a super-panel (2S, 2S+1) are the d = 1 step of the single-level schedule: it runs first in every sweep with the
-// single-level kernels (full 3-block Gram from the data) and its eigen-solve emits the fresh carried block of every super-panel.
-// HBM passes per sweep: 3 (nb/2 - 1) + 3 instead of 3 (nb - 1); MFMA flops 5 R n^2 instead of 7 R n^2 (one cross block per pair
-// instead of three); the number of 64x64 eigen-solves is unchanged (every 32-panel pair still meets exactly once per sweep).
-// CPU prototype (tools/proto_two_level.py, n = 1024): same sweep count as the single-level schedule, slightly ahead per sweep.
+// single-level kernels (full 3-block Gram from the data) and its eigen-solve emits the fresh carried blocks of both panels.
+// HBM passes per sweep: 3 (nb/2 - 1) + 3 instead of 3 (nb - 1); launches per step: 4; the number of 64x64 eigen-solves is
+// unchanged (every 32-panel pair still meets exactly once per sweep).  Each eigen-solve sorts its own 64 columns (larger half to
+// the lower panel); there is no global 128-column sort (CPU prototype tools/proto_two_level.py: same sweep count either way).
 
 constexpr int SW = 64;       // super-panel width
 constexpr int SP = 2 * SW;   // super-pair width
 
-// inner step t, sub-pair sp -> the two 32-blocks (a in {0,1} = S0,S1;  b in {2,3} = T0,T1):  t = 0: (0,2),(1,3);  t = 1: (0,3),(1,2)
-__device__ __forceinline__ void sub_blocks(int t, int sp, int& a, int& b) { a = sp; b = 2 + (sp ^ t); }
+// a super-pair is updated when any of its four eigen-solves rotated
+__device__ __forceinline__ bool pair_active(const int* __restrict__ subact, int64_t slot) {
+    const int* sa = subact + slot * 4;
+    return (sa[0] | sa[1] | sa[2] | sa[3]) != 0;
+}
 
 // --------------------------------------------------------------------------------------------------
-// sgram: partial cross Gram of a super-pair, Gx[split] (64x64 row-major) = X_S[rows]^T X_T[rows].  Same streaming structure as
-// gram_kernel (register prefetch of the next 32-row chunk, wave-private LDS image, one ds_read_b32 per MFMA operand); four panels
-// and four accumulators per wave.
-__global__ __launch_bounds__(256) void sgram_kernel(const float* __restrict__ X, int64_t panel_stride, int64_t batch_stride, int ns, int D,
-                                                    int m_pad, int rows_per_split, float* __restrict__ Gx, const int* __restrict__ done) {
+// sgram6: partial Gram tiles of a super-pair over a row range: Gx6[split][t] (32x32 row-major), t = 0..5 -> [0,2] [0,3] [1,2] [1,3]
+// [0,1] [2,3], tile [x,y] = X_x[rows]^T X_y[rows].  Same streaming structure as gram_kernel (register prefetch of the next 16-row
+// chunk, wave-private LDS image, one ds_read_b32 per MFMA operand); four panels and six accumulators per wave.
+__global__ __launch_bounds__(256) void sgram6_kernel(const float* __restrict__ X, int64_t panel_stride, int64_t batch_stride, int ns, int D,
+                                                     int m_pad, int rows_per_split, float* __restrict__ Gx, const int* __restrict__ done) {
     const int split = blockIdx.x, pair = blockIdx.y, b = blockIdx.z;
     const int nsplit = gridDim.x, npairs = gridDim.y;
+    ASVD_KERNEL_ACQUIRE();
     if (done[b]) return;
     int S, T;
     rr_pair(ns, D - 1, pair, S, T);
@@ -44,13 +48,12 @@ __global__ __launch_bounds__(256) void sgram_kernel(const float* __restrict__ X,
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int r_begin = split * rows_per_split;
     const int r_end = min(r_begin + rows_per_split, m_pad);
-    constexpr int SCH = 16;  // rows per staged chunk: 8 KiB per wave, 32 KiB per workgroup (co-residency with the eigen-solves matters
-                             // more than a deeper per-wave pipeline: several workgroups per CU hide the latency)
+    constexpr int SCH = 16;  // rows per staged chunk: 8 KiB per wave, 32 KiB per workgroup
     const int nchunks = (r_end - r_begin) / SCH;  // m_pad and rows_per_split are multiples of 32
 
     __shared__ __attribute__((aligned(16))) float stage[4][4 * SCH * PB];  // per wave: 16 rows of the four panels
     float* s = stage[w];
-    f32x16 a00 = {0}, a01 = {0}, a10 = {0}, a11 = {0};
+    f32x16 a02 = {0}, a03 = {0}, a12 = {0}, a13 = {0}, a01 = {0}, a23 = {0};
     {
         f32x4 p0[SCH / 8], p1[SCH / 8], p2[SCH / 8], p3[SCH / 8];
         auto fetch = [&](int ch) {
@@ -78,24 +81,26 @@ __global__ __launch_bounds__(256) void sgram_kernel(const float* __restrict__ X,
             for (int u = 0; u < SCH / 2; ++u) {
                 const float x0 = s[0 * (SCH * PB) + u * 64 + lane], x1 = s[1 * (SCH * PB) + u * 64 + lane];
                 const float y0 = s[2 * (SCH * PB) + u * 64 + lane], y1 = s[3 * (SCH * PB) + u * 64 + lane];
-                a00 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, y0, a00, 0, 0, 0);
-                a01 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, y1, a01, 0, 0, 0);
-                a10 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, y0, a10, 0, 0, 0);
-                a11 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, y1, a11, 0, 0, 0);
+                a02 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, y0, a02, 0, 0, 0);
+                a03 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, y1, a03, 0, 0, 0);
+                a12 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, y0, a12, 0, 0, 0);
+                a13 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, y1, a13, 0, 0, 0);
+                a01 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, x1, a01, 0, 0, 0);
+                a23 = __builtin_amdgcn_mfma_f32_32x32x2f32(y0, y1, a23, 0, 0, 0);
             }
         }
     }
-    // cross-wave reduction in a fixed order ((w0 + w2) + (w1 + w3)) through the staging memory, two 32x32 tiles per round
+    // cross-wave reduction in a fixed order ((w0 + w2) + (w1 + w3)) through the staging memory, two tiles per round
     // (4 waves x 2 tiles x 4 KiB = 32 KiB), coalesced store
     float* red = &stage[0][0];
-    float* __restrict__ out = Gx + (((int64_t)b * npairs + pair) * nsplit + split) * (SW * SW);
+    float* __restrict__ out = Gx + (((int64_t)b * npairs + pair) * nsplit + split) * (6 * 1024);
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
+    for (int rnd = 0; rnd < 3; ++rnd) {
         __syncthreads();
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
-            red[w * 2048 + (0 * 16 + reg) * 64 + lane] = half ? a10[reg] : a00[reg];
-            red[w * 2048 + (1 * 16 + reg) * 64 + lane] = half ? a11[reg] : a01[reg];
+            red[w * 2048 + (0 * 16 + reg) * 64 + lane] = rnd == 0 ? a02[reg] : (rnd == 1 ? a12[reg] : a01[reg]);
+            red[w * 2048 + (1 * 16 + reg) * 64 + lane] = rnd == 0 ? a03[reg] : (rnd == 1 ? a13[reg] : a23[reg]);
         }
         __syncthreads();
 #pragma unroll
@@ -103,191 +108,12 @@ __global__ __launch_bounds__(256) void sgram_kernel(const float* __restrict__ X,
             const int p = tid + 256 * q;
             const float v = (red[p] + red[2 * 2048 + p]) + (red[2048 + p] + red[3 * 2048 + p]);
             const int rg = p >> 6, ln = p & 63;
-            const int tile = 2 * half + (rg >> 4), reg = rg & 15;
+            const int tile = 2 * rnd + (rg >> 4), reg = rg & 15;
             const int i = (reg & 3) + 8 * (reg >> 2) + 4 * (ln >> 5), j = ln & 31;
-            out[(32 * (tile >> 1) + i) * SW + 32 * (tile & 1) + j] = v;
+            out[tile * 1024 + i * 32 + j] = v;
         }
     }
-}
-
-// sassemble: G (128x128, row-major) of every super-pair of the step from the carried diagonal blocks and the summed cross partials
-__global__ __launch_bounds__(256) void sassemble_kernel(const float* __restrict__ Gx, int nsplit, const float* __restrict__ Gd, int ns, int D,
-                                                        float* __restrict__ G128, const int* __restrict__ done) {
-    const int pair = blockIdx.x, b = blockIdx.y, npairs = gridDim.x, tid = threadIdx.x;
-    if (done[b]) return;
-    int S, T;
-    rr_pair(ns, D - 1, pair, S, T);
-    if (T >= ns) return;
-    __shared__ float xt[SW][SW + 1];
-    const float* __restrict__ gx = Gx + ((int64_t)b * npairs + pair) * nsplit * (SW * SW);
-    float* __restrict__ G = G128 + ((int64_t)b * npairs + pair) * (SP * SP);
-    const float* __restrict__ dS = Gd + ((int64_t)b * ns + S) * (SW * SW);
-    const float* __restrict__ dT = Gd + ((int64_t)b * ns + T) * (SW * SW);
-#pragma unroll 4
-    for (int q = 0; q < 16; ++q) {
-        const int e = tid + 256 * q, r = e >> 6, c = e & 63;
-        float v = 0.0f;
-        for (int sp = 0; sp < nsplit; ++sp) v += gx[(int64_t)sp * (SW * SW) + e];
-        xt[r][c] = v;
-        G[r * SP + SW + c] = v;
-        G[r * SP + c] = dS[e];
-        G[(SW + r) * SP + SW + c] = dT[e];
-    }
-    __syncthreads();
-#pragma unroll 4
-    for (int q = 0; q < 16; ++q) {
-        const int e = tid + 256 * q, r = e >> 6, c = e & 63;
-        G[(SW + r) * SP + c] = xt[c][r];
-    }
-}
-
-// --------------------------------------------------------------------------------------------------
-// gupdate: after the two eigen-solves of inner step t (Q_0, Q_1 of the sub-pairs), apply them to the 128x128 Gram matrix and to
-// the accumulated transformation.  grid.x = 6: x < 4 -> tile (px, py) of G: G[I_px, I_py] <- Q_px^T G[I_px, I_py] Q_py (gathered
-// 64x64, two 64^3 products, in place: a tile depends only on itself); x = 4, 5 -> Qacc[:, I_px] <- Qacc[:, I_px] Q_px (128x64;
-// `first`: Qacc is the identity and is written from scratch).  One 32x32 output block per wave, fp32 MFMA, operands from LDS.
-constexpr int GLD = 68;
-__global__ __launch_bounds__(256) void gupdate_kernel(float* __restrict__ G128, float* __restrict__ Qacc, const float* __restrict__ Qsub,
-                                                      const int* __restrict__ subact, int ns, int D, int inner_t, int first,
-                                                      const int* __restrict__ done) {
-    const int x = blockIdx.x, pair = blockIdx.y, b = blockIdx.z, npairs = gridDim.y;
-    if (done[b]) return;
-    int S, T;
-    rr_pair(ns, D - 1, pair, S, T);
-    if (T >= ns) return;
-    const int* sa = subact + ((int64_t)b * npairs + pair) * 4 + inner_t * 2;
-    const bool act[2] = {sa[0] != 0, sa[1] != 0};
-    __shared__ float M[SW * GLD], QX[SW * GLD], QY[SW * GLD], T1[SW * GLD];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, c = lane & 31;
-    const int wi = w >> 1, wj = w & 1;
-    const int64_t slot = (int64_t)b * npairs + pair;
-    if (x < 4) {
-        const int px = x >> 1, py = x & 1;
-        if (!act[px] && !act[py]) return;  // both factors are the identity
-        int ax, bx, ay, by;
-        sub_blocks(inner_t, px, ax, bx);
-        sub_blocks(inner_t, py, ay, by);
-        float* __restrict__ G = G128 + slot * (SP * SP);
-        const float* __restrict__ qx = Qsub + (slot * 2 + px) * (SW * SW);
-        const float* __restrict__ qy = Qsub + (slot * 2 + py) * (SW * SW);
-#pragma unroll 4
-        for (int q = 0; q < 16; ++q) {
-            const int e = tid + 256 * q, r = e >> 6, cc = e & 63;
-            const int gr = 32 * (r < 32 ? ax : bx) + (r & 31), gc = 32 * (cc < 32 ? ay : by) + (cc & 31);
-            M[r * GLD + cc] = G[gr * SP + gc];
-            QX[r * GLD + cc] = qx[e];
-            QY[r * GLD + cc] = qy[e];
-        }
-        __syncthreads();
-        f32x16 acc = {0};
-#pragma unroll 8
-        for (int k2 = 0; k2 < 32; ++k2) {
-            const int k = 2 * k2 + h;
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(M[(32 * wi + c) * GLD + k], QY[k * GLD + 32 * wj + c], acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int i = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-            T1[(32 * wi + i) * GLD + 32 * wj + c] = acc[reg];
-        }
-        __syncthreads();
-        acc = (f32x16){0};
-#pragma unroll 8
-        for (int k2 = 0; k2 < 32; ++k2) {
-            const int k = 2 * k2 + h;
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(QX[k * GLD + 32 * wi + c], T1[k * GLD + 32 * wj + c], acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int i = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-            const int r = 32 * wi + i, cc = 32 * wj + c;
-            const int gr = 32 * (r < 32 ? ax : bx) + (r & 31), gc = 32 * (cc < 32 ? ay : by) + (cc & 31);
-            G[gr * SP + gc] = acc[reg];
-        }
-    } else {
-        const int px = x - 4;
-        if (!act[px] && !first) return;
-        int ax, bx;
-        sub_blocks(inner_t, px, ax, bx);
-        float* __restrict__ Qa = Qacc + slot * (SP * SP);
-        const float* __restrict__ qx = Qsub + (slot * 2 + px) * (SW * SW);
-#pragma unroll 4
-        for (int q = 0; q < 16; ++q) {
-            const int e = tid + 256 * q, r = e >> 6, cc = e & 63;
-            QX[r * GLD + cc] = qx[e];
-        }
-        for (int rh = 0; rh < 2; ++rh) {
-            __syncthreads();  // QX loaded / previous half's M consumed
-#pragma unroll 4
-            for (int q = 0; q < 16; ++q) {
-                const int e = tid + 256 * q, r = e >> 6, cc = e & 63;
-                const int gc = 32 * (cc < 32 ? ax : bx) + (cc & 31);
-                M[r * GLD + cc] = first ? ((64 * rh + r == gc) ? 1.0f : 0.0f) : Qa[(64 * rh + r) * SP + gc];
-            }
-            __syncthreads();
-            f32x16 acc = {0};
-#pragma unroll 8
-            for (int k2 = 0; k2 < 32; ++k2) {
-                const int k = 2 * k2 + h;
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(M[(32 * wi + c) * GLD + k], QX[k * GLD + 32 * wj + c], acc, 0, 0, 0);
-            }
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int i = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                const int cc = 32 * wj + c;
-                const int gc = 32 * (cc < 32 ? ax : bx) + (cc & 31);
-                Qa[(64 * rh + 32 * wi + i) * SP + gc] = acc[reg];
-            }
-        }
-    }
-}
-
-// sfinish: sort by decreasing diagonal, renormalise the accumulated transformation, emit Qfin and the carried diagonal blocks
-__global__ __launch_bounds__(256) void sfinish_kernel(const float* __restrict__ G128, const float* __restrict__ Qacc, float* __restrict__ Qfin,
-                                                      float* __restrict__ Gd, const int* __restrict__ subact, int* __restrict__ active_s, int ns,
-                                                      int D, const int* __restrict__ done) {
-    const int pair = blockIdx.x, b = blockIdx.y, npairs = gridDim.x, tid = threadIdx.x;
-    if (done[b]) return;
-    int S, T;
-    rr_pair(ns, D - 1, pair, S, T);
-    const int64_t slot = (int64_t)b * npairs + pair;
-    if (T >= ns) { if (tid == 0) active_s[slot] = 0; return; }
-    const int* sa = subact + slot * 4;
-    if (!(sa[0] | sa[1] | sa[2] | sa[3])) { if (tid == 0) active_s[slot] = 0; return; }  // nothing rotated: X and the carried blocks stay
-    __shared__ float d[SP], cs[SP];
-    __shared__ int rnk[SP];
-    __shared__ double part[2][SP];
-    const float* __restrict__ G = G128 + slot * (SP * SP);
-    const float* __restrict__ Qa = Qacc + slot * (SP * SP);
-    if (tid < SP) d[tid] = G[tid * SP + tid];
-    {
-        const int col = tid & (SP - 1), half = tid >> 7;
-        double acc = 0.0;
-        for (int r = 0; r < 64; ++r) { const double v = Qa[(64 * half + r) * SP + col]; acc += v * v; }
-        part[half][col] = acc;
-    }
-    __syncthreads();
-    if (tid < SP) {
-        const double sq = part[0][tid] + part[1][tid];
-        cs[tid] = sq > 0.0 ? (float)(1.0 / sqrt(sq)) : 1.0f;
-        const float me = d[tid];
-        int cnt = 0;
-        for (int i = 0; i < SP; ++i) { const float o = d[i]; cnt += (o > me || (o == me && i < tid)) ? 1 : 0; }
-        rnk[tid] = cnt;
-    }
-    __syncthreads();
-    float* __restrict__ Qf = Qfin + slot * (SP * SP);
-    float* __restrict__ gS = Gd + ((int64_t)b * ns + S) * (SW * SW);
-    float* __restrict__ gT = Gd + ((int64_t)b * ns + T) * (SW * SW);
-    for (int q = 0; q < 64; ++q) {
-        const int e = tid + 256 * q, r = e >> 7, cc = e & 127;
-        const int rr = rnk[r], rc = rnk[cc];
-        Qf[r * SP + rc] = Qa[e] * cs[cc];
-        const float v = G[e] * cs[r] * cs[cc];
-        if (rr < SW && rc < SW) gS[rr * SW + rc] = v;
-        else if (rr >= SW && rc >= SW) gT[(rr - SW) * SW + rc - SW] = v;
-    }
-    if (tid == 0) active_s[slot] = 1;
+    ASVD_KERNEL_RELEASE();
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -297,9 +123,10 @@ __global__ __launch_bounds__(256) void sfinish_kernel(const float* __restrict__ 
 constexpr int ULD = SP + 4;  // LDS row stride in floats (528 B: conflict-free b128 row-per-lane reads)
 __global__ __launch_bounds__(256, 2) void supdate_kernel(float* __restrict__ X, int64_t panel_stride, int64_t batch_stride, int ns, int D,
                                                          int R, int rows_per_wg, const float* __restrict__ Qfin,
-                                                         const int* __restrict__ active_s, const int* __restrict__ done) {
+                                                         const int* __restrict__ subact, const int* __restrict__ done) {
     const int chunk = blockIdx.x, pair = blockIdx.y, b = blockIdx.z, npairs = gridDim.y;
-    if (done[b] || !active_s[(int64_t)b * npairs + pair]) return;
+    ASVD_KERNEL_ACQUIRE();
+    if (done[b] || !pair_active(subact, (int64_t)b * npairs + pair)) return;
     int S, T;
     rr_pair(ns, D - 1, pair, S, T);
     if (T >= ns) return;
@@ -360,6 +187,7 @@ __global__ __launch_bounds__(256, 2) void supdate_kernel(float* __restrict__ X, 
         __syncthreads();
         cur ^= 1;
     }
+    ASVD_KERNEL_RELEASE();
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -384,9 +212,10 @@ __device__ __forceinline__ void split3(float x0, float x1, unsigned& p1, unsigne
 
 __global__ __launch_bounds__(256, 2) void supdate_split_kernel(float* __restrict__ X, int64_t panel_stride, int64_t batch_stride, int ns,
                                                                int D, int R, int rows_per_wg, const float* __restrict__ Qfin,
-                                                               const int* __restrict__ active_s, const int* __restrict__ done) {
+                                                               const int* __restrict__ subact, const int* __restrict__ done) {
     const int chunk = blockIdx.x, pair = blockIdx.y, b = blockIdx.z, npairs = gridDim.y;
-    if (done[b] || !active_s[(int64_t)b * npairs + pair]) return;
+    ASVD_KERNEL_ACQUIRE();
+    if (done[b] || !pair_active(subact, (int64_t)b * npairs + pair)) return;
     int S, T;
     rr_pair(ns, D - 1, pair, S, T);
     if (T >= ns) return;
@@ -471,4 +300,6 @@ __global__ __launch_bounds__(256, 2) void supdate_split_kernel(float* __restrict
         __syncthreads();
         cur ^= 1;
     }
+    ASVD_KERNEL_RELEASE();
 }
+

@@ -1,6 +1,7 @@
 """torch-tensor front end of the C ABI (include/asvd_hip.h).  torch is used for device memory and streams only —
 every arithmetic step below runs in libasvd_hip.so.  Tensors must live on a gfx950 device; nothing falls back to CPU."""
 import ctypes
+import os
 
 import torch
 
@@ -31,7 +32,11 @@ def _ptr(t):
 
 
 def _work(nbytes, device):
-    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+    w = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+    fill = os.environ.get("ASVD_DEBUG_WORKFILL")  # debug: poison (255 -> NaN patterns) or zero the workspace to expose reads of unwritten memory
+    if fill is not None:
+        w.fill_(int(fill))
+    return w
 
 
 def absstat_accum(x2d, acc, method):

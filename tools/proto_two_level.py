@@ -55,6 +55,7 @@ def sweep_single(A, stats, dup=0):
 
 
 NB = int(sys.argv[4]) if len(sys.argv) > 4 else 2  # panels per super-panel
+GLOBAL_SORT = not (len(sys.argv) > 5 and sys.argv[5] == "nosort")
 
 
 def super_pair(A, S, T, stats, full):
@@ -78,7 +79,7 @@ def super_pair(A, S, T, stats, full):
                 G[idx, :] = Q.T @ G[idx, :]
                 Qacc[:, idx] = Qacc[:, idx] @ Q
     if rotated:
-        perm = np.argsort(-np.diag(G), kind="stable")
+        perm = np.argsort(-np.diag(G), kind="stable") if GLOBAL_SORT else np.arange(G.shape[0])
         A[:, cols] = Pn @ Qacc[:, perm]
         stats[1] += 1
 
