@@ -302,30 +302,38 @@ __device__ __forceinline__ void store_diag_blocks(const float* G, const int* rnk
     }
 }
 
-template <int MODE, int KEEPG>
-__global__ __launch_bounds__(256, 4) void evd_kernel(const float* __restrict__ Gpart, int nsplit, float* __restrict__ Qbuf,
-                                                   int* __restrict__ active, unsigned* __restrict__ maxoff_bits,
-                                                   int* __restrict__ nrot, const int* __restrict__ done, float tol,
-                                                   int inner_sweeps, int nb, int step, int kb, int* __restrict__ hist,
-                                                   const int* __restrict__ plist, int list_stride, EvdV3 v3) {
-    static_assert(MODE == 0 || KEEPG == 1, "the two-level modes read G after the solve");
-    __shared__ __attribute__((aligned(16))) float G[PW * PW];
-    __shared__ __attribute__((aligned(16))) float Qs[KEEPG ? PW * PW : 4];
-    float* Q = KEEPG ? Qs : G;
-    __shared__ float sdiag[2][PW];
-    __shared__ float sb[2][32];
-    __shared__ float redmax[4];
-    __shared__ float cscale[PW];
-    __shared__ int rnk[PW];
+// block coordinates of a kernel body: the bodies below run either as their own launch or as one half of a merged launch (dual
+// kernels further down), so they take their grid position as data instead of reading blockIdx / gridDim
+struct BlockCtx { int bx, by, bz, gx, gy, gz; };
 
-    const int pair = MODE ? (blockIdx.x >> 1) : blockIdx.x, b = blockIdx.y, npairs = MODE ? (gridDim.x >> 1) : gridDim.x;
+constexpr int EVD_SMEM_FLOATS(int keepg) { return (keepg ? 2 : 1) * PW * PW + 2 * PW + 64 + 8 + PW + PW; }
+
+template <int MODE, int KEEPG>
+__device__ __forceinline__ void evd_body(const BlockCtx& ctx, float* __restrict__ smem, const float* __restrict__ Gpart, int nsplit,
+                                         float* __restrict__ Qbuf, int* __restrict__ active, unsigned* __restrict__ maxoff_bits,
+                                         int* __restrict__ nrot, const int* __restrict__ done, float tol, int inner_sweeps, int nb, int step,
+                                         int kb, int* __restrict__ hist, const int* __restrict__ plist, int list_stride, const EvdV3& v3) {
+    static_assert(MODE == 0 || KEEPG == 1, "the two-level modes read G after the solve");
+    // LDS carve-up (EVD_SMEM_FLOATS): G, [Qs], sdiag[2][64], sb[2][32], redmax[4], redmax_t[4], cscale[64], rnk[64]
+    float* G = smem;
+    float* Qs = smem + PW * PW;
+    float* Q = KEEPG ? Qs : G;
+    float* small = smem + (KEEPG ? 2 : 1) * PW * PW;
+    float (*sdiag)[PW] = (float (*)[PW])small;
+    float (*sb)[32] = (float (*)[32])(small + 2 * PW);
+    float* redmax = small + 2 * PW + 64;
+    float* redmax_t = redmax + 4;
+    float* cscale = redmax + 8;
+    int* rnk = (int*)(cscale + PW);
+
+    const int pair = MODE ? (ctx.bx >> 1) : ctx.bx, b = ctx.by, npairs = MODE ? (ctx.gx >> 1) : ctx.gx;
     ASVD_KERNEL_ACQUIRE();
     if (done[b]) return;
     // the eigen-solve is a dependent chain of short VALU/LDS phases on every group's critical path: let its waves win the issue
     // arbitration against the matrix-pipe-bound gram/update waves of the other stream groups that share the SIMD
     __builtin_amdgcn_s_setprio(3);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int sp = MODE ? (blockIdx.x & 1) : 0;
+    const int sp = MODE ? (ctx.bx & 1) : 0;
     const int64_t slot = (int64_t)b * npairs + pair;
     int I, J;        // the two 32-column panels of this solve
     int* act_flag;   // where this solve reports whether it rotated
@@ -494,7 +502,6 @@ __global__ __launch_bounds__(256, 4) void evd_kernel(const float* __restrict__ G
             }
         }
     }
-    __shared__ float redmax_t[4];
     {
         float v = loc, vt = loct;
 #pragma unroll
@@ -740,6 +747,18 @@ __global__ __launch_bounds__(256, 4) void evd_kernel(const float* __restrict__ G
         }
     }
     ASVD_KERNEL_RELEASE();
+}
+
+template <int MODE, int KEEPG>
+__global__ __launch_bounds__(256, 4) void evd_kernel(const float* __restrict__ Gpart, int nsplit, float* __restrict__ Qbuf,
+                                                   int* __restrict__ active, unsigned* __restrict__ maxoff_bits,
+                                                   int* __restrict__ nrot, const int* __restrict__ done, float tol,
+                                                   int inner_sweeps, int nb, int step, int kb, int* __restrict__ hist,
+                                                   const int* __restrict__ plist, int list_stride, EvdV3 v3) {
+    __shared__ __attribute__((aligned(16))) float smem[EVD_SMEM_FLOATS(KEEPG)];
+    const BlockCtx ctx{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, (int)gridDim.y, (int)gridDim.z};
+    evd_body<MODE, KEEPG>(ctx, smem, Gpart, nsplit, Qbuf, active, maxoff_bits, nrot, done, tol, inner_sweeps, nb, step, kb, hist, plist,
+                          list_stride, v3);
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -1743,7 +1762,7 @@ int make_plan(int batch, int64_t m, int64_t n, int want_u, int want_vv, Plan& p)
         int pw2 = 2;
         while (pw2 < p.ns) pw2 <<= 1;
         p.npairs_s = pw2 / 2;
-        const int launch_batch = (int)ceil_div64(batch, stream_groups_for(batch));
+        const int launch_batch = stream_groups_for(batch) > 1 ? (int)ceil_div64(batch, stream_groups_for(batch)) : (batch + 1) / 2;  // one stream: two pipelined halves
         // sgram6: 3 workgroups (32 KiB LDS, ~150 VGPRs) per CU -> 768 slots; 16-row chunks per wave, same cost model as the single-level Gram
         const int64_t nchunk_total = p.m_pad / 32;
         int64_t best_ns = 1;
@@ -1959,7 +1978,7 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
     {
         const int order = pair_order_xor() ? 1 : 0;
         ASVD_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_pair_order), &order, sizeof(int), 0, hipMemcpyHostToDevice));
-        const int fence = stream_groups_for(batch) > 1 ? 1 : 0;
+        const int fence = (stream_groups_for(batch) > 1 || getenv("ASVD_DBG_FENCE")) ? 1 : 0;
         ASVD_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_fence), &fence, sizeof(int), 0, hipMemcpyHostToDevice));
     }
     const int nsteps = pair_order_xor() ? 2 * p.npairs - 1 : p.nb - 1;
@@ -2016,7 +2035,11 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
     const bool sparse_allowed = pair_order_xor() && p.nb >= 8 && !(getenv("ASVD_SPARSE") && atoi(getenv("ASVD_SPARSE")) == 0);
     const double sparse_frac = getenv("ASVD_SPARSE_FRAC") ? atof(getenv("ASVD_SPARSE_FRAC")) : 0.5;
     bool sparse = false;
-    const bool split_check = getenv("ASVD_SPLIT") && atoi(getenv("ASVD_SPLIT")) == 1;
+    // split-bf16 arithmetic (twolevel.h) for the update pass and the coupling snapshot: on unless ASVD_SPLIT=0; the pipelined dual
+    // launches need it (their update body is the split-bf16 one) and can be switched off separately with ASVD_PIPE=0
+    const bool split_on = !(getenv("ASVD_SPLIT") && atoi(getenv("ASVD_SPLIT")) == 0);
+    const bool split_piped = split_on && !(getenv("ASVD_PIPE") && atoi(getenv("ASVD_PIPE")) == 0);
+    const bool split_check = split_on;
     std::vector<unsigned char> hflag;
     std::vector<int> hlist;
     std::vector<int> sl_off((size_t)MAXG * (nsteps > 0 ? nsteps : 1), 0), sl_cnt((size_t)MAXG * (nsteps > 0 ? nsteps : 1), 0);
@@ -2173,13 +2196,92 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
                 }
             }
         }
-        if (two_now) {
+        // pipelined two-level sweep (twolevel.h "dual launches"): two halves of the batch, two phases apart, on ONE stream
+        const bool piped = two_now && ngroups == 1 && batch >= 2 && split_piped;
+        if (piped) {
             const int nsuper = 2 * p.npairs_s - 1;
-            const bool split_bf16 = getenv("ASVD_SPLIT") && atoi(getenv("ASVD_SPLIT")) == 1;
+            const int dup2 = std::min(nsuper, getenv("ASVD_DUP2") ? atoi(getenv("ASVD_DUP2")) : 0);
+            std::vector<int> seq;
+            for (int di = 0; di < nsuper + dup2; ++di) seq.push_back(di < dup2 ? di + 1 : di - dup2 + 1);
+            if (getenv("ASVD_DBG_MAXD")) seq.resize(std::min<size_t>(seq.size(), (size_t)atoi(getenv("ASVD_DBG_MAXD"))));
+            const int L = (int)seq.size();
+            const int hb0[2] = {0, (batch + 1) / 2}, hnb[2] = {(batch + 1) / 2, batch / 2};
+            auto solve_args = [&](int h, int D) {
+                SolveArgs a{};
+                const int b0 = hb0[h];
+                a.maxoff = maxoff + b0; a.nrot = nrot + b0; a.done = done + b0; a.tol = tol; a.inner_sweeps = inner_sweeps; a.nb = p.nb;
+                a.step = D - 1; a.kb = kb; a.hist = hist_dev;
+                a.v3.ns = p.ns; a.v3.nbpan = p.nb; a.v3.nsplit6 = p.nsplit_s;
+                a.v3.Gx6 = (float*)(wb + p.off_gx6) + (int64_t)b0 * p.npairs_s * p.nsplit_s * 6 * 1024;
+                a.v3.Gd32 = (float*)(wb + p.off_gd32) + (int64_t)b0 * p.nb * 1024;
+                a.v3.Q0 = (float*)(wb + p.off_q0) + (int64_t)b0 * p.npairs_s * 2 * PW * PW;
+                a.v3.D0 = (float*)(wb + p.off_d0) + (int64_t)b0 * p.npairs_s * 4 * 1024;
+                a.v3.Qfin = (float*)(wb + p.off_qfin) + (int64_t)b0 * p.npairs_s * SP * SP;
+                a.v3.subact = (int*)(wb + p.off_subact) + (int64_t)b0 * p.npairs_s * 4;
+                a.gx = 2 * p.npairs_s; a.gy = hnb[h];
+                return a;
+            };
+            for (int slot = 0; slot < 4 * L + 2; ++slot) {
+                // the (at most) two operations of this slot: half 0 runs operation `slot`, half 1 operation `slot - 2`
+                int sh = -1, sD = 0, sphase = 0, th = -1, tD = 0, tphase = 0;  // solve part (E1 / E2), streaming part (G / U)
+                for (int h = 0; h < 2; ++h) {
+                    const int op = slot - 2 * h;
+                    if (op < 0 || op >= 4 * L || hnb[h] == 0) continue;
+                    const int ph = op & 3, D = seq[op >> 2];
+                    if (ph == 1 || ph == 2) { sh = h; sD = D; sphase = ph; }
+                    else { th = h; tD = D; tphase = ph; }
+                }
+                SolveArgs sa{};
+                if (sh >= 0) sa = solve_args(sh, sD);
+                const int nsolve = sa.gx * sa.gy;
+                const bool gram_slot = (th >= 0) ? (tphase == 0) : (sphase == 2);  // E2 pairs with G, E1 with U
+                if (gram_slot) {
+                    GramArgs ga{};
+                    if (th >= 0) {
+                        const int b0 = hb0[th];
+                        ga.X = X + (int64_t)b0 * p.batch_stride; ga.panel_stride = p.panel_stride; ga.batch_stride = p.batch_stride; ga.ns = p.ns;
+                        ga.D = tD; ga.m_pad = p.m_pad; ga.rows_per_split = p.rows_per_split_s;
+                        ga.Gx = (float*)(wb + p.off_gx6) + (int64_t)b0 * p.npairs_s * p.nsplit_s * 6 * 1024;
+                        ga.done = done + b0; ga.gx = p.nsplit_s; ga.gy = p.npairs_s; ga.gz = hnb[th];
+                    }
+                    const int nblk = nsolve + ga.gx * ga.gy * ga.gz;
+                    ProfScope ps(1, st);
+                    if (getenv("ASVD_DBG_SEPARATE") && (atoi(getenv("ASVD_DBG_SEPARATE")) & 1)) {
+                        if (nsolve) dual_gram_kernel<2><<<nsolve, 256, 0, st>>>(sa, GramArgs{});
+                        if (nblk > nsolve) dual_gram_kernel<2><<<nblk - nsolve, 256, 0, st>>>(SolveArgs{}, ga);
+                    } else if (sh >= 0 && sphase == 1) dual_gram_kernel<1><<<nblk, 256, 0, st>>>(sa, ga);
+                    else dual_gram_kernel<2><<<nblk, 256, 0, st>>>(sa, ga);
+                } else {
+                    UpdArgs ua{};
+                    if (th >= 0) {
+                        const int b0 = hb0[th];
+                        ua.X = X + (int64_t)b0 * p.batch_stride; ua.panel_stride = p.panel_stride; ua.batch_stride = p.batch_stride; ua.ns = p.ns;
+                        ua.D = tD; ua.R = p.R_upd; ua.rows_per_wg = p.rows_per_wg_s;
+                        ua.Qfin = (float*)(wb + p.off_qfin) + (int64_t)b0 * p.npairs_s * SP * SP;
+                        ua.subact = (int*)(wb + p.off_subact) + (int64_t)b0 * p.npairs_s * 4;
+                        ua.done = done + b0; ua.gx = p.nchunks_s; ua.gy = p.npairs_s; ua.gz = hnb[th];
+                    }
+                    const int nblk = nsolve + ua.gx * ua.gy * ua.gz;
+                    ProfScope ps(3, st);
+                    if (getenv("ASVD_DBG_SEPARATE") && (atoi(getenv("ASVD_DBG_SEPARATE")) & 2)) {
+                        if (nsolve) dual_upd_kernel<1><<<nsolve, 256, 0, st>>>(sa, UpdArgs{});
+                        if (nblk > nsolve) dual_upd_kernel<1><<<nblk - nsolve, 256, 0, st>>>(SolveArgs{}, ua);
+                    } else if (getenv("ASVD_DBG_SEPARATE") && (atoi(getenv("ASVD_DBG_SEPARATE")) & 4)) {
+                        if (nblk > nsolve) dual_upd_kernel<1><<<nblk - nsolve, 256, 0, st>>>(SolveArgs{}, ua);
+                        if (nsolve) dual_upd_kernel<1><<<nsolve, 256, 0, st>>>(sa, UpdArgs{});
+                    } else if (sh >= 0 && sphase == 2) dual_upd_kernel<2><<<nblk, 256, 0, st>>>(sa, ua);
+                    else dual_upd_kernel<1><<<nblk, 256, 0, st>>>(sa, ua);
+                }
+                if (getenv("ASVD_DBG_SYNC")) (void)hipStreamSynchronize(st);
+            }
+        } else if (two_now) {
+            const int nsuper = 2 * p.npairs_s - 1;
+            const bool split_bf16 = split_on;
             const int dbg_sync = getenv("ASVD_DBG_SYNC") ? atoi(getenv("ASVD_DBG_SYNC")) : 0;
             // local super-levels D = 1..L run twice at the start of the sweep (the two-level form of ASVD_DUP; ASVD_DUP2=L)
             const int dup2 = std::min(nsuper, getenv("ASVD_DUP2") ? atoi(getenv("ASVD_DUP2")) : 0);
-            for (int di = 0; di < nsuper + dup2; ++di) {
+            const int dbg_maxd = getenv("ASVD_DBG_MAXD") ? atoi(getenv("ASVD_DBG_MAXD")) : (1 << 30);
+            for (int di = 0; di < std::min(nsuper + dup2, dbg_maxd); ++di) {
                 const int D = di < dup2 ? di + 1 : di - dup2 + 1;
                 for (int g = 0; g < ngroups; ++g) {
                     const int b0 = gb0[g], nbg = gnb[g];
@@ -2222,6 +2324,70 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
                     }
                     if (dbg_sync & 1) (void)hipStreamSynchronize(s2);
                 }
+            }
+        }
+        if (getenv("ASVD_DBG_SELFTEST") && two_now && batch >= 3 && sweep == 0) {
+            // debug: is the step-0 eigen-solve of half 1 reproducible when the update of half 0 runs in the same launch?
+            const int hb0[2] = {0, (batch + 1) / 2}, hnb[2] = {(batch + 1) / 2, batch / 2};
+            const int D = 5;
+            auto mk_solve = [&](int h) {
+                SolveArgs a{};
+                const int b0 = hb0[h];
+                a.maxoff = maxoff + b0; a.nrot = nrot + b0; a.done = done + b0; a.tol = tol; a.inner_sweeps = inner_sweeps; a.nb = p.nb;
+                a.step = D - 1; a.kb = kb; a.hist = nullptr;
+                a.v3.ns = p.ns; a.v3.nbpan = p.nb; a.v3.nsplit6 = p.nsplit_s;
+                a.v3.Gx6 = (float*)(wb + p.off_gx6) + (int64_t)b0 * p.npairs_s * p.nsplit_s * 6 * 1024;
+                a.v3.Gd32 = (float*)(wb + p.off_gd32) + (int64_t)b0 * p.nb * 1024;
+                a.v3.Q0 = (float*)(wb + p.off_q0) + (int64_t)b0 * p.npairs_s * 2 * PW * PW;
+                a.v3.D0 = (float*)(wb + p.off_d0) + (int64_t)b0 * p.npairs_s * 4 * 1024;
+                a.v3.Qfin = (float*)(wb + p.off_qfin) + (int64_t)b0 * p.npairs_s * SP * SP;
+                a.v3.subact = (int*)(wb + p.off_subact) + (int64_t)b0 * p.npairs_s * 4;
+                a.gx = 2 * p.npairs_s; a.gy = hnb[h];
+                return a;
+            };
+            // fresh Gram tiles of step D for half 1
+            GramArgs ga{};
+            {
+                const int b0 = hb0[1];
+                ga.X = X + (int64_t)b0 * p.batch_stride; ga.panel_stride = p.panel_stride; ga.batch_stride = p.batch_stride; ga.ns = p.ns;
+                ga.D = D; ga.m_pad = p.m_pad; ga.rows_per_split = p.rows_per_split_s;
+                ga.Gx = (float*)(wb + p.off_gx6) + (int64_t)b0 * p.npairs_s * p.nsplit_s * 6 * 1024;
+                ga.done = done + b0; ga.gx = p.nsplit_s; ga.gy = p.npairs_s; ga.gz = hnb[1];
+            }
+            dual_gram_kernel<2><<<ga.gx * ga.gy * ga.gz, 256, 0, st>>>(SolveArgs{}, ga);
+            SolveArgs s1 = mk_solve(1);
+            const size_t nq = (size_t)hnb[1] * p.npairs_s * 2 * PW * PW;
+            std::vector<float> qa(nq), qb(nq);
+            dual_upd_kernel<1><<<s1.gx * s1.gy, 256, 0, st>>>(s1, UpdArgs{});
+            ASVD_HIP_CHECK(hipMemcpyAsync(qa.data(), s1.v3.Q0, nq * sizeof(float), hipMemcpyDeviceToHost, st));
+            ASVD_HIP_CHECK(hipStreamSynchronize(st));
+            UpdArgs ua{};
+            ua.X = X; ua.panel_stride = p.panel_stride; ua.batch_stride = p.batch_stride; ua.ns = p.ns; ua.D = 7; ua.R = p.R_upd;
+            ua.rows_per_wg = p.rows_per_wg_s; ua.Qfin = (float*)(wb + p.off_qfin); ua.subact = (int*)(wb + p.off_subact); ua.done = done;
+            ua.gx = p.nchunks_s; ua.gy = p.npairs_s; ua.gz = hnb[0];
+            if (getenv("ASVD_DBG_UR")) ua.R = atoi(getenv("ASVD_DBG_UR"));
+            const size_t ngx = (size_t)hnb[1] * p.npairs_s * p.nsplit_s * 6 * 1024, ngd = (size_t)hnb[1] * p.nb * 1024;
+            std::vector<float> gx0(ngx), gx1(ngx), gd0(ngd), gd1(ngd);
+            ASVD_HIP_CHECK(hipMemcpy(gx0.data(), s1.v3.Gx6, ngx * 4, hipMemcpyDeviceToHost));
+            ASVD_HIP_CHECK(hipMemcpy(gd0.data(), s1.v3.Gd32, ngd * 4, hipMemcpyDeviceToHost));
+            for (int rep = 0; rep < 3; ++rep) {
+                if (rep == 2) {  // update alone, then the solve alone
+                    dual_upd_kernel<1><<<ua.gx * ua.gy * ua.gz, 256, 0, st>>>(SolveArgs{}, ua);
+                    dual_upd_kernel<1><<<s1.gx * s1.gy, 256, 0, st>>>(s1, UpdArgs{});
+                } else
+                dual_upd_kernel<1><<<s1.gx * s1.gy + ua.gx * ua.gy * ua.gz, 256, 0, st>>>(s1, ua);
+                ASVD_HIP_CHECK(hipMemcpyAsync(gx1.data(), s1.v3.Gx6, ngx * 4, hipMemcpyDeviceToHost, st));
+                ASVD_HIP_CHECK(hipMemcpyAsync(gd1.data(), s1.v3.Gd32, ngd * 4, hipMemcpyDeviceToHost, st));
+                ASVD_HIP_CHECK(hipStreamSynchronize(st));
+                fprintf(stderr, "[selftest] rep %d: inputs changed? Gx6 %d Gd32 %d\n", rep, memcmp(gx0.data(), gx1.data(), ngx * 4) != 0,
+                        memcmp(gd0.data(), gd1.data(), ngd * 4) != 0);
+                ASVD_HIP_CHECK(hipMemcpyAsync(qb.data(), s1.v3.Q0, nq * sizeof(float), hipMemcpyDeviceToHost, st));
+                ASVD_HIP_CHECK(hipStreamSynchronize(st));
+                size_t bad = 0, firstbad = 0;
+                for (size_t i = 0; i < nq; ++i)
+                    if (memcmp(&qa[i], &qb[i], 4) != 0) { if (!bad) firstbad = i; ++bad; }
+                fprintf(stderr, "[selftest] rep %d: Q0 of half 1 alone vs combined with update: %zu of %zu floats differ (first at %zu: slot %zu, elem %zu)\n",
+                        rep, bad, nq, firstbad, firstbad / 4096, firstbad % 4096);
             }
         }
         if (ngroups >= 2) {

@@ -31,10 +31,12 @@ __device__ __forceinline__ bool pair_active(const int* __restrict__ subact, int6
 // sgram6: partial Gram tiles of a super-pair over a row range: Gx6[split][t] (32x32 row-major), t = 0..5 -> [0,2] [0,3] [1,2] [1,3]
 // [0,1] [2,3], tile [x,y] = X_x[rows]^T X_y[rows].  Same streaming structure as gram_kernel (register prefetch of the next 16-row
 // chunk, wave-private LDS image, one ds_read_b32 per MFMA operand); four panels and six accumulators per wave.
-__global__ __launch_bounds__(256) void sgram6_kernel(const float* __restrict__ X, int64_t panel_stride, int64_t batch_stride, int ns, int D,
-                                                     int m_pad, int rows_per_split, float* __restrict__ Gx, const int* __restrict__ done) {
-    const int split = blockIdx.x, pair = blockIdx.y, b = blockIdx.z;
-    const int nsplit = gridDim.x, npairs = gridDim.y;
+constexpr int SGRAM6_SMEM_FLOATS = 4 * 4 * 16 * PB;  // 32 KiB
+__device__ __forceinline__ void sgram6_body(const BlockCtx& ctx, float* __restrict__ smem, const float* __restrict__ X, int64_t panel_stride,
+                                            int64_t batch_stride, int ns, int D, int m_pad, int rows_per_split, float* __restrict__ Gx,
+                                            const int* __restrict__ done) {
+    const int split = ctx.bx, pair = ctx.by, b = ctx.bz;
+    const int nsplit = ctx.gx, npairs = ctx.gy;
     ASVD_KERNEL_ACQUIRE();
     if (done[b]) return;
     int S, T;
@@ -51,7 +53,7 @@ __global__ __launch_bounds__(256) void sgram6_kernel(const float* __restrict__ X
     constexpr int SCH = 16;  // rows per staged chunk: 8 KiB per wave, 32 KiB per workgroup
     const int nchunks = (r_end - r_begin) / SCH;  // m_pad and rows_per_split are multiples of 32
 
-    __shared__ __attribute__((aligned(16))) float stage[4][4 * SCH * PB];  // per wave: 16 rows of the four panels
+    float (*stage)[4 * SCH * PB] = (float (*)[4 * SCH * PB])smem;  // per wave: 16 rows of the four panels
     float* s = stage[w];
     f32x16 a02 = {0}, a03 = {0}, a12 = {0}, a13 = {0}, a01 = {0}, a23 = {0};
     {
@@ -114,6 +116,13 @@ __global__ __launch_bounds__(256) void sgram6_kernel(const float* __restrict__ X
         }
     }
     ASVD_KERNEL_RELEASE();
+}
+
+__global__ __launch_bounds__(256) void sgram6_kernel(const float* __restrict__ X, int64_t panel_stride, int64_t batch_stride, int ns, int D,
+                                                     int m_pad, int rows_per_split, float* __restrict__ Gx, const int* __restrict__ done) {
+    __shared__ __attribute__((aligned(16))) float smem[SGRAM6_SMEM_FLOATS];
+    const BlockCtx ctx{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, (int)gridDim.y, (int)gridDim.z};
+    sgram6_body(ctx, smem, X, panel_stride, batch_stride, ns, D, m_pad, rows_per_split, Gx, done);
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -210,10 +219,11 @@ __device__ __forceinline__ void split3(float x0, float x1, unsigned& p1, unsigne
     p3 = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
 }
 
-__global__ __launch_bounds__(256, 2) void supdate_split_kernel(float* __restrict__ X, int64_t panel_stride, int64_t batch_stride, int ns,
-                                                               int D, int R, int rows_per_wg, const float* __restrict__ Qfin,
-                                                               const int* __restrict__ subact, const int* __restrict__ done) {
-    const int chunk = blockIdx.x, pair = blockIdx.y, b = blockIdx.z, npairs = gridDim.y;
+constexpr int SUPDATE_SMEM_FLOATS = 2 * 32 * ULD;  // 33 KiB
+__device__ __forceinline__ void supdate_split_body(const BlockCtx& ctx, float* __restrict__ smem, float* __restrict__ X, int64_t panel_stride,
+                                                   int64_t batch_stride, int ns, int D, int R, int rows_per_wg, const float* __restrict__ Qfin,
+                                                   const int* __restrict__ subact, const int* __restrict__ done) {
+    const int chunk = ctx.bx, pair = ctx.by, b = ctx.bz, npairs = ctx.gy;
     ASVD_KERNEL_ACQUIRE();
     if (done[b] || !pair_active(subact, (int64_t)b * npairs + pair)) return;
     int S, T;
@@ -242,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void supdate_split_kernel(float* __restrict
     }
     float* __restrict__ Pw = (w == 0) ? P0 : (w == 1) ? P1 : (w == 2) ? P2 : P3;
 
-    __shared__ __attribute__((aligned(16))) float tile[2][32 * ULD];
+    float (*tile)[32 * ULD] = (float (*)[32 * ULD])smem;
     const int r_begin = chunk * rows_per_wg;
     const int r_end = min(r_begin + rows_per_wg, R);
     if (r_begin >= r_end) return;
@@ -269,7 +279,7 @@ __global__ __launch_bounds__(256, 2) void supdate_split_kernel(float* __restrict
         const bool more = r0 + 32 < r_end;
         if (more) fetch(r0 + 32);
         const float* my = tile[cur] + c * ULD + 8 * h;
-        f32x16 accA = {0}, accB = {0};  // leading term / correction terms
+        f32x16 acc = {0};  // one accumulator: the small terms of a k-step go in first
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             const f32x4 v0 = *(const f32x4*)(my + 16 * s);
@@ -284,17 +294,17 @@ __global__ __launch_bounds__(256, 2) void supdate_split_kernel(float* __restrict
             }
             const bf16x8 A1 = __builtin_bit_cast(bf16x8, a1), A2 = __builtin_bit_cast(bf16x8, a2), A3 = __builtin_bit_cast(bf16x8, a3);
             const bf16x8 B1 = __builtin_bit_cast(bf16x8, q1[s]), B2 = __builtin_bit_cast(bf16x8, q2[s]), B3 = __builtin_bit_cast(bf16x8, q3[s]);
-            accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B1, accA, 0, 0, 0);
-            accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B2, accB, 0, 0, 0);
-            accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, B1, accB, 0, 0, 0);
-            accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, B2, accB, 0, 0, 0);
-            accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B3, accB, 0, 0, 0);
-            accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A3, B1, accB, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A3, B1, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B3, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, B2, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, B1, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B2, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B1, acc, 0, 0, 0);
         }
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int i = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-            Pw[(int64_t)(r0 + i) * PB + c] = accA[reg] + accB[reg];
+            Pw[(int64_t)(r0 + i) * PB + c] = acc[reg];
         }
         if (more) stash(tile[cur ^ 1]);
         __syncthreads();
@@ -303,3 +313,84 @@ __global__ __launch_bounds__(256, 2) void supdate_split_kernel(float* __restrict
     ASVD_KERNEL_RELEASE();
 }
 
+__global__ __launch_bounds__(256, 2) void supdate_split_kernel(float* __restrict__ X, int64_t panel_stride, int64_t batch_stride, int ns,
+                                                               int D, int R, int rows_per_wg, const float* __restrict__ Qfin,
+                                                               const int* __restrict__ subact, const int* __restrict__ done) {
+    __shared__ __attribute__((aligned(16))) float smem[SUPDATE_SMEM_FLOATS];
+    const BlockCtx ctx{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, (int)gridDim.y, (int)gridDim.z};
+    supdate_split_body(ctx, smem, X, panel_stride, batch_stride, ns, D, R, rows_per_wg, Qfin, subact, done);
+}
+
+// ==================================================================================================
+// Dual launches: software pipelining on ONE stream.  The four phases of a super-step — Gram pass (G), eigen-solves of inner step 0
+// and 1 (E1, E2), update pass (U) — are bound by different resources: G and U stream panels through HBM and the matrix pipe, E1 and
+// E2 are chains of short VALU/LDS phases on a few hundred workgroups.  Run back to back on one stream each phase leaves the other
+// resource idle (and several streams are not an option, common.h).  The batch is therefore cut into two halves that run two phases
+// apart, and every launch carries the streaming phase of one half TOGETHER with the solve phase of the other:
+//     slot:   0    1    2     3     4     5     6   ...
+//     half 0: G1   E1   E2    U1    G2    E1    E2
+//     half 1: -    -    G1    E1    E2    U1    G2          ->  launches  [G|E2]  [U|E1]  [G|E2]  [U|E1] ...
+// Blocks [0, nsolve) of a dual launch run the solve body (dispatched first: they are the long-latency ones), the rest the streaming
+// body; both bodies are the ones of the stand-alone kernels above.  Kernel boundaries on a single stream keep every dependency: a
+// phase only consumes what the previous launch (or an earlier one) of the same half produced.
+struct SolveArgs {
+    unsigned* maxoff;
+    int* nrot;
+    const int* done;
+    float tol;
+    int inner_sweeps, nb, step, kb;
+    int* hist;
+    EvdV3 v3;
+    int gx, gy;  // grid of the solve part: (2 * super-pair slots, problems of its half); gy = 0: no solve part
+};
+struct GramArgs {
+    const float* X;
+    int64_t panel_stride, batch_stride;
+    int ns, D, m_pad, rows_per_split;
+    float* Gx;
+    const int* done;
+    int gx, gy, gz;  // (row splits, super-pair slots, problems); gz = 0: no streaming part
+};
+struct UpdArgs {
+    float* X;
+    int64_t panel_stride, batch_stride;
+    int ns, D, R, rows_per_wg;
+    const float* Qfin;
+    const int* subact;
+    const int* done;
+    int gx, gy, gz;
+};
+constexpr int DUAL_SMEM_FLOATS = EVD_SMEM_FLOATS(1) > SUPDATE_SMEM_FLOATS ? EVD_SMEM_FLOATS(1) : SUPDATE_SMEM_FLOATS;
+static_assert(DUAL_SMEM_FLOATS >= SGRAM6_SMEM_FLOATS, "LDS of the dual kernels");
+
+template <int EMODE>
+__global__ __launch_bounds__(256, 3) void dual_gram_kernel(SolveArgs sa, GramArgs ga) {
+    __shared__ __attribute__((aligned(16))) float smem[DUAL_SMEM_FLOATS];
+    int id = blockIdx.x;
+    const int nsolve = sa.gx * sa.gy;
+    if (id < nsolve) {
+        const BlockCtx ctx{id % sa.gx, id / sa.gx, 0, sa.gx, sa.gy, 1};
+        evd_body<EMODE, 1>(ctx, smem, nullptr, 0, nullptr, nullptr, sa.maxoff, sa.nrot, sa.done, sa.tol, sa.inner_sweeps, sa.nb, sa.step, sa.kb,
+                           sa.hist, nullptr, 0, sa.v3);
+    } else {
+        id -= nsolve;
+        const BlockCtx ctx{id % ga.gx, (id / ga.gx) % ga.gy, id / (ga.gx * ga.gy), ga.gx, ga.gy, ga.gz};
+        sgram6_body(ctx, smem, ga.X, ga.panel_stride, ga.batch_stride, ga.ns, ga.D, ga.m_pad, ga.rows_per_split, ga.Gx, ga.done);
+    }
+}
+
+template <int EMODE>
+__global__ __launch_bounds__(256, 2) void dual_upd_kernel(SolveArgs sa, UpdArgs ua) {
+    __shared__ __attribute__((aligned(16))) float smem[DUAL_SMEM_FLOATS];
+    int id = blockIdx.x;
+    const int nsolve = sa.gx * sa.gy;
+    if (id < nsolve) {
+        const BlockCtx ctx{id % sa.gx, id / sa.gx, 0, sa.gx, sa.gy, 1};
+        evd_body<EMODE, 1>(ctx, smem, nullptr, 0, nullptr, nullptr, sa.maxoff, sa.nrot, sa.done, sa.tol, sa.inner_sweeps, sa.nb, sa.step, sa.kb,
+                           sa.hist, nullptr, 0, sa.v3);
+    } else {
+        id -= nsolve;
+        const BlockCtx ctx{id % ua.gx, (id / ua.gx) % ua.gy, id / (ua.gx * ua.gy), ua.gx, ua.gy, ua.gz};
+        supdate_split_body(ctx, smem, ua.X, ua.panel_stride, ua.batch_stride, ua.ns, ua.D, ua.R, ua.rows_per_wg, ua.Qfin, ua.subact, ua.done);
+    }
+}

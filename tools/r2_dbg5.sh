@@ -1,5 +1,5 @@
 #!/bin/bash
-for cfg in "B=16 ASVD_SPLIT=1" "B=16 ASVD_SPLIT=1 ASVD_DBG_SYNC=4" "B=16 ASVD_SPLIT=0"; do
+for cfg in "B=16" "B=15" "B=16 ASVD_PIPE=0"; do
 echo "== $cfg"
 env $cfg timeout 600 python - <<'PY' 2>&1 | grep -E "^SW"
 import torch, sys, os
