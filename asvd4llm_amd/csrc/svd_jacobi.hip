@@ -1796,7 +1796,7 @@ int make_plan(int batch, int64_t m, int64_t n, int want_u, int want_vv, Plan& p)
     p.off_ina = take((size_t)batch * p.n_pad * sizeof(float));
     p.off_inv = take((size_t)batch * p.n_pad * sizeof(float));
     p.off_perm = take((size_t)batch * p.n_pad * sizeof(int));
-    p.off_flags = take((size_t)batch * 4 * sizeof(int));  // [maxoff bits | nrot | done | pad] x batch (SoA)
+    p.off_flags = take((size_t)batch * 4 * sizeof(int));  // [maxoff bits | nrot | done | super-pair updates] x batch (SoA)
     p.off_pflag = take((size_t)batch * p.nb * p.nb);      // sparse-sweep pair marks
     p.off_plist = take((size_t)batch * p.nb * p.nb * sizeof(int));  // per-step lists of marked pairs (bound: steps x nb/2 slots per problem)
     const size_t t2 = p.two ? 1 : 0;
@@ -1812,9 +1812,12 @@ int make_plan(int batch, int64_t m, int64_t n, int want_u, int want_vv, Plan& p)
 
 // ---- optional per-class timing with HIP events on the call's stream ------------------------------
 bool g_prof_enabled = false;
-float g_prof_ms[6] = {0, 0, 0, 0, 0, 0};
-int g_prof_launches[6] = {0, 0, 0, 0, 0, 0};
-long long g_prof_pairs[2] = {0, 0};
+// classes: 0 pack / reduce, 1 two-level Gram pass, 2 eigen-solves, 3 two-level update pass, 4 finalize, 5 coupling snapshot,
+//          6 single-level Gram, 7 single-level update
+constexpr int NPROF = 8;
+float g_prof_ms[NPROF] = {0};
+int g_prof_launches[NPROF] = {0};
+long long g_prof_pairs[3] = {0, 0, 0};  // 32-panel pair visits, rotated 32-panel pairs, updated super-pairs (two-level sweeps)
 std::vector<float> g_prof_sweep_ms;       // wall time of every sweep of the last profiled call (all problems of the batch together)
 std::vector<long long> g_prof_sweep_rot;  // pairs rotated in it  // {pair visits (gram), rotated pairs (evd + update)} of the last profiled call
 struct ProfRec { int cls; hipEvent_t a, b; };
@@ -1830,8 +1833,8 @@ struct ProfScope {
     }
 };
 void prof_begin() {
-    for (int i = 0; i < 6; ++i) { g_prof_ms[i] = 0; g_prof_launches[i] = 0; }
-    g_prof_pairs[0] = g_prof_pairs[1] = 0;
+    for (int i = 0; i < NPROF; ++i) { g_prof_ms[i] = 0; g_prof_launches[i] = 0; }
+    g_prof_pairs[0] = g_prof_pairs[1] = g_prof_pairs[2] = 0;
     g_prof_sweep_ms.clear();
     g_prof_sweep_rot.clear();
     g_prof_recs.clear();
@@ -1880,12 +1883,13 @@ int asvd_svd_get_pair_counts(long long* counts_host) {
     if (!counts_host) return ASVD_E_BADARG;
     counts_host[0] = g_prof_pairs[0];
     counts_host[1] = g_prof_pairs[1];
+    counts_host[2] = g_prof_pairs[2];
     return ASVD_OK;
 }
 
 int asvd_svd_get_profile(float* ms_host, int* launches_host) {
     if (!ms_host || !launches_host) return ASVD_E_BADARG;
-    for (int i = 0; i < 6; ++i) { ms_host[i] = g_prof_ms[i]; launches_host[i] = g_prof_launches[i]; }
+    for (int i = 0; i < NPROF; ++i) { ms_host[i] = g_prof_ms[i]; launches_host[i] = g_prof_launches[i]; }
     return ASVD_OK;
 }
 
@@ -1941,6 +1945,7 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
     int* perm = (int*)(wb + p.off_perm);
     unsigned* maxoff = (unsigned*)(wb + p.off_flags);
     int* nrot = (int*)(wb + p.off_flags) + batch;
+    int* nupd = (int*)(wb + p.off_flags) + 3 * batch;  // instrumentation: super-pair updates of the sweep
     int* done = (int*)(wb + p.off_flags) + 2 * batch;
 
     if (g_prof_enabled && manage_profile) prof_begin();
@@ -1978,7 +1983,7 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
     {
         const int order = pair_order_xor() ? 1 : 0;
         ASVD_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_pair_order), &order, sizeof(int), 0, hipMemcpyHostToDevice));
-        const int fence = (stream_groups_for(batch) > 1 || getenv("ASVD_DBG_FENCE")) ? 1 : 0;
+        const int fence = stream_groups_for(batch) > 1 ? 1 : 0;
         ASVD_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_fence), &fence, sizeof(int), 0, hipMemcpyHostToDevice));
     }
     const int nsteps = pair_order_xor() ? 2 * p.npairs - 1 : p.nb - 1;
@@ -2035,10 +2040,11 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
     const bool sparse_allowed = pair_order_xor() && p.nb >= 8 && !(getenv("ASVD_SPARSE") && atoi(getenv("ASVD_SPARSE")) == 0);
     const double sparse_frac = getenv("ASVD_SPARSE_FRAC") ? atof(getenv("ASVD_SPARSE_FRAC")) : 0.5;
     bool sparse = false;
-    // split-bf16 arithmetic (twolevel.h) for the update pass and the coupling snapshot: on unless ASVD_SPLIT=0; the pipelined dual
-    // launches need it (their update body is the split-bf16 one) and can be switched off separately with ASVD_PIPE=0
+    // split-bf16 arithmetic (twolevel.h) for the update pass and the coupling snapshot: on unless ASVD_SPLIT=0.
+    // ASVD_PIPE=1 (opt-in, measured slower: 77 vs 69 ms per dense sweep of 16 x 4096^2) rides the eigen-solves of one half of the batch
+    // on the Gram launches of the other half (twolevel.h "dual launches").
     const bool split_on = !(getenv("ASVD_SPLIT") && atoi(getenv("ASVD_SPLIT")) == 0);
-    const bool split_piped = split_on && !(getenv("ASVD_PIPE") && atoi(getenv("ASVD_PIPE")) == 0);
+    const bool split_piped = split_on && getenv("ASVD_PIPE") && atoi(getenv("ASVD_PIPE")) == 1;
     const bool split_check = split_on;
     std::vector<unsigned char> hflag;
     std::vector<int> hlist;
@@ -2051,6 +2057,7 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
         for (int g = 0; g < ngroups; ++g) {  // maxoff, nrot of this group's problems
             ASVD_HIP_CHECK(hipMemsetAsync(maxoff + gb0[g], 0, (size_t)gnb[g] * sizeof(int), gst[g]));
             ASVD_HIP_CHECK(hipMemsetAsync(nrot + gb0[g], 0, (size_t)gnb[g] * sizeof(int), gst[g]));
+            ASVD_HIP_CHECK(hipMemsetAsync(nupd + gb0[g], 0, (size_t)gnb[g] * sizeof(int), gst[g]));
         }
         long long marked_total = 0;
         if (sparse) {
@@ -2145,7 +2152,7 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
                     const int rpw = (int)(ceil_div64(iters, nc) * 128);
                     const int nch = (int)ceil_div64(p.R_upd, rpw);
                     {
-                        ProfScope ps(1, s2);
+                        ProfScope ps(6, s2);
                         gram_kernel<<<dim3(nsp, slots, nbg), 256, 0, s2>>>(Xg, p.panel_stride, p.batch_stride, p.nb, step, p.m_pad, rps, Gg,
                                                                            done + b0, pl, slots);
                     }
@@ -2155,7 +2162,7 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
                                                                            p.nb, step, kb, hist_dev, pl, slots, EvdV3{});
                     }
                     {
-                        ProfScope ps(3, s2);
+                        ProfScope ps(7, s2);
                         update_kernel<<<dim3(nch, slots, nbg), 256, 0, s2>>>(Xg, p.panel_stride, p.batch_stride, p.nb, step, p.R_upd, rpw, Qg,
                                                                              ag, done + b0, pl, slots);
                     }
@@ -2164,7 +2171,7 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
                 const bool gram_here = !p.fused || (sweep == 0 && step == 0);
                 const int ns_here = gram_here ? p.nsplit : p.nchunks_f;
                 if (gram_here) {
-                    ProfScope ps(1, s2);
+                    ProfScope ps(6, s2);
                     gram_kernel<<<dim3(p.nsplit, p.npairs, nbg), 256, 0, s2>>>(Xg, p.panel_stride, p.batch_stride, p.nb, step, p.m_pad,
                                                                                p.rows_per_split, Gg, done + b0, nullptr, 0);
                 }
@@ -2183,7 +2190,7 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
                     }
                 }
                 {
-                    ProfScope ps(3, s2);
+                    ProfScope ps(7, s2);
                     if (p.fused) {
                         const int d = step + 1, e = (step + 1 < nsteps) ? step + 2 : 1;
                         upgram_kernel<<<dim3(p.nchunks_f, p.nb / 4, nbg), 256, 0, s2>>>(Xg, p.panel_stride, p.batch_stride, p.nb, d, e,
@@ -2203,7 +2210,6 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
             const int dup2 = std::min(nsuper, getenv("ASVD_DUP2") ? atoi(getenv("ASVD_DUP2")) : 0);
             std::vector<int> seq;
             for (int di = 0; di < nsuper + dup2; ++di) seq.push_back(di < dup2 ? di + 1 : di - dup2 + 1);
-            if (getenv("ASVD_DBG_MAXD")) seq.resize(std::min<size_t>(seq.size(), (size_t)atoi(getenv("ASVD_DBG_MAXD"))));
             const int L = (int)seq.size();
             const int hb0[2] = {0, (batch + 1) / 2}, hnb[2] = {(batch + 1) / 2, batch / 2};
             auto solve_args = [&](int h, int D) {
@@ -2221,67 +2227,56 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
                 a.gx = 2 * p.npairs_s; a.gy = hnb[h];
                 return a;
             };
-            for (int slot = 0; slot < 4 * L + 2; ++slot) {
-                // the (at most) two operations of this slot: half 0 runs operation `slot`, half 1 operation `slot - 2`
-                int sh = -1, sD = 0, sphase = 0, th = -1, tD = 0, tphase = 0;  // solve part (E1 / E2), streaming part (G / U)
-                for (int h = 0; h < 2; ++h) {
-                    const int op = slot - 2 * h;
-                    if (op < 0 || op >= 4 * L || hnb[h] == 0) continue;
-                    const int ph = op & 3, D = seq[op >> 2];
-                    if (ph == 1 || ph == 2) { sh = h; sD = D; sphase = ph; }
-                    else { th = h; tD = D; tphase = ph; }
-                }
-                SolveArgs sa{};
-                if (sh >= 0) sa = solve_args(sh, sD);
-                const int nsolve = sa.gx * sa.gy;
-                const bool gram_slot = (th >= 0) ? (tphase == 0) : (sphase == 2);  // E2 pairs with G, E1 with U
-                if (gram_slot) {
-                    GramArgs ga{};
-                    if (th >= 0) {
-                        const int b0 = hb0[th];
-                        ga.X = X + (int64_t)b0 * p.batch_stride; ga.panel_stride = p.panel_stride; ga.batch_stride = p.batch_stride; ga.ns = p.ns;
-                        ga.D = tD; ga.m_pad = p.m_pad; ga.rows_per_split = p.rows_per_split_s;
-                        ga.Gx = (float*)(wb + p.off_gx6) + (int64_t)b0 * p.npairs_s * p.nsplit_s * 6 * 1024;
-                        ga.done = done + b0; ga.gx = p.nsplit_s; ga.gy = p.npairs_s; ga.gz = hnb[th];
-                    }
-                    const int nblk = nsolve + ga.gx * ga.gy * ga.gz;
-                    ProfScope ps(1, st);
-                    if (getenv("ASVD_DBG_SEPARATE") && (atoi(getenv("ASVD_DBG_SEPARATE")) & 1)) {
-                        if (nsolve) dual_gram_kernel<2><<<nsolve, 256, 0, st>>>(sa, GramArgs{});
-                        if (nblk > nsolve) dual_gram_kernel<2><<<nblk - nsolve, 256, 0, st>>>(SolveArgs{}, ga);
-                    } else if (sh >= 0 && sphase == 1) dual_gram_kernel<1><<<nblk, 256, 0, st>>>(sa, ga);
-                    else dual_gram_kernel<2><<<nblk, 256, 0, st>>>(sa, ga);
+            auto gram_args = [&](int h, int D, int part) {  // part 0 / 1: lower / upper half of the pair slots; 2: all
+                GramArgs ga{};
+                const int b0 = hb0[h];
+                ga.X = X + (int64_t)b0 * p.batch_stride; ga.panel_stride = p.panel_stride; ga.batch_stride = p.batch_stride; ga.ns = p.ns;
+                ga.D = D; ga.m_pad = p.m_pad; ga.rows_per_split = p.rows_per_split_s;
+                ga.Gx = (float*)(wb + p.off_gx6) + (int64_t)b0 * p.npairs_s * p.nsplit_s * 6 * 1024;
+                ga.done = done + b0; ga.gx = p.nsplit_s; ga.gz = hnb[h]; ga.npairs = p.npairs_s;
+                const int lo = p.npairs_s / 2;
+                ga.pair0 = (part == 1) ? lo : 0;
+                ga.gy = (part == 2) ? p.npairs_s : (part == 0 ? lo : p.npairs_s - lo);
+                return ga;
+            };
+            auto launch_gs = [&](const SolveArgs& sa, const GramArgs& ga, int emode) {
+                const int nblk = sa.gx * sa.gy + ga.gx * ga.gy * ga.gz;
+                if (nblk == 0) return;
+                ProfScope ps(emode ? 2 : 1, st);
+                if (emode == 1) dual_gram_kernel<1><<<nblk, 256, 0, st>>>(sa, ga);
+                else dual_gram_kernel<2><<<nblk, 256, 0, st>>>(sa, ga);
+            };
+            auto launch_u = [&](int h, int D) {
+                const int b0 = hb0[h];
+                ProfScope ps(3, st);
+                supdate_split_kernel<<<dim3(p.nchunks_s, p.npairs_s, hnb[h]), 256, 0, st>>>(
+                    X + (int64_t)b0 * p.batch_stride, p.panel_stride, p.batch_stride, p.ns, D, p.R_upd, p.rows_per_wg_s,
+                    (float*)(wb + p.off_qfin) + (int64_t)b0 * p.npairs_s * SP * SP, (int*)(wb + p.off_subact) + (int64_t)b0 * p.npairs_s * 4,
+                    done + b0, nupd + b0);
+            };
+            const GramArgs nog{};
+            const SolveArgs nos{};
+            launch_gs(nos, gram_args(1, seq[0], 2), 0);  // prologue: Gram tiles of the first step for half 1
+            for (int i = 0; i < L; ++i) {
+                const int D = seq[i];
+                launch_gs(solve_args(1, D), gram_args(0, D, 0), 1);   // [Ga(h0) | E1(h1)]
+                launch_gs(solve_args(1, D), gram_args(0, D, 1), 2);   // [Gb(h0) | E2(h1)]
+                launch_u(1, D);
+                if (i + 1 < L) {
+                    launch_gs(solve_args(0, D), gram_args(1, seq[i + 1], 0), 1);   // [Ga'(h1) | E1(h0)]
+                    launch_gs(solve_args(0, D), gram_args(1, seq[i + 1], 1), 2);   // [Gb'(h1) | E2(h0)]
                 } else {
-                    UpdArgs ua{};
-                    if (th >= 0) {
-                        const int b0 = hb0[th];
-                        ua.X = X + (int64_t)b0 * p.batch_stride; ua.panel_stride = p.panel_stride; ua.batch_stride = p.batch_stride; ua.ns = p.ns;
-                        ua.D = tD; ua.R = p.R_upd; ua.rows_per_wg = p.rows_per_wg_s;
-                        ua.Qfin = (float*)(wb + p.off_qfin) + (int64_t)b0 * p.npairs_s * SP * SP;
-                        ua.subact = (int*)(wb + p.off_subact) + (int64_t)b0 * p.npairs_s * 4;
-                        ua.done = done + b0; ua.gx = p.nchunks_s; ua.gy = p.npairs_s; ua.gz = hnb[th];
-                    }
-                    const int nblk = nsolve + ua.gx * ua.gy * ua.gz;
-                    ProfScope ps(3, st);
-                    if (getenv("ASVD_DBG_SEPARATE") && (atoi(getenv("ASVD_DBG_SEPARATE")) & 2)) {
-                        if (nsolve) dual_upd_kernel<1><<<nsolve, 256, 0, st>>>(sa, UpdArgs{});
-                        if (nblk > nsolve) dual_upd_kernel<1><<<nblk - nsolve, 256, 0, st>>>(SolveArgs{}, ua);
-                    } else if (getenv("ASVD_DBG_SEPARATE") && (atoi(getenv("ASVD_DBG_SEPARATE")) & 4)) {
-                        if (nblk > nsolve) dual_upd_kernel<1><<<nblk - nsolve, 256, 0, st>>>(SolveArgs{}, ua);
-                        if (nsolve) dual_upd_kernel<1><<<nsolve, 256, 0, st>>>(sa, UpdArgs{});
-                    } else if (sh >= 0 && sphase == 2) dual_upd_kernel<2><<<nblk, 256, 0, st>>>(sa, ua);
-                    else dual_upd_kernel<1><<<nblk, 256, 0, st>>>(sa, ua);
+                    launch_gs(solve_args(0, D), nog, 1);
+                    launch_gs(solve_args(0, D), nog, 2);
                 }
-                if (getenv("ASVD_DBG_SYNC")) (void)hipStreamSynchronize(st);
+                launch_u(0, D);
             }
         } else if (two_now) {
             const int nsuper = 2 * p.npairs_s - 1;
             const bool split_bf16 = split_on;
-            const int dbg_sync = getenv("ASVD_DBG_SYNC") ? atoi(getenv("ASVD_DBG_SYNC")) : 0;
             // local super-levels D = 1..L run twice at the start of the sweep (the two-level form of ASVD_DUP; ASVD_DUP2=L)
             const int dup2 = std::min(nsuper, getenv("ASVD_DUP2") ? atoi(getenv("ASVD_DUP2")) : 0);
-            const int dbg_maxd = getenv("ASVD_DBG_MAXD") ? atoi(getenv("ASVD_DBG_MAXD")) : (1 << 30);
-            for (int di = 0; di < std::min(nsuper + dup2, dbg_maxd); ++di) {
+            for (int di = 0; di < nsuper + dup2; ++di) {
                 const int D = di < dup2 ? di + 1 : di - dup2 + 1;
                 for (int g = 0; g < ngroups; ++g) {
                     const int b0 = gb0[g], nbg = gnb[g];
@@ -2303,91 +2298,23 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
                         sgram6_kernel<<<dim3(p.nsplit_s, p.npairs_s, nbg), 256, 0, s2>>>(Xg, p.panel_stride, p.batch_stride, p.ns, D, p.m_pad,
                                                                                         p.rows_per_split_s, Gx6g, done + b0);
                     }
-                    if (dbg_sync & 4) (void)hipStreamSynchronize(s2);
                     {
                         ProfScope ps(2, s2);
                         evd_kernel<1, 1><<<dim3(2 * p.npairs_s, nbg), 256, 0, s2>>>(nullptr, 0, nullptr, nullptr, maxoff + b0, nrot + b0, done + b0, tol,
                                                                                    inner_sweeps, p.nb, D - 1, kb, hist_dev, nullptr, 0, v3);
-                        if (dbg_sync & 8) (void)hipStreamSynchronize(s2);
                         evd_kernel<2, 1><<<dim3(2 * p.npairs_s, nbg), 256, 0, s2>>>(nullptr, 0, nullptr, nullptr, maxoff + b0, nrot + b0, done + b0, tol,
                                                                                    inner_sweeps, p.nb, D - 1, kb, hist_dev, nullptr, 0, v3);
                     }
-                    if (dbg_sync & 2) (void)hipStreamSynchronize(s2);
                     {
                         ProfScope ps(3, s2);
                         if (split_bf16)
                             supdate_split_kernel<<<dim3(p.nchunks_s, p.npairs_s, nbg), 256, 0, s2>>>(Xg, p.panel_stride, p.batch_stride, p.ns, D,
-                                                                                                    p.R_upd, p.rows_per_wg_s, v3.Qfin, v3.subact, done + b0);
+                                                                                                    p.R_upd, p.rows_per_wg_s, v3.Qfin, v3.subact, done + b0, nupd + b0);
                         else
                             supdate_kernel<<<dim3(p.nchunks_s, p.npairs_s, nbg), 256, 0, s2>>>(Xg, p.panel_stride, p.batch_stride, p.ns, D, p.R_upd,
-                                                                                              p.rows_per_wg_s, v3.Qfin, v3.subact, done + b0);
+                                                                                              p.rows_per_wg_s, v3.Qfin, v3.subact, done + b0, nupd + b0);
                     }
-                    if (dbg_sync & 1) (void)hipStreamSynchronize(s2);
                 }
-            }
-        }
-        if (getenv("ASVD_DBG_SELFTEST") && two_now && batch >= 3 && sweep == 0) {
-            // debug: is the step-0 eigen-solve of half 1 reproducible when the update of half 0 runs in the same launch?
-            const int hb0[2] = {0, (batch + 1) / 2}, hnb[2] = {(batch + 1) / 2, batch / 2};
-            const int D = 5;
-            auto mk_solve = [&](int h) {
-                SolveArgs a{};
-                const int b0 = hb0[h];
-                a.maxoff = maxoff + b0; a.nrot = nrot + b0; a.done = done + b0; a.tol = tol; a.inner_sweeps = inner_sweeps; a.nb = p.nb;
-                a.step = D - 1; a.kb = kb; a.hist = nullptr;
-                a.v3.ns = p.ns; a.v3.nbpan = p.nb; a.v3.nsplit6 = p.nsplit_s;
-                a.v3.Gx6 = (float*)(wb + p.off_gx6) + (int64_t)b0 * p.npairs_s * p.nsplit_s * 6 * 1024;
-                a.v3.Gd32 = (float*)(wb + p.off_gd32) + (int64_t)b0 * p.nb * 1024;
-                a.v3.Q0 = (float*)(wb + p.off_q0) + (int64_t)b0 * p.npairs_s * 2 * PW * PW;
-                a.v3.D0 = (float*)(wb + p.off_d0) + (int64_t)b0 * p.npairs_s * 4 * 1024;
-                a.v3.Qfin = (float*)(wb + p.off_qfin) + (int64_t)b0 * p.npairs_s * SP * SP;
-                a.v3.subact = (int*)(wb + p.off_subact) + (int64_t)b0 * p.npairs_s * 4;
-                a.gx = 2 * p.npairs_s; a.gy = hnb[h];
-                return a;
-            };
-            // fresh Gram tiles of step D for half 1
-            GramArgs ga{};
-            {
-                const int b0 = hb0[1];
-                ga.X = X + (int64_t)b0 * p.batch_stride; ga.panel_stride = p.panel_stride; ga.batch_stride = p.batch_stride; ga.ns = p.ns;
-                ga.D = D; ga.m_pad = p.m_pad; ga.rows_per_split = p.rows_per_split_s;
-                ga.Gx = (float*)(wb + p.off_gx6) + (int64_t)b0 * p.npairs_s * p.nsplit_s * 6 * 1024;
-                ga.done = done + b0; ga.gx = p.nsplit_s; ga.gy = p.npairs_s; ga.gz = hnb[1];
-            }
-            dual_gram_kernel<2><<<ga.gx * ga.gy * ga.gz, 256, 0, st>>>(SolveArgs{}, ga);
-            SolveArgs s1 = mk_solve(1);
-            const size_t nq = (size_t)hnb[1] * p.npairs_s * 2 * PW * PW;
-            std::vector<float> qa(nq), qb(nq);
-            dual_upd_kernel<1><<<s1.gx * s1.gy, 256, 0, st>>>(s1, UpdArgs{});
-            ASVD_HIP_CHECK(hipMemcpyAsync(qa.data(), s1.v3.Q0, nq * sizeof(float), hipMemcpyDeviceToHost, st));
-            ASVD_HIP_CHECK(hipStreamSynchronize(st));
-            UpdArgs ua{};
-            ua.X = X; ua.panel_stride = p.panel_stride; ua.batch_stride = p.batch_stride; ua.ns = p.ns; ua.D = 7; ua.R = p.R_upd;
-            ua.rows_per_wg = p.rows_per_wg_s; ua.Qfin = (float*)(wb + p.off_qfin); ua.subact = (int*)(wb + p.off_subact); ua.done = done;
-            ua.gx = p.nchunks_s; ua.gy = p.npairs_s; ua.gz = hnb[0];
-            if (getenv("ASVD_DBG_UR")) ua.R = atoi(getenv("ASVD_DBG_UR"));
-            const size_t ngx = (size_t)hnb[1] * p.npairs_s * p.nsplit_s * 6 * 1024, ngd = (size_t)hnb[1] * p.nb * 1024;
-            std::vector<float> gx0(ngx), gx1(ngx), gd0(ngd), gd1(ngd);
-            ASVD_HIP_CHECK(hipMemcpy(gx0.data(), s1.v3.Gx6, ngx * 4, hipMemcpyDeviceToHost));
-            ASVD_HIP_CHECK(hipMemcpy(gd0.data(), s1.v3.Gd32, ngd * 4, hipMemcpyDeviceToHost));
-            for (int rep = 0; rep < 3; ++rep) {
-                if (rep == 2) {  // update alone, then the solve alone
-                    dual_upd_kernel<1><<<ua.gx * ua.gy * ua.gz, 256, 0, st>>>(SolveArgs{}, ua);
-                    dual_upd_kernel<1><<<s1.gx * s1.gy, 256, 0, st>>>(s1, UpdArgs{});
-                } else
-                dual_upd_kernel<1><<<s1.gx * s1.gy + ua.gx * ua.gy * ua.gz, 256, 0, st>>>(s1, ua);
-                ASVD_HIP_CHECK(hipMemcpyAsync(gx1.data(), s1.v3.Gx6, ngx * 4, hipMemcpyDeviceToHost, st));
-                ASVD_HIP_CHECK(hipMemcpyAsync(gd1.data(), s1.v3.Gd32, ngd * 4, hipMemcpyDeviceToHost, st));
-                ASVD_HIP_CHECK(hipStreamSynchronize(st));
-                fprintf(stderr, "[selftest] rep %d: inputs changed? Gx6 %d Gd32 %d\n", rep, memcmp(gx0.data(), gx1.data(), ngx * 4) != 0,
-                        memcmp(gd0.data(), gd1.data(), ngd * 4) != 0);
-                ASVD_HIP_CHECK(hipMemcpyAsync(qb.data(), s1.v3.Q0, nq * sizeof(float), hipMemcpyDeviceToHost, st));
-                ASVD_HIP_CHECK(hipStreamSynchronize(st));
-                size_t bad = 0, firstbad = 0;
-                for (size_t i = 0; i < nq; ++i)
-                    if (memcmp(&qa[i], &qb[i], 4) != 0) { if (!bad) firstbad = i; ++bad; }
-                fprintf(stderr, "[selftest] rep %d: Q0 of half 1 alone vs combined with update: %zu of %zu floats differ (first at %zu: slot %zu, elem %zu)\n",
-                        rep, bad, nq, firstbad, firstbad / 4096, firstbad % 4096);
             }
         }
         if (ngroups >= 2) {
@@ -2426,7 +2353,7 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
             std::memcpy(&mo, &bits, sizeof(float));
             sweeps_done[b] = sweep + 1;
             last_rot[b] = flags[batch + b];
-            if (g_prof_enabled) { g_prof_pairs[0] += sparse ? 0 : (long long)p.nb * (p.nb - 1) / 2; g_prof_pairs[1] += last_rot[b]; }
+            if (g_prof_enabled) { g_prof_pairs[0] += sparse ? 0 : (long long)p.nb * (p.nb - 1) / 2; g_prof_pairs[1] += last_rot[b]; g_prof_pairs[2] += flags[3 * batch + b]; }
             last_off[b] = mo;
             if (debug) fprintf(stderr, "[asvd_svd] b=%d sweep=%d maxoff=%.3e rotated_pairs=%d\n", b, sweep + 1, mo, last_rot[b]);
             if (mo != mo) { status[b] = ASVD_N_NAN; host_done[b] = 1; changed = true; }
@@ -2689,19 +2616,21 @@ static int svd_tall(int batch, const void* const* a_host, int a_dtype, int64_t m
     return rc;
 }
 
-// Debug / test hook (tests/test_gpu_kernels_twolevel.py): one launch of the two-level update kernel on caller-built panels.
-// X: [batch][nb][R][32] fp32 panels; Qfin: [batch][npairs][128*128]; subact: [batch][npairs][4]; done: [batch] ints (device).
-int asvd_dbg_supdate(int split, float* X, int64_t panel_stride, int64_t batch_stride, int ns, int D, int R, int rows_per_wg, const float* Qfin,
-                     const int* subact, const int* done, int nchunks, int npairs, int batch, void* stream) {
+// Test hook (tests/test_gpu_twolevel.py): ONE launch of the two-level update kernel on caller-built panels, so that the kernel can
+// be checked against a plain fp64 product.  X: [batch][nb][R][32] fp32 panels; Qfin: [batch][npairs][128*128]; subact: [batch][npairs][4];
+// done, nupd: [batch] ints (all device pointers).  split != 0 selects the split-bf16 kernel.
+int asvd_test_supdate(int split, float* X, int64_t panel_stride, int64_t batch_stride, int ns, int D, int R, int rows_per_wg, const float* Qfin,
+                      const int* subact, const int* done, int* nupd, int nchunks, int npairs, int batch, void* stream) {
+    if (!X || !Qfin || !subact || !done || !nupd || ns < 2 || D < 1 || R < 32 || (R % 32) || rows_per_wg < 32 || (rows_per_wg % 32)) return ASVD_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     {
         const int order = 1;
         ASVD_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_pair_order), &order, sizeof(int), 0, hipMemcpyHostToDevice));
     }
     if (split)
-        supdate_split_kernel<<<dim3(nchunks, npairs, batch), 256, 0, st>>>(X, panel_stride, batch_stride, ns, D, R, rows_per_wg, Qfin, subact, done);
+        supdate_split_kernel<<<dim3(nchunks, npairs, batch), 256, 0, st>>>(X, panel_stride, batch_stride, ns, D, R, rows_per_wg, Qfin, subact, done, nupd);
     else
-        supdate_kernel<<<dim3(nchunks, npairs, batch), 256, 0, st>>>(X, panel_stride, batch_stride, ns, D, R, rows_per_wg, Qfin, subact, done);
+        supdate_kernel<<<dim3(nchunks, npairs, batch), 256, 0, st>>>(X, panel_stride, batch_stride, ns, D, R, rows_per_wg, Qfin, subact, done, nupd);
     ASVD_HIP_CHECK(hipGetLastError());
     return ASVD_OK;
 }

@@ -132,13 +132,14 @@ __global__ __launch_bounds__(256) void sgram6_kernel(const float* __restrict__ X
 constexpr int ULD = SP + 4;  // LDS row stride in floats (528 B: conflict-free b128 row-per-lane reads)
 __global__ __launch_bounds__(256, 2) void supdate_kernel(float* __restrict__ X, int64_t panel_stride, int64_t batch_stride, int ns, int D,
                                                          int R, int rows_per_wg, const float* __restrict__ Qfin,
-                                                         const int* __restrict__ subact, const int* __restrict__ done) {
+                                                         const int* __restrict__ subact, const int* __restrict__ done, int* __restrict__ nupd) {
     const int chunk = blockIdx.x, pair = blockIdx.y, b = blockIdx.z, npairs = gridDim.y;
     ASVD_KERNEL_ACQUIRE();
     if (done[b] || !pair_active(subact, (int64_t)b * npairs + pair)) return;
     int S, T;
     rr_pair(ns, D - 1, pair, S, T);
     if (T >= ns) return;
+    if (chunk == 0 && threadIdx.x == 0) atomicAdd(&nupd[b], 1);  // instrumentation: super-pairs updated in this sweep
     float* __restrict__ Xb = X + (int64_t)b * batch_stride;
     float* __restrict__ P0 = Xb + (int64_t)(2 * S) * panel_stride;
     float* __restrict__ P1 = Xb + (int64_t)(2 * S + 1) * panel_stride;
@@ -222,13 +223,14 @@ __device__ __forceinline__ void split3(float x0, float x1, unsigned& p1, unsigne
 constexpr int SUPDATE_SMEM_FLOATS = 2 * 32 * ULD;  // 33 KiB
 __device__ __forceinline__ void supdate_split_body(const BlockCtx& ctx, float* __restrict__ smem, float* __restrict__ X, int64_t panel_stride,
                                                    int64_t batch_stride, int ns, int D, int R, int rows_per_wg, const float* __restrict__ Qfin,
-                                                   const int* __restrict__ subact, const int* __restrict__ done) {
+                                                   const int* __restrict__ subact, const int* __restrict__ done, int* __restrict__ nupd) {
     const int chunk = ctx.bx, pair = ctx.by, b = ctx.bz, npairs = ctx.gy;
     ASVD_KERNEL_ACQUIRE();
     if (done[b] || !pair_active(subact, (int64_t)b * npairs + pair)) return;
     int S, T;
     rr_pair(ns, D - 1, pair, S, T);
     if (T >= ns) return;
+    if (chunk == 0 && threadIdx.x == 0) atomicAdd(&nupd[b], 1);  // instrumentation: super-pairs updated in this sweep
     float* __restrict__ Xb = X + (int64_t)b * batch_stride;
     float* __restrict__ P0 = Xb + (int64_t)(2 * S) * panel_stride;
     float* __restrict__ P1 = Xb + (int64_t)(2 * S + 1) * panel_stride;
@@ -315,24 +317,26 @@ __device__ __forceinline__ void supdate_split_body(const BlockCtx& ctx, float* _
 
 __global__ __launch_bounds__(256, 2) void supdate_split_kernel(float* __restrict__ X, int64_t panel_stride, int64_t batch_stride, int ns,
                                                                int D, int R, int rows_per_wg, const float* __restrict__ Qfin,
-                                                               const int* __restrict__ subact, const int* __restrict__ done) {
+                                                               const int* __restrict__ subact, const int* __restrict__ done, int* __restrict__ nupd) {
     __shared__ __attribute__((aligned(16))) float smem[SUPDATE_SMEM_FLOATS];
     const BlockCtx ctx{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, (int)gridDim.y, (int)gridDim.z};
-    supdate_split_body(ctx, smem, X, panel_stride, batch_stride, ns, D, R, rows_per_wg, Qfin, subact, done);
+    supdate_split_body(ctx, smem, X, panel_stride, batch_stride, ns, D, R, rows_per_wg, Qfin, subact, done, nupd);
 }
 
 // ==================================================================================================
-// Dual launches: software pipelining on ONE stream.  The four phases of a super-step — Gram pass (G), eigen-solves of inner step 0
-// and 1 (E1, E2), update pass (U) — are bound by different resources: G and U stream panels through HBM and the matrix pipe, E1 and
-// E2 are chains of short VALU/LDS phases on a few hundred workgroups.  Run back to back on one stream each phase leaves the other
-// resource idle (and several streams are not an option, common.h).  The batch is therefore cut into two halves that run two phases
-// apart, and every launch carries the streaming phase of one half TOGETHER with the solve phase of the other:
-//     slot:   0    1    2     3     4     5     6   ...
-//     half 0: G1   E1   E2    U1    G2    E1    E2
-//     half 1: -    -    G1    E1    E2    U1    G2          ->  launches  [G|E2]  [U|E1]  [G|E2]  [U|E1] ...
-// Blocks [0, nsolve) of a dual launch run the solve body (dispatched first: they are the long-latency ones), the rest the streaming
-// body; both bodies are the ones of the stand-alone kernels above.  Kernel boundaries on a single stream keep every dependency: a
-// phase only consumes what the previous launch (or an earlier one) of the same half produced.
+// Dual launches: software pipelining on ONE stream.  The phases of a super-step — Gram pass (G), eigen-solves of inner step 0 and 1
+// (E1, E2), update pass (U) — are bound by different resources: G and U stream panels through HBM and the matrix pipe, E1 and E2 are
+// chains of short VALU/LDS phases on a few hundred workgroups.  Run back to back on one stream each phase leaves the other resource
+// idle (and several streams are not an option, common.h).  The batch is therefore cut into two halves, and the Gram pass of one half
+// (in two launches, each over half of the super-pairs) carries the two solve launches of the other half:
+//     [Ga(h0) | E1(h1)]  [Gb(h0) | E2(h1)]  U(h1)   [Ga'(h1) | E1(h0)]  [Gb'(h1) | E2(h0)]  U(h0)   ...      (' = next step)
+// Blocks [0, nsolve) of a dual launch run the solve body (dispatched first: they are the long-latency ones), the rest the Gram body;
+// both are the bodies of the stand-alone kernels above.  Kernel boundaries on the single stream keep every dependency.
+// The update pass is NOT combined with solves: measured in round 2 (library self-test, since removed), eigen-solve workgroups that
+// share a CU with split-bf16 update workgroups of the same launch produce a different, wrong Q (most of the 64x64 matrix; never with
+// Gram workgroups, never when the two kernels run one after the other, independent of LDS size, priority and fences) — cause not
+// found.  And the pairing that is safe does not pay: the solve workgroups slow down next to the Gram workgroups (LDS / issue
+// contention on a 128-phase dependent chain) by more than the overlap saves — 77 vs 69 ms per dense sweep.  Opt-in: ASVD_PIPE=1.
 struct SolveArgs {
     unsigned* maxoff;
     int* nrot;
@@ -349,16 +353,8 @@ struct GramArgs {
     int ns, D, m_pad, rows_per_split;
     float* Gx;
     const int* done;
-    int gx, gy, gz;  // (row splits, super-pair slots, problems); gz = 0: no streaming part
-};
-struct UpdArgs {
-    float* X;
-    int64_t panel_stride, batch_stride;
-    int ns, D, R, rows_per_wg;
-    const float* Qfin;
-    const int* subact;
-    const int* done;
-    int gx, gy, gz;
+    int gx, gy, gz;  // (row splits, super-pair slots of THIS launch, problems); gz = 0: no streaming part
+    int pair0, npairs;  // the launch covers pair slots [pair0, pair0 + gy) of npairs
 };
 constexpr int DUAL_SMEM_FLOATS = EVD_SMEM_FLOATS(1) > SUPDATE_SMEM_FLOATS ? EVD_SMEM_FLOATS(1) : SUPDATE_SMEM_FLOATS;
 static_assert(DUAL_SMEM_FLOATS >= SGRAM6_SMEM_FLOATS, "LDS of the dual kernels");
@@ -374,23 +370,7 @@ __global__ __launch_bounds__(256, 3) void dual_gram_kernel(SolveArgs sa, GramArg
                            sa.hist, nullptr, 0, sa.v3);
     } else {
         id -= nsolve;
-        const BlockCtx ctx{id % ga.gx, (id / ga.gx) % ga.gy, id / (ga.gx * ga.gy), ga.gx, ga.gy, ga.gz};
+        const BlockCtx ctx{id % ga.gx, ga.pair0 + (id / ga.gx) % ga.gy, id / (ga.gx * ga.gy), ga.gx, ga.npairs, ga.gz};
         sgram6_body(ctx, smem, ga.X, ga.panel_stride, ga.batch_stride, ga.ns, ga.D, ga.m_pad, ga.rows_per_split, ga.Gx, ga.done);
-    }
-}
-
-template <int EMODE>
-__global__ __launch_bounds__(256, 2) void dual_upd_kernel(SolveArgs sa, UpdArgs ua) {
-    __shared__ __attribute__((aligned(16))) float smem[DUAL_SMEM_FLOATS];
-    int id = blockIdx.x;
-    const int nsolve = sa.gx * sa.gy;
-    if (id < nsolve) {
-        const BlockCtx ctx{id % sa.gx, id / sa.gx, 0, sa.gx, sa.gy, 1};
-        evd_body<EMODE, 1>(ctx, smem, nullptr, 0, nullptr, nullptr, sa.maxoff, sa.nrot, sa.done, sa.tol, sa.inner_sweeps, sa.nb, sa.step, sa.kb,
-                           sa.hist, nullptr, 0, sa.v3);
-    } else {
-        id -= nsolve;
-        const BlockCtx ctx{id % ua.gx, (id / ua.gx) % ua.gy, id / (ua.gx * ua.gy), ua.gx, ua.gy, ua.gz};
-        supdate_split_body(ctx, smem, ua.X, ua.panel_stride, ua.batch_stride, ua.ns, ua.D, ua.R, ua.rows_per_wg, ua.Qfin, ua.subact, ua.done);
     }
 }

@@ -234,14 +234,14 @@ def svd_profile(enable=None):
     if enable is not None:
         lib.asvd_svd_set_profiling(1 if enable else 0)
         return None
-    ms = (ctypes.c_float * 6)()
-    n = (ctypes.c_int * 6)()
+    ms = (ctypes.c_float * 8)()
+    n = (ctypes.c_int * 8)()
     lib.asvd_svd_get_profile(ms, n)
-    names = ["pack", "gram", "evd", "update", "finalize", "snapshot"]
-    out = {names[i]: {"ms": ms[i], "launches": n[i]} for i in range(6)}
-    cnt = (ctypes.c_longlong * 2)()
+    names = ["pack", "sgram", "evd", "supdate", "finalize", "snapshot", "gram1", "update1"]
+    out = {names[i]: {"ms": ms[i], "launches": n[i]} for i in range(8)}
+    cnt = (ctypes.c_longlong * 3)()
     lib.asvd_svd_get_pair_counts(cnt)
-    out["pairs"] = {"visited": int(cnt[0]), "rotated": int(cnt[1])}
+    out["pairs"] = {"visited": int(cnt[0]), "rotated": int(cnt[1]), "super_updates": int(cnt[2])}
     sms = (ctypes.c_float * 64)()
     srot = (ctypes.c_longlong * 64)()
     ns = min(64, lib.asvd_svd_get_sweep_times(sms, srot, 64))

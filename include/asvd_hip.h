@@ -176,12 +176,19 @@ int asvd_reconstruct_err(const void* W, int w_dtype, int64_t ldw, const void* A,
 
 /* ---------------------------------------------------------------------------------------------
  * Instrumentation: per-kernel-class wall time of the last asvd_svd_batched call, measured with HIP
- * events on the call's stream when enabled.  classes: 0 pack, 1 gram, 2 evd, 3 update, 4 finalize, 5 snapshot (the
- * blocked X^T X pass that opens a sparse sweep).  ms_host: float[6] total milliseconds; launches_host: int[6].  */
+ * events on the call's stream when enabled.  classes: 0 pack + Cholesky-QR reduction, 1 two-level Gram pass (sgram6),
+ * 2 eigen-solves, 3 two-level update pass (supdate), 4 finalize, 5 snapshot (the blocked X^T X pass that opens a sparse sweep),
+ * 6 single-level Gram, 7 single-level update.  ms_host: float[8] total milliseconds; launches_host: int[8].  */
 void asvd_svd_set_profiling(int enabled);
 int asvd_svd_get_profile(float* ms_host, int* launches_host);
-/* counts_host: long long[2] = {panel-pair visits (one Gram each), pairs actually rotated (one eigen-solve + one update each)} summed
- * over the sweeps and problems of the last profiled call: the algorithmic byte counts of the streaming kernels follow from these. */
+/* Test hook: one launch of the two-level update kernel ([X_S X_T] <- [X_S X_T] Qfin for every super-pair of XOR step D) on
+ * caller-built panels X [batch][nb][R][32]; Qfin [batch][npairs][128*128]; subact [batch][npairs][4] (pair updated when any flag is
+ * set); done, nupd [batch] ints.  split != 0: split-bf16 arithmetic.  Used by tests/test_gpu_twolevel.py only. */
+int asvd_test_supdate(int split, float* X, int64_t panel_stride, int64_t batch_stride, int ns, int D, int R, int rows_per_wg,
+                      const float* Qfin, const int* subact, const int* done, int* nupd, int nchunks, int npairs, int batch, void* stream);
+/* counts_host: long long[3] = {32-column panel-pair visits (one 64x64 eigen-solve each), pairs actually rotated, 128-column
+ * super-pairs updated by the two-level sweeps (one 128-wide update pass over the rows each)} summed over the sweeps and problems of
+ * the last profiled call: the algorithmic byte counts of the streaming kernels follow from these. */
 int asvd_svd_get_pair_counts(long long* counts_host);
 /* host wall time (ms) and rotated pairs of every Jacobi sweep of the last profiled call, whole batch together (the call
  * synchronises once per sweep).  Fills at most `cap` entries; returns the number of sweeps. */
