@@ -123,6 +123,9 @@ def build_parser():
     parser.add_argument("--save_repo", type=str, default="", help="write the compressed model in the exported HF-repo layout of the reference (truncation_ranks in config.json)")
     parser.add_argument("--no_fused_sweep", dest="fused_sweep", action="store_false",
                         help="evaluate every (layer, ratio) with full model forwards as the reference does (default: prefix-cached evaluator, same values)")
+    parser.add_argument("--no_fused_ratios", dest="fused_ratios", action="store_false",
+                        help="evaluate every candidate ratio of a layer in its own suffix pass (default: all ratios as one batched pass; "
+                             "same search trace, perplexities equal to ~1e-4 relative in fp16)")
     parser.add_argument("--gather_factors", type=str, default="rank0", choices=["rank0", "all", "none"],
                         help="--dist: after the sharded decomposition send every layer's A/B factors to rank 0 (point-to-point), to all ranks "
                              "(broadcast), or nowhere")

@@ -37,6 +37,25 @@ def collect_linear_info(model):
     return linear_info
 
 
+def _multi_rank_module(raw_linear, ratios, args):
+    """MultiRankSVDLinear for the candidate ratios of one Linear, or None when the fused path does not apply (a rank outside
+    [1, min(in, out)] or a failed / NaN factorisation: the per-ratio path then reproduces the reference's fallback behaviour)."""
+    from .sweep_eval import MultiRankSVDLinear
+    ranks = [SVDLinear.compute_rank(raw_linear, r, args.rank_align) for r in ratios]
+    kmax = min(raw_linear.in_features, raw_linear.out_features)
+    if min(ranks) < 1 or max(ranks) > kmax:
+        return None
+    try:
+        U, S, V, s = SVDLinear.factorize(raw_linear, True, args.alpha, k=max(ranks), k_compute=getattr(raw_linear, "_asvd_rank_hint", None))
+    except Exception:
+        return None
+    A, B, flags = ops.truncate_split(U, S, V, s, max(ranks), "UV", raw_linear.weight.dtype)  # sweep: from_linear's default sigma_fuse
+    if any(int(x) for x in flags.tolist()):
+        return None
+    bias = raw_linear.bias.data if raw_linear.bias is not None else None
+    return MultiRankSVDLinear(A, B, bias, ranks)
+
+
 def _ppl_candidates(args):
     if args.compress_kv_cache:
         return [0.1 * i for i in range(1, 20)]
@@ -77,11 +96,26 @@ def calib_sensitivity_ppl(model, calib_loader, args, use_cache=True):
     if getattr(args, "fused_sweep", True) and n_mine > 0:
         evaluator = PrefixCachedEvaluator(model, input_ids, args.n_calib_samples)
     pbar = tqdm(total=n_mine * len(param_ratio_candidates), disable=(rank != 0))
+    fused_ratios = evaluator is not None and getattr(args, "fused_ratios", True)
     for (raw_linear, info), own in zip(linears, owner):
         if own != rank:
             continue
         local[info["full_name"]] = {}
-        for param_ratio in param_ratio_candidates:
+        done_ratios = False
+        if fused_ratios:
+            # all candidate ratios of this layer in ONE batched suffix pass (sweep_eval.MultiRankSVDLinear): one factorisation, the
+            # factors at the largest rank, nested truncations as a batch dimension
+            multi = _multi_rank_module(raw_linear, param_ratio_candidates, args)
+            if multi is not None:
+                setattr(info["father"], info["name"], multi)
+                ppls = evaluator.perplexities(info["full_name"], multi)
+                if ppls is not None:
+                    for param_ratio, ppl in zip(param_ratio_candidates, ppls):
+                        local[info["full_name"]][param_ratio] = ppl
+                        print(f"{info['full_name']} {param_ratio} {ppl}")
+                        pbar.update(1)
+                    done_ratios = True
+        for param_ratio in ([] if done_ratios else param_ratio_candidates):
             svd_linear = SVDLinear.from_linear(
                 raw_linear,
                 param_ratio=param_ratio,

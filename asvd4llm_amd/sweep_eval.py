@@ -13,6 +13,15 @@ model's own forward still does everything else (masks, rotary tables, final norm
 kernels on the same values as the full forward and the perplexities are bit-identical to the plain evaluator's.
 A Linear that is called after the last block (lm_head, OPT project_out) is evaluated with every block skipped and its own
 cached input substituted.  Average cost per evaluation: (N+1)/2N of a full forward, and ~0 for the head.
+
+All candidate ratios of a layer in ONE suffix pass (`perplexities`, SURVEY 8f row 1, second half).  The factors of the sweep are
+NESTED: rank-r factors are the first r columns / rows of the rank-r_max factors (each column of A = U sqrt(S) and row of B depends on
+its own sigma only), so the rank-r output is a prefix sum over sigma-ordered components.  `MultiRankSVDLinear` holds the r_max factors
+and gives batch element j the truncation r_j by zeroing the components >= r_j of z = B x before the A GEMM.  The cached hidden state
+entering the layer's block is expanded to a batch of R identical copies, the suffix runs ONCE on [R, T, C] (masks and rotary tables
+broadcast over the batch) and the logits give R perplexities.  GEMMs see R x T rows instead of T and the launch count drops R-fold.
+Not bit-identical to the per-ratio path: the masked K = r_max GEMM and the batched suffix GEMMs accumulate in a different order
+(fp16: ~1e-3 relative in the logits, ~1e-4 in the perplexity; fp32: 1e-6) — tolerance and the unchanged search trace are tested.
 """
 import torch
 import torch.nn as nn
@@ -39,6 +48,30 @@ def _with_hidden(args, kwargs, h):
     kwargs = dict(kwargs)
     kwargs["hidden_states"] = h
     return args, kwargs
+
+
+class MultiRankSVDLinear(nn.Module):
+    """R nested truncations of one factorisation behind a single module: batch element j of the input gets rank ranks[j].
+    A [out, r_max], B [r_max, in] are the fused, cast factors at the largest rank (what SVDLinear holds); forward(x) expects the
+    batch dimension of x to be R (3-D [R, T, in], or 2-D [R*T, in] as OPT's flattened MLP inputs)."""
+
+    def __init__(self, A, B, bias, ranks):
+        super().__init__()
+        self.A, self.B, self.bias = A, B, bias
+        self.ranks = list(ranks)
+        rmax = B.shape[0]
+        idx = torch.arange(rmax, device=B.device)
+        self.mask = torch.stack([(idx < r) for r in self.ranks]).to(B.dtype)  # [R, r_max]
+
+    def forward(self, x):
+        R = len(self.ranks)
+        flat = x.dim() == 2
+        if flat:
+            x = x.view(R, -1, x.shape[-1])
+        assert x.shape[0] == R, f"MultiRankSVDLinear expects batch {R}, got {tuple(x.shape)}"
+        z = nn.functional.linear(x, self.B)                       # [R, T, r_max]
+        y = nn.functional.linear(z * self.mask[:, None, :], self.A, self.bias)
+        return y.view(-1, y.shape[-1]) if flat else y
 
 
 class PrefixCachedEvaluator:
@@ -200,3 +233,50 @@ class PrefixCachedEvaluator:
             self._restore(undo)
         ppl = torch.exp(torch.stack(nlls).sum() / (len(nlls) * seqlen))
         return ppl.item()
+
+    @torch.no_grad()
+    def perplexities(self, full_name, multi_module):
+        """Calibration perplexities of the R rank truncations held by `multi_module` (a MultiRankSVDLinear already installed in place
+        of the Linear `full_name`): ONE suffix pass per calibration sample on a batch of R copies.  Returns a list of R floats, each
+        with the arithmetic of evaluate_perplexity (mean over T-1 tokens times seqlen, evaluate_utils.py:95-114).
+        Returns None when the layer sits in front of the decoder blocks (nothing to batch: use the per-ratio path)."""
+        model = self.model
+        R = len(multi_module.ranks)
+        cur = {"i": 0}
+        undo, handle = [], None
+        if full_name in self.block_index:
+            start = (self.block_index[full_name] // self.stride) * self.stride
+            undo = self._skip_blocks(start)
+
+            def sub(mod, args, kwargs):
+                h = self.cached[cur["i"]][start] if start in self.cached[cur["i"]] else _hidden_of(args, kwargs)
+                return _with_hidden(args, kwargs, h.expand(R, *h.shape[1:]) if h.dim() == 3 else h.repeat(R, 1))
+
+            handle = self.blocks[start].register_forward_pre_hook(sub, with_kwargs=True)
+        elif full_name in self.after_blocks:
+            undo = self._skip_blocks(self.nblocks)
+
+            def sub(mod, args):
+                x = self.tail_inputs[cur["i"]][full_name]
+                return (x.expand(R, *x.shape[1:]) if x.dim() == 3 else x.repeat(R, 1),) + tuple(args[1:])
+
+            handle = multi_module.register_forward_pre_hook(sub)
+        else:
+            return None
+        nll = torch.zeros(R, dtype=torch.float32, device=model.device)
+        seqlen = self.seqlen
+        try:
+            for i in range(self.n):
+                cur["i"] = i
+                input_ids = self.input_ids[i:i + 1, :-1].to(model.device)
+                labels = self.input_ids[i:i + 1, 1:].contiguous().to(model.device).view(-1)
+                logits = model(input_ids=input_ids, use_cache=False)[0]      # [R, T-1, V]
+                assert logits.shape[0] == R, f"batched suffix returned batch {logits.shape[0]}, expected {R}"
+                for j in range(R):  # one CrossEntropyLoss per truncation, exactly the per-sample arithmetic
+                    loss = nn.CrossEntropyLoss()(logits[j].view(-1, logits.size(-1)), labels)
+                    nll[j] += loss.float() * seqlen
+        finally:
+            if handle is not None:
+                handle.remove()
+            self._restore(undo)
+        return [torch.exp(nll[j] / (self.n * seqlen)).item() for j in range(R)]

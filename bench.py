@@ -63,13 +63,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=16, help="matrices factorised concurrently per step and GPU (6+5+5 per stream group; 32 measured +3 % at best but with large run-to-run variance)")
+    ap.add_argument("--batch", type=int, default=16, help="matrices factorised concurrently per step and GPU (same-shape problems share every launch; 16 = the q/k/v/o Linears of four layers)")
     ap.add_argument("--m", type=int, default=4096)
     ap.add_argument("--n", type=int, default=4096)
     ap.add_argument("--rank", type=int, default=512)
     ap.add_argument("--prewarm_s", type=float, default=5.0, help="seconds of untimed identical work before the warm-up steps (0 disables)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
-    ap.add_argument("--cpu_reps", type=int, default=1, help="timed repetitions of the CPU oracle pipeline (about 15-25 s each on the GPU box host)")
+    ap.add_argument("--no_latency", action="store_true", help="skip the batch-1 latency leg (profiling runs: keeps per-kernel averages to the batch workload)")
+    ap.add_argument("--cpu_reps", type=int, default=3, help="repetitions of the CPU oracle pipeline at the best thread count (>= 3; median reported)")
+    ap.add_argument("--cpu_budget_s", type=float, default=90.0, help="soft bound on the CPU-baseline leg (warm-up + thread sweep + repetitions)")
     ap.add_argument("--dry_run", action="store_true", help="launch plumbing only (CPU, gloo): spawn/bind ranks, barrier, max-reduce, JSON line; no kernels, value = null")
     args = ap.parse_args()
 
@@ -142,6 +144,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    dt_local = dt
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -153,6 +156,15 @@ def main():
     torch.cuda.synchronize()
     prof = ops.svd_profile()
     ops.svd_profile(False)
+    assert all(i.status == 0 for i in infos), [i.status for i in infos]  # every SVD of the batch converged
+
+    # per-rank rates (N > 1): every rank's own SVDs/s over its own wall clock
+    per_rank = None
+    if world > 1:
+        mine = torch.tensor([B * args.steps / dt_local], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [float(t.item()) for t in allr]
 
     if rank == 0:
         total_svds = B * args.steps * world
@@ -160,72 +172,55 @@ def main():
         f_svd = svd_flops(m, n)
         pairs_cnt = prof.pop("pairs")
         sweep_ms, sweep_rot = prof.pop("sweep_ms"), prof.pop("sweep_rotated")
-        dom_all = max(("gram", "evd", "update"), key=lambda k: prof[k]["ms"])
-        # the eigen-solve is a latency-bound LDS kernel without a byte/flop ceiling; the roofline is reported for the dominant
-        # STREAMING kernel and the class that leads by total time is named next to it
-        dom = max(("gram", "update"), key=lambda k: prof[k]["ms"])
         classes = {k: {"ms_per_step": v["ms"], "launches": v["launches"], "avg_us": (1e3 * v["ms"] / v["launches"]) if v["launches"] else 0.0}
                    for k, v in prof.items()}
-        # ALGORITHMIC HBM bytes of the two streaming kernels, from the library's own pair counters of this step:
-        # a gram launch reads both panels of every pair it visits (rows * 64 * 4 B per pair); an update launch reads and writes both
-        # panels of every pair that was actually rotated (converged pairs are skipped: no eigen-solve, no update, no bytes).
-        # With >= 128 columns the Jacobi sweeps run on the square Cholesky factor (cols_pad rows), otherwise on the matrix itself.
+        # Jacobi runs on the square Cholesky factor (cols_pad rows) when the problem has >= 128 columns, else on the matrix itself
         rows_pad = ((max(m, n) + 31) // 32) * 32
         cols_pad = ((min(m, n) + 63) // 64) * 64
         rows_j = cols_pad if min(m, n) >= 128 else rows_pad
-        ngroups = 3 if B >= 12 else (2 if B >= 8 else 1)  # stream groups of asvd_svd_batched
-        per_launch_problems = B / ngroups
-        pair_bytes = rows_j * 64 * 4
-        alg_bytes = {"update": 2.0 * pair_bytes * pairs_cnt["rotated"] / max(1, classes["update"]["launches"]),
-                     "gram": 1.0 * pair_bytes * pairs_cnt["visited"] / max(1, classes["gram"]["launches"])}
-        all_active = {"update": 2.0 * rows_j * cols_pad * 4 * per_launch_problems, "gram": 1.0 * rows_j * cols_pad * 4 * per_launch_problems}
-        traffic = None
+        # ALGORITHMIC HBM bytes of the streaming kernels, from the library's own counters of this step:
+        #   supdate (two-level update pass)  reads + writes the 128 columns of every super-pair it updates:  2 * rows * 128 * 4 B each
+        #   sgram   (two-level Gram pass)    reads the 128 columns of every super-pair of the step:             rows * 128 * 4 B each
+        #   update1 / gram1 (single-level kernels: internal step, sparse tail sweeps): 64 columns per rotated / visited 32-panel pair
+        nb_ = cols_pad // 32
+        two_level = classes["supdate"]["launches"] > 0
+        alg = {}
+        if two_level:
+            ns_ = nb_ // 2
+            sp2 = 1
+            while sp2 < ns_: sp2 *= 2
+            dense_sweeps = classes["sgram"]["launches"] / max(1, sp2 - 1)
+            alg["supdate"] = 2.0 * rows_j * 128 * 4 * pairs_cnt["super_updates"] / classes["supdate"]["launches"]
+            alg["sgram"] = 1.0 * rows_j * 128 * 4 * (B * (ns_ // 2)) * 1.0  # every launch visits all super-pairs of all problems of the batch
+        dom = max((k for k in ("supdate", "sgram", "update1", "gram1") if classes[k]["launches"]), key=lambda k: classes[k]["ms_per_step"])
+        dom_all = max(("sgram", "evd", "supdate", "gram1", "update1", "snapshot"), key=lambda k: classes[k]["ms_per_step"])
+        traffic, traffic_src = None, None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            key = dom + "_kernel"
-            if key in pmc and (m, n) == (4096, 4096):
-                traffic = pmc[key]["hbm_bytes_per_launch"] / pmc["batch"] * per_launch_problems
+            if dom in pmc.get("kernels", {}) and (m, n, B) == (4096, 4096, pmc.get("batch")):
+                traffic = pmc["kernels"][dom]["hbm_bytes_per_launch"]
+                traffic_src = "stored: " + pmc.get("source", "profiles/pmc_traffic.json") + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
         except Exception:
             pass
-        if dom in alg_bytes:
-            ach = alg_bytes[dom] / (classes[dom]["avg_us"] * 1e-6) / 1e9
-            roofline = {"bound": "hbm", "kernel": dom + "_kernel", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
-                        "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes[dom],
-                        "algorithmic_bytes_per_launch_if_no_pair_were_skipped": all_active[dom],
-                        "pairs": {"visited": pairs_cnt["visited"], "rotated": pairs_cnt["rotated"]},
-                        "avg_launch_us": classes[dom]["avg_us"],
-                        "note": "dominant kernel by total time, averaged over ALL its launches of the step (the late sweeps' launches move few bytes: "
-                                "most pairs are converged and skipped); measured while the other stream group's kernels share the GPU"}
+        if dom in alg:
+            ach = alg[dom] / (classes[dom]["avg_us"] * 1e-6) / 1e9
+            roofline = {"bound": "hbm", "kernel": {"supdate": "supdate_split_kernel", "sgram": "sgram6_kernel"}[dom], "achieved": ach, "peak": 8000.0,
+                        "unit": "GB/s", "frac": ach / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
+                        "algorithmic_bytes_per_launch": alg[dom], "avg_launch_us": classes[dom]["avg_us"],
+                        "note": "dominant streaming kernel by total time; bytes from the library's own counters of the profiled step, duration = HIP "
+                                "events around every launch on the launch stream, averaged over ALL its launches (one stream: nothing else runs beside it)"}
         else:
-            roofline = {"bound": "lds", "kernel": "evd_kernel", "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": traffic,
-                        "avg_launch_us": classes[dom]["avg_us"], "note": "dominant kernel is the LDS-resident 64x64 eigen-solve (latency bound)"}
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None, "traffic": traffic,
+                        "avg_launch_us": classes[dom]["avg_us"]}
         achieved = f_svd * (value / world) / 1e12  # algorithmic TFLOP/s per GPU of the whole SVD job, from the timed region's wall clock
         roofline["svd_level"] = {"bound": "mfma", "unit_of_work": "one economy SVD, F = 14 m n^2 + 8 n^3", "achieved": achieved, "peak": 157.3,
-                                 "unit": "TFLOP/s", "frac": achieved / 157.3}
-        # the same kernels seen from the MFMA side: executed fp32-MFMA flops of one gram/update launch (2*rows*64*64 per panel pair) and
-        # of the whole Jacobi phase — at panel width 32 the HBM and the fp32-MFMA ceilings of the streaming kernels nearly coincide
-        pair_flops = {"update": 2.0 * rows_j * 64 * 64, "gram": 2.0 * rows_j * 64 * 64 * 0.75}  # gram: 3 of the 4 32x32 blocks
-        if dom in alg_bytes:
-            flops_launch = pair_flops[dom] * pairs_cnt["rotated" if dom == "update" else "visited"] / max(1, classes[dom]["launches"])
-            roofline["mfma_view"] = {"flops_per_launch": flops_launch, "achieved": flops_launch / (classes[dom]["avg_us"] * 1e-6) / 1e12,
-                                     "peak": 157.3, "unit": "TFLOP/s", "frac": flops_launch / (classes[dom]["avg_us"] * 1e-6) / 1e12 / 157.3}
-        issued = pair_flops["update"] * pairs_cnt["rotated"] + pair_flops["gram"] * pairs_cnt["visited"]
-        roofline["executed_tflops_whole_job"] = {"issued_fp32_mfma_flops_per_step": issued, "achieved": issued / (dt / args.steps) / 1e12,
-                                                 "peak": 157.3, "unit": "TFLOP/s"}
-        roofline["dominant_by_total_time"] = dom_all + "_kernel"
-        # whole-GPU view of the hot loop: in the first sweep every pair rotates, so the pairwise kernels of all stream groups together
-        # move (gram 1x + update 2x) the panels of every visited pair and issue gram (3 blocks) + update (4 blocks) MFMAs per pair
-        if sweep_ms:
-            P2 = 1
-            while P2 < cols_pad // 32: P2 *= 2
-            dup = max(0, min(7, P2 // 16 - 1))
-            nb_ = cols_pad // 32
-            visits = B * (nb_ * (nb_ - 1) // 2 + sum(sum(1 for i in range(nb_) if i < (i ^ d) < nb_) for d in range(1, dup + 1)))
-            t1 = sweep_ms[0] * 1e-3
-            roofline["first_sweep_aggregate"] = {
-                "wall_ms": sweep_ms[0], "pair_visits": visits, "GBps": 3.0 * pair_bytes * visits / t1 / 1e9, "frac_of_8TBps": 3.0 * pair_bytes * visits / t1 / 8e12,
-                "TFLOPs_fp32_mfma": (pair_flops["gram"] + pair_flops["update"]) * visits / t1 / 1e12,
-                "frac_of_157TF": (pair_flops["gram"] + pair_flops["update"]) * visits / t1 / 157.3e12}
+                                 "unit": "TFLOP/s", "frac": achieved / 157.3,
+                                 "note": "fp32-MFMA peak as the yardstick (SURVEY 8d); the update pass itself runs split-bf16 on the bf16 matrix pipe"}
+        if two_level:
+            roofline["streaming_kernels"] = {k: {"GBps": alg[k] / (classes[k]["avg_us"] * 1e-6) / 1e9, "frac_of_8TBps": alg[k] / (classes[k]["avg_us"] * 1e-6) / 8e12,
+                                                 "avg_launch_us": classes[k]["avg_us"], "algorithmic_bytes_per_launch": alg[k]} for k in ("supdate", "sgram")}
+        roofline["dominant_by_total_time"] = dom_all
+        roofline["pairs"] = pairs_cnt
         roofline["sweep_wall_ms"] = sweep_ms
         roofline["sweep_rotated_pairs"] = sweep_rot
         roofline["classes"] = classes
@@ -238,34 +233,70 @@ def main():
                        "batch_per_gpu": B, "m": m, "n": n, "rank": r, "parallelism": f"independent matrices x{world}"},
             "roofline": roofline,
         }
+        if per_rank is not None:
+            out["per_rank_svds_per_s"] = per_rank
+        # ---- batch-1 latency (BASELINE configs[1] says "single ... Linear"): one matrix alone, same path, median of 3 ----
+        if world == 1 and not args.no_latency:
+            lat = []
+            for _ in range(4):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                sc1 = ops.make_scale(stats[0], alpha=0.5)
+                U1, S1, V1, i1 = ops.svd(mats[0], sc1)
+                ops.truncate_split(U1, S1, V1, sc1, r, "UV", torch.float16)
+                torch.cuda.synchronize()
+                lat.append(time.perf_counter() - t1)
+            lat = sorted(lat[1:])
+            out["latency_batch1_ms"] = 1e3 * lat[len(lat) // 2]
+            out["svds_per_s_batch1"] = 1.0 / lat[len(lat) // 2]
         # ---- parity + CPU baseline (rank 0, N=1 only): the oracle pipeline on the box's host cores, bounded sample ----
         if world == 1 and not args.no_cpu_baseline:
             from oracle import asvd_oracle as O
             W0, st0 = mats[0].cpu(), stats[0].cpu()
             s0 = O.make_scale(st0, 0.5)
-            times = []
-            o = None
-            for rep in range(args.cpu_reps):
+
+            def cpu_once():
                 t1 = time.perf_counter()
                 ws = O.scaled_weight(W0, s0)
                 Uo, So, Vo = O.exact_svd(ws)
                 Ao, Bo, _ = O.truncate_split(Uo, So, Vo, s0, r, "UV", torch.float16)
-                times.append(time.perf_counter() - t1)
-            times = sorted(times)
-            tcpu = times[len(times) // 2]
+                return time.perf_counter() - t1, (So, Ao, Bo)
+
+            # 1 warm-up, then a thread sweep (one run each), then >= 3 repetitions at the best thread count, median; bounded
+            # to about --cpu_budget_s seconds of CPU work
+            t_budget0 = time.perf_counter()
+            default_threads = torch.get_num_threads()
+            _, ref = cpu_once()  # warm-up (MKL first-call cost), also the parity reference
+            sweep = {}
+            ncpu = os.cpu_count() or default_threads
+            for t in [t for t in (32, 64, 16, 128, 8) if t <= ncpu]:
+                if time.perf_counter() - t_budget0 > 0.5 * args.cpu_budget_s and sweep:
+                    break
+                torch.set_num_threads(t)
+                sweep[t] = cpu_once()[0]
+            best_t = min(sweep, key=sweep.get)
+            torch.set_num_threads(best_t)
+            reps = [sweep[best_t]]
+            while len(reps) < 3 or (len(reps) < args.cpu_reps and time.perf_counter() - t_budget0 < args.cpu_budget_s):
+                reps.append(cpu_once()[0])
+            reps.sort()
+            tcpu = reps[len(reps) // 2]
             # what the reference literally calls (modules/svd_linear.py:65): randomized torch.svd_lowrank(q=rank), one run
             t1 = time.perf_counter()
             torch.manual_seed(233)
             torch.svd_lowrank(O.scaled_weight(W0, s0), q=r)
             t_lowrank = time.perf_counter() - t1
+            torch.set_num_threads(default_threads)
+            So, Ao, Bo = ref
             r9 = int(m * n * 0.9) // (m + n)
             serr = O.sigma_rel_err(S[0].cpu(), So, r9)
             A_g, B_g, _ = outs[0]
             rerr, rerr_scaled = O.recon_parity(A_g, B_g, Ao, Bo, W0, s0)
-            out["cpu_baseline"] = {"value": 1.0 / tcpu, "unit": "SVD/s", "cores": torch.get_num_threads(), "kind": "port",
-                                   "sample": f"{args.cpu_reps} rep(s) (median, no warm-up) of oracle scale+torch.linalg.svd(gesdd)+truncate/split on ONE {m}x{n} matrix of the batch",
-                                   "seconds_per_svd": tcpu, "host_cpu_count": os.cpu_count(),
-                                   "seconds_torch_svd_lowrank_q_rank": t_lowrank}
+            out["cpu_baseline"] = {"value": 1.0 / tcpu, "unit": "SVD/s", "cores": best_t, "kind": "port",
+                                   "sample": f"oracle scale + torch.linalg.svd (gesdd) + truncate/split on ONE {m}x{n} matrix of the batch: 1 warm-up, thread sweep "
+                                             f"{sorted(sweep)} (one run each), median of {len(reps)} runs at the best thread count",
+                                   "seconds_per_svd": tcpu, "seconds_by_threads": {str(k): v for k, v in sorted(sweep.items())},
+                                   "host_cpu_count": ncpu, "seconds_torch_svd_lowrank_q_rank": t_lowrank}
             out["parity"] = {"sigma_rel_err_top_r": serr, "r": r9, "recon_fro_err_rank512_vs_oracle": rerr, "recon_fro_err_scaled_norm": rerr_scaled, "tolerance": {"sigma": 1e-4, "recon": 1e-3}}
         print(json.dumps(out))
     if world > 1:

@@ -73,3 +73,70 @@ def test_stride_fallback_identical():
     swapped = _perturbed(lin, 0)
     model.model.layers[3].mlp.up_proj = swapped
     assert ev.perplexity("model.layers.3.mlp.up_proj", swapped) == evaluate_perplexity(model, ids, 2)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# all candidate ranks of a layer in ONE batched suffix pass (MultiRankSVDLinear / PrefixCachedEvaluator.perplexities)
+def _factors(linear, rmax, seed=0):
+    """exact fp64 SVD factors at rank rmax, fused 'UV' like SVDLinear (CPU stand-in for the device factorisation)"""
+    U, S, Vh = torch.linalg.svd(linear.weight.data.double(), full_matrices=False)
+    A = (U[:, :rmax] * S[:rmax].sqrt()).to(linear.weight.dtype)
+    B = (S[:rmax].sqrt()[:, None] * Vh[:rmax]).to(linear.weight.dtype)
+    return A, B
+
+
+class _TwoLin(nn.Module):
+    def __init__(self, A, B, bias):
+        super().__init__()
+        self.A, self.B, self.bias = A, B, bias
+
+    def forward(self, x):
+        return nn.functional.linear(nn.functional.linear(x, self.B), self.A, self.bias)
+
+
+def _check_multi(model, vocab, n=3, T=20, tol=2e-6):
+    from asvd4llm_amd.sweep_eval import MultiRankSVDLinear
+    torch.manual_seed(7)
+    ids = torch.randint(0, vocab, (n, T))
+    model.eval()
+    ev = PrefixCachedEvaluator(model, ids, n)
+    info = collect_linear_info(model)
+    kinds = set()
+    for lin, meta in info.items():
+        name = meta["full_name"]
+        kmax = min(lin.in_features, lin.out_features)
+        ranks = sorted({max(1, kmax // 4), max(1, kmax // 2), max(1, (3 * kmax) // 4)})
+        A, B = _factors(lin, max(ranks))
+        bias = lin.bias.data if lin.bias is not None else None
+        multi = MultiRankSVDLinear(A, B, bias, ranks)
+        setattr(meta["father"], meta["name"], multi)
+        try:
+            got = ev.perplexities(name, multi)
+        finally:
+            setattr(meta["father"], meta["name"], lin)
+        if got is None:
+            kinds.add("front")
+            continue
+        kinds.add("block" if name in ev.block_index else "tail")
+        for r, g in zip(ranks, got):
+            two = _TwoLin(A[:, :r].contiguous(), B[:r].contiguous(), bias)  # the per-ratio module: the first r components
+            setattr(meta["father"], meta["name"], two)
+            try:
+                ref = ev.perplexity(name, two)
+            finally:
+                setattr(meta["father"], meta["name"], lin)
+            assert abs(g - ref) <= tol * abs(ref), (name, r, g, ref)
+    return kinds
+
+
+def test_multi_rank_pass_matches_per_ratio_tiny_lm():
+    assert _check_multi(TinyLM(n_layers=3), 50) == {"block", "tail"}
+
+
+@pytest.mark.parametrize("name", ["tiny-llama", "tiny-opt"])
+def test_multi_rank_pass_matches_per_ratio_hf(name):
+    """HF Llama / OPT: masks and rotary tables of the batch-1 input broadcast over the R-copy batch substituted at the block input;
+    OPT's MLP Linears receive the flattened [R*T, C] view"""
+    model = random_init_model(name, dtype=torch.float32, seed=2)
+    kinds = _check_multi(model, model.config.vocab_size, tol=5e-6)
+    assert "block" in kinds and "tail" in kinds

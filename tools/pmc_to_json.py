@@ -1,0 +1,30 @@
+"""Turn the per-kernel PMC text summaries of tools/prof_final.sh into profiles/pmc_traffic.json (HBM bytes per launch of the streaming
+kernels).  FETCH_SIZE is reported in KiB of 64-B requests: on gfx950 a wide coalesced streaming read is counted at HALF its bytes
+(MI355X_MICROARCH.md, HBM section) -> doubled here; WRITE_SIZE is taken as reported (KiB)."""
+import json, os, sys
+d = sys.argv[1]
+def table(path):
+    out = {}
+    if not os.path.exists(path):
+        return out
+    for line in open(path):
+        p = line.split()
+        if len(p) >= 5 and p[-3].isdigit():
+            out[(p[0], p[1])] = {"calls": int(p[-3]), "avg": float(p[-2]), "avg_dur_us": float(p[-1])}
+    return out
+fetch, write = table(os.path.join(d, "pmc_FETCH_SIZE.txt")), table(os.path.join(d, "pmc_WRITE_SIZE.txt"))
+names = {"supdate": "supdate_split_kernel", "sgram": "sgram6_kernel", "evd": "evd_kernel", "snapshot": "fullcheck_kernel"}
+res = {"batch": 16, "source": "profiles/" + os.path.basename(d).replace("prof_", "") + "_pmc_*.txt",
+       "note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes of `python bench.py --no_cpu_baseline --no_latency --steps 1 --warmup 0 --prewarm_s 0` "
+               "(16 x 4096x4096 fp32, one stream); mean per dispatch over all launches of the run; FETCH doubled (gfx950 half-count), WRITE as reported",
+       "kernels": {}}
+for key, kn in names.items():
+    f = [v for (n, c), v in fetch.items() if kn in n and c == "FETCH_SIZE"]
+    w = [v for (n, c), v in write.items() if kn in n and c == "WRITE_SIZE"]
+    if not f and not w:
+        continue
+    fk = sum(x["avg"] * x["calls"] for x in f) / max(1, sum(x["calls"] for x in f)) if f else 0.0
+    wk = sum(x["avg"] * x["calls"] for x in w) / max(1, sum(x["calls"] for x in w)) if w else 0.0
+    res["kernels"][key] = {"fetch_kib_raw": fk, "write_kib": wk, "hbm_bytes_per_launch": int(2 * fk * 1024 + wk * 1024),
+                           "launches": sum(x["calls"] for x in f) if f else sum(x["calls"] for x in w)}
+print(json.dumps(res, indent=1))
