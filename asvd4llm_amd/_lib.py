@@ -23,6 +23,8 @@ SIGNATURES = {
     "asvd_device_count": (_i, []),
     "asvd_absstat_worksize": (_i, [_i64, _i64, _c.POINTER(_sz)]),
     "asvd_absstat_accum": (_i, [_vp, _i, _i64, _i64, _i64, _vp, _i, _i, _vp, _sz, _vp]),
+    "asvd_absstat_partial": (_i, [_vp, _i, _i64, _i64, _i64, _i, _vp, _sz, _vp]),
+    "asvd_absstat_finalize": (_i, [_vp, _sz, _i64, _i64, _vp, _i, _i, _vp]),
     "asvd_make_scale": (_i, [_vp, _vp, _i, _i64, _f, _f, _vp, _vp]),
     "asvd_scale_cols": (_i, [_vp, _i, _i64, _i64, _i64, _vp, _i, _vp, _i64, _vp]),
     "asvd_svd_worksize": (_i, [_i, _i64, _i64, _i, _c.POINTER(_sz)]),
@@ -32,6 +34,13 @@ SIGNATURES = {
     "asvd_sigma_max_worksize": (_i, [_i, _i64, _i64, _i, _c.POINTER(_sz)]),
     "asvd_sigma_max_batched": (_i, [_i, _c.POINTER(_vp), _i, _i64, _i64, _i64, _c.POINTER(_vp), _i, _f, _vp, _sz, _c.POINTER(_i), _vp]),
     "asvd_truncate_split": (_i, [_vp, _i64, _vp, _vp, _i64, _vp, _i, _i64, _i64, _i64, _i, _vp, _vp, _i, _vp, _vp]),
+    "asvd_truncate_split_batched": (_i, [_i, _c.POINTER(_vp), _i64, _c.POINTER(_vp), _c.POINTER(_vp), _i64, _c.POINTER(_vp), _i, _i64, _i64, _i64, _i,
+                                         _c.POINTER(_vp), _c.POINTER(_vp), _i, _vp, _vp]),
+    "asvd_make_scale_batched": (_i, [_i, _c.POINTER(_vp), _c.POINTER(_vp), _i, _i64, _f, _f, _c.POINTER(_vp), _vp]),
+    "asvd_comm_init": (_i, [_c.POINTER(_vp), _i, _i, _i, _c.c_char_p, _i]),
+    "asvd_comm_allgather_f32": (_i, [_vp, _vp, _vp, _i64, _vp]),
+    "asvd_comm_allgather_f64": (_i, [_vp, _vp, _vp, _i64, _vp]),
+    "asvd_comm_destroy": (_i, [_vp]),
     "asvd_fro_worksize": (_i, [_i64, _i64, _c.POINTER(_sz)]),
     "asvd_fro_norm_sq": (_i, [_vp, _i, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
     "asvd_reconstruct_worksize": (_i, [_i64, _i64, _c.POINTER(_sz)]),

@@ -15,6 +15,11 @@ from . import ops
 
 
 def _hook_factory(method):
+    # Linears called with the SAME input tensor in one forward (q/k/v_proj, gate/up_proj) share the pass over X: the partial column
+    # statistics of the last input are kept (with the tensor itself, so its address cannot be recycled) and only the tiny finalize
+    # runs for the followers — X is read once per distinct input instead of once per Linear (the reference re-reads it every time)
+    last = {"key": None, "x": None, "work": None}
+
     def hook(module, input, output):
         x = input[0].detach()
         if x.dim() >= 2:
@@ -31,8 +36,15 @@ def _hook_factory(method):
         if not torch.is_tensor(acc):  # python int 0 start (act_aware_utils.py:80)
             acc = torch.zeros(x2.shape[1], dtype=x2.dtype, device=x2.device)
             module.scaling_diag_matrix = acc
-        ops.absstat_accum(x2, acc, method)
+        key = (x2.data_ptr(), tuple(x2.shape), x2.stride(0), x2.dtype, x._version)
+        if last["key"] != key:
+            last["key"], last["x"], last["work"] = key, x2, ops.absstat_partial(x2, method)
+        ops.absstat_finalize(last["work"], x2.shape[0], x2.shape[1], acc, method)
 
+    def release():
+        last["key"] = last["x"] = last["work"] = None
+
+    hook.release = release
     return hook
 
 
@@ -58,6 +70,7 @@ def calib_input_distribution(model, calib_loader, method, use_cache=True):
     for batch in tqdm(calib_loader):
         batch = {k: v.to(model.device) for k, v in batch.items()}
         model(**batch)
+        hook.release()
 
     all_scaling_diag_matrix = {}
     for name, module in model.named_modules():

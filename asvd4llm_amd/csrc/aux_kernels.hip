@@ -342,9 +342,11 @@ int asvd_absstat_worksize(int64_t rows, int64_t cols, size_t* bytes) {
     return ASVD_OK;
 }
 
-int asvd_absstat_accum(const void* x, int x_dtype, int64_t rows, int64_t cols, int64_t ld, void* acc, int acc_dtype, int mode,
-                       void* work, size_t work_bytes, void* stream) {
-    if (!x || !acc || !work || rows < 1 || cols < 1 || ld < cols || !dtype_ok(x_dtype) || !dtype_ok(acc_dtype)) return ASVD_E_BADARG;
+// the two halves of asvd_absstat_accum: the pass over X (partials into `work`) and the ordered finalize into ONE accumulator.  Linears
+// that receive the same input tensor (q/k/v, gate/up) share the first half: X is read once per distinct input.
+int asvd_absstat_partial(const void* x, int x_dtype, int64_t rows, int64_t cols, int64_t ld, int mode, void* work, size_t work_bytes,
+                         void* stream) {
+    if (!x || !work || rows < 1 || cols < 1 || ld < cols || !dtype_ok(x_dtype)) return ASVD_E_BADARG;
     if (mode != ASVD_STAT_ABS_MEAN && mode != ASVD_STAT_ABS_MAX && mode != ASVD_STAT_SQ_MEAN) return ASVD_E_BADARG;
     const int ns = absstat_nsplit(rows, cols);
     if (work_bytes < (size_t)ns * cols * (sizeof(float) + sizeof(int))) return ASVD_E_WORKSPACE;
@@ -359,6 +361,18 @@ int asvd_absstat_accum(const void* x, int x_dtype, int64_t rows, int64_t cols, i
         else if (mode == ASVD_STAT_SQ_MEAN) absstat_partial_kernel<XT, ASVD_STAT_SQ_MEAN><<<grid, 256, 0, st>>>(x, rows, cols, ld, rps, part, nanflag);
         else absstat_partial_kernel<XT, ASVD_STAT_ABS_MAX><<<grid, 256, 0, st>>>(x, rows, cols, ld, rps, part, nanflag);
     });
+    ASVD_HIP_CHECK(hipGetLastError());
+    return ASVD_OK;
+}
+
+int asvd_absstat_finalize(const void* work, size_t work_bytes, int64_t rows, int64_t cols, void* acc, int acc_dtype, int mode, void* stream) {
+    if (!work || !acc || rows < 1 || cols < 1 || !dtype_ok(acc_dtype)) return ASVD_E_BADARG;
+    if (mode != ASVD_STAT_ABS_MEAN && mode != ASVD_STAT_ABS_MAX && mode != ASVD_STAT_SQ_MEAN) return ASVD_E_BADARG;
+    const int ns = absstat_nsplit(rows, cols);
+    if (work_bytes < (size_t)ns * cols * (sizeof(float) + sizeof(int))) return ASVD_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const float* part = (const float*)work;
+    const int* nanflag = (const int*)(part + (int64_t)ns * cols);
     const unsigned fg = (unsigned)ceil_div64(cols, 256);
     ASVD_DISPATCH_DTYPE(acc_dtype, AT, {
         if (mode != ASVD_STAT_ABS_MAX) absstat_final_kernel<AT, ASVD_STAT_ABS_MEAN><<<fg, 256, 0, st>>>(part, nanflag, ns, rows, cols, acc);
@@ -366,6 +380,14 @@ int asvd_absstat_accum(const void* x, int x_dtype, int64_t rows, int64_t cols, i
     });
     ASVD_HIP_CHECK(hipGetLastError());
     return ASVD_OK;
+}
+
+int asvd_absstat_accum(const void* x, int x_dtype, int64_t rows, int64_t cols, int64_t ld, void* acc, int acc_dtype, int mode,
+                       void* work, size_t work_bytes, void* stream) {
+    if (!acc || !dtype_ok(acc_dtype)) return ASVD_E_BADARG;
+    const int rc = asvd_absstat_partial(x, x_dtype, rows, cols, ld, mode, work, work_bytes, stream);
+    if (rc) return rc;
+    return asvd_absstat_finalize(work, work_bytes, rows, cols, acc, acc_dtype, mode, stream);
 }
 
 int asvd_make_scale(const void* scaling, const void* fisher, int dtype, int64_t n, float alpha, float eps, void* out, void* stream) {
@@ -459,6 +481,28 @@ int asvd_reconstruct_err(const void* W, int w_dtype, int64_t ldw, const void* A,
     });
     ordered_sum_d2_kernel<<<1, 256, 0, st>>>((const double*)work, gx * gy, out);
     ASVD_HIP_CHECK(hipGetLastError());
+    return ASVD_OK;
+}
+
+int asvd_make_scale_batched(int batch, const void* const* scaling_host, const void* const* fisher_host, int dtype, int64_t n, float alpha,
+                            float eps, void* const* out_host, void* stream) {
+    if (batch < 1 || !scaling_host || !out_host) return ASVD_E_BADARG;
+    for (int b = 0; b < batch; ++b) {
+        const int rc = asvd_make_scale(scaling_host[b], fisher_host ? fisher_host[b] : nullptr, dtype, n, alpha, eps, out_host[b], stream);
+        if (rc) return rc;
+    }
+    return ASVD_OK;
+}
+
+int asvd_truncate_split_batched(int batch, const float* const* U_host, int64_t ldu, const float* const* S_host, const float* const* V_host,
+                                int64_t ldv, const void* const* s_host, int s_dtype, int64_t m, int64_t n, int64_t r, int sigma_fuse,
+                                void* const* A_host, void* const* B_host, int out_dtype, int* nan_flags, void* stream) {
+    if (batch < 1 || !U_host || !S_host || !V_host || !A_host || !B_host) return ASVD_E_BADARG;
+    for (int b = 0; b < batch; ++b) {
+        const int rc = asvd_truncate_split(U_host[b], ldu, S_host[b], V_host[b], ldv, s_host ? s_host[b] : nullptr, s_dtype, m, n, r, sigma_fuse,
+                                           A_host[b], B_host[b], out_dtype, nan_flags ? nan_flags + 3 * b : nullptr, stream);
+        if (rc) return rc;
+    }
     return ASVD_OK;
 }
 

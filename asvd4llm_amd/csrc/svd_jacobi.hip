@@ -124,10 +124,9 @@ __global__ void vinit_kernel(float* __restrict__ X, int cols, int R, int m_pad) 
 // --------------------------------------------------------------------------------------------------
 // gram: per (row split, pair, problem) partial 64x64 Gram matrix, three 32x32 blocks II, IJ, JJ.
 // MFMA 32x32x2 f32: lane l supplies A[i=l&31][k=l>>5] and B[k=l>>5][j=l&31]; with A = panel^T the operand of a wave for
-// rows (r, r+1) is simply panel[r*32 + l].  Panels are streamed HBM -> LDS with the LDS-DMA (`global_load_lds_dwordx4`:
-// 1 KiB = 8 panel rows per wave-instruction, no VGPR round trip, LDS image == HBM image), each wave into its own 8-KiB
-// chunk (32 rows of both panels), then read back as conflict-free ds_read_b32 (one per MFMA operand).  Latency is hidden
-// by occupancy (workgroups are small: 4 waves, 32 KiB LDS), not by intra-wave double buffering.
+// rows (r, r+1) is simply panel[r*32 + l].  Panels are streamed HBM -> registers (16-B loads, the next 32-row chunk prefetched while
+// the current one is in the matrix pipe) -> a wave-private 8-KiB LDS image of the HBM layout (32 rows of both panels), then read
+// back as conflict-free ds_read_b32 (one per MFMA operand).
 constexpr int GCH = 32;  // rows per staged chunk
 
 
@@ -1811,17 +1810,18 @@ int make_plan(int batch, int64_t m, int64_t n, int want_u, int want_vv, Plan& p)
 }
 
 // ---- optional per-class timing with HIP events on the call's stream ------------------------------
-bool g_prof_enabled = false;
+// profiling state is per host thread: concurrent calls from different threads (on their own streams and workspaces) do not share it
+thread_local bool g_prof_enabled = false;
 // classes: 0 pack / reduce, 1 two-level Gram pass, 2 eigen-solves, 3 two-level update pass, 4 finalize, 5 coupling snapshot,
 //          6 single-level Gram, 7 single-level update
 constexpr int NPROF = 8;
-float g_prof_ms[NPROF] = {0};
-int g_prof_launches[NPROF] = {0};
-long long g_prof_pairs[3] = {0, 0, 0};  // 32-panel pair visits, rotated 32-panel pairs, updated super-pairs (two-level sweeps)
-std::vector<float> g_prof_sweep_ms;       // wall time of every sweep of the last profiled call (all problems of the batch together)
-std::vector<long long> g_prof_sweep_rot;  // pairs rotated in it  // {pair visits (gram), rotated pairs (evd + update)} of the last profiled call
+thread_local float g_prof_ms[NPROF] = {0};
+thread_local int g_prof_launches[NPROF] = {0};
+thread_local long long g_prof_pairs[3] = {0, 0, 0};  // 32-panel pair visits, rotated 32-panel pairs, updated super-pairs (two-level sweeps)
+thread_local std::vector<float> g_prof_sweep_ms;       // wall time of every sweep of the last profiled call (all problems of the batch together)
+thread_local std::vector<long long> g_prof_sweep_rot;  // pairs rotated in it  // {pair visits (gram), rotated pairs (evd + update)} of the last profiled call
 struct ProfRec { int cls; hipEvent_t a, b; };
-std::vector<ProfRec> g_prof_recs;
+thread_local std::vector<ProfRec> g_prof_recs;
 
 struct ProfScope {
     int cls; hipStream_t st; hipEvent_t a = nullptr, b = nullptr; bool on;
@@ -2004,7 +2004,13 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
     int gb0[MAXG] = {0, 0, 0, 0}, gnb[MAXG] = {batch, 0, 0, 0};
     hipEvent_t ev_fork = nullptr, ev_join[MAXG] = {nullptr, nullptr, nullptr, nullptr};
     if (ngroups >= 2) {
-        static hipStream_t s_streams[MAXG] = {nullptr, nullptr, nullptr, nullptr};
+        // side streams belong to the device that is current for this call (one set per device, created on first use)
+        constexpr int MAXDEV = 16;
+        static hipStream_t s_streams_dev[MAXDEV][MAXG] = {};
+        int devid = 0;
+        ASVD_HIP_CHECK(hipGetDevice(&devid));
+        if (devid < 0 || devid >= MAXDEV) return ASVD_E_BADARG;
+        hipStream_t* s_streams = s_streams_dev[devid];
         int off = 0;
         for (int g = 0; g < ngroups; ++g) {
             if (!s_streams[g]) ASVD_HIP_CHECK(hipStreamCreateWithFlags(&s_streams[g], hipStreamNonBlocking));
@@ -2274,6 +2280,7 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
         } else if (two_now) {
             const int nsuper = 2 * p.npairs_s - 1;
             const bool split_bf16 = split_on;
+            const bool gram_split = split_on && getenv("ASVD_GRAM_SPLIT") && atoi(getenv("ASVD_GRAM_SPLIT")) == 1;
             // local super-levels D = 1..L run twice at the start of the sweep (the two-level form of ASVD_DUP; ASVD_DUP2=L)
             const int dup2 = std::min(nsuper, getenv("ASVD_DUP2") ? atoi(getenv("ASVD_DUP2")) : 0);
             for (int di = 0; di < nsuper + dup2; ++di) {
@@ -2295,8 +2302,12 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
                     v3.subact = (int*)(wb + p.off_subact) + (int64_t)b0 * p.npairs_s * 4;
                     {
                         ProfScope ps(1, s2);
-                        sgram6_kernel<<<dim3(p.nsplit_s, p.npairs_s, nbg), 256, 0, s2>>>(Xg, p.panel_stride, p.batch_stride, p.ns, D, p.m_pad,
-                                                                                        p.rows_per_split_s, Gx6g, done + b0);
+                        if (gram_split)
+                            sgram6_kernel<1><<<dim3(p.nsplit_s, p.npairs_s, nbg), 256, 0, s2>>>(Xg, p.panel_stride, p.batch_stride, p.ns, D, p.m_pad,
+                                                                                               p.rows_per_split_s, Gx6g, done + b0);
+                        else
+                            sgram6_kernel<0><<<dim3(p.nsplit_s, p.npairs_s, nbg), 256, 0, s2>>>(Xg, p.panel_stride, p.batch_stride, p.ns, D, p.m_pad,
+                                                                                               p.rows_per_split_s, Gx6g, done + b0);
                     }
                     {
                         ProfScope ps(2, s2);
@@ -2572,7 +2583,12 @@ static int svd_tall(int batch, const void* const* a_host, int a_dtype, int64_t m
         // the per-problem epilogues (un-permute, long-side GEMM, sigma refinement) are independent: spread them over three side
         // streams so the 1024-workgroup GEMMs overlap each other's tails
         constexpr int NES = 3;
-        static hipStream_t s_epi[NES] = {nullptr, nullptr, nullptr};
+        constexpr int MAXDEV_E = 16;
+        static hipStream_t s_epi_dev[MAXDEV_E][NES] = {};
+        int devid_e = 0;
+        ASVD_HIP_CHECK(hipGetDevice(&devid_e));
+        if (devid_e < 0 || devid_e >= MAXDEV_E) return ASVD_E_BADARG;
+        hipStream_t* s_epi = s_epi_dev[devid_e];
         hipEvent_t e_fork = nullptr, e_join[NES] = {nullptr, nullptr, nullptr};
         const int nes = (batch >= 2 && getenv("ASVD_EPI_STREAMS") && atoi(getenv("ASVD_EPI_STREAMS")) > 1) ? NES : 1;  // one stream by default: see common.h
         if (nes > 1) {

@@ -27,11 +27,26 @@ __device__ __forceinline__ bool pair_active(const int* __restrict__ subact, int6
     return (sa[0] | sa[1] | sa[2] | sa[3]) != 0;
 }
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split3(float x0, float x1, unsigned& p1, unsigned& p2, unsigned& p3) {
+    const unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
+    p1 = __builtin_amdgcn_perm(u1, u0, 0x07060302u);  // {hi16(x1) : hi16(x0)}
+    const float r0 = x0 - __uint_as_float(u0 & 0xffff0000u), r1 = x1 - __uint_as_float(u1 & 0xffff0000u);  // exact
+    const unsigned v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
+    p2 = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+    const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u), s1 = r1 - __uint_as_float(v1 & 0xffff0000u);  // exact, <= 8 bits left
+    p3 = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+}
+
+
 // --------------------------------------------------------------------------------------------------
 // sgram6: partial Gram tiles of a super-pair over a row range: Gx6[split][t] (32x32 row-major), t = 0..5 -> [0,2] [0,3] [1,2] [1,3]
 // [0,1] [2,3], tile [x,y] = X_x[rows]^T X_y[rows].  Same streaming structure as gram_kernel (register prefetch of the next 16-row
 // chunk, wave-private LDS image, one ds_read_b32 per MFMA operand); four panels and six accumulators per wave.
 constexpr int SGRAM6_SMEM_FLOATS = 4 * 4 * 16 * PB;  // 32 KiB
+template <int GSPLIT>  // 1: split-bf16 arithmetic (six bf16 products per fp32 product), 0: fp32 MFMA
 __device__ __forceinline__ void sgram6_body(const BlockCtx& ctx, float* __restrict__ smem, const float* __restrict__ X, int64_t panel_stride,
                                             int64_t batch_stride, int ns, int D, int m_pad, int rows_per_split, float* __restrict__ Gx,
                                             const int* __restrict__ done) {
@@ -79,6 +94,34 @@ __device__ __forceinline__ void sgram6_body(const BlockCtx& ctx, float* __restri
                 *(f32x4*)(s + 3 * (SCH * PB) + it * 256 + lane * 4) = p3[it];
             }
             if (ch + 4 < nchunks) fetch(ch + 4);
+            if constexpr (GSPLIT) {
+                // split-bf16: the 16 rows of the chunk are ONE k-step of v_mfma_f32_32x32x16_bf16; lane (column c, group h) holds rows
+                // 8 h + e, e = 0..7, of its column, each fp32 value as three bf16 (exact), six products per fp32 product
+                const int hh = lane >> 5, cc = lane & 31;
+                bf16x8 o1[4], o2[4], o3[4];
+#pragma unroll
+                for (int pnl = 0; pnl < 4; ++pnl) {
+                    const float* sp = s + pnl * (SCH * PB) + (8 * hh) * PB + cc;
+                    u32x4 p1, p2, p3;
+#pragma unroll
+                    for (int e2 = 0; e2 < 4; ++e2) {
+                        unsigned x, y, z;
+                        split3(sp[(2 * e2) * PB], sp[(2 * e2 + 1) * PB], x, y, z);
+                        p1[e2] = x; p2[e2] = y; p3[e2] = z;
+                    }
+                    o1[pnl] = __builtin_bit_cast(bf16x8, p1); o2[pnl] = __builtin_bit_cast(bf16x8, p2); o3[pnl] = __builtin_bit_cast(bf16x8, p3);
+                }
+                auto mm = [&](int a, int b, f32x16 acc) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o3[a], o1[b], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o1[a], o3[b], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o2[a], o2[b], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o2[a], o1[b], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o1[a], o2[b], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o1[a], o1[b], acc, 0, 0, 0);
+                    return acc;
+                };
+                a02 = mm(0, 2, a02); a03 = mm(0, 3, a03); a12 = mm(1, 2, a12); a13 = mm(1, 3, a13); a01 = mm(0, 1, a01); a23 = mm(2, 3, a23);
+            } else {
 #pragma unroll
             for (int u = 0; u < SCH / 2; ++u) {
                 const float x0 = s[0 * (SCH * PB) + u * 64 + lane], x1 = s[1 * (SCH * PB) + u * 64 + lane];
@@ -89,6 +132,7 @@ __device__ __forceinline__ void sgram6_body(const BlockCtx& ctx, float* __restri
                 a13 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, y1, a13, 0, 0, 0);
                 a01 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, x1, a01, 0, 0, 0);
                 a23 = __builtin_amdgcn_mfma_f32_32x32x2f32(y0, y1, a23, 0, 0, 0);
+            }
             }
         }
     }
@@ -118,11 +162,12 @@ __device__ __forceinline__ void sgram6_body(const BlockCtx& ctx, float* __restri
     ASVD_KERNEL_RELEASE();
 }
 
-__global__ __launch_bounds__(256) void sgram6_kernel(const float* __restrict__ X, int64_t panel_stride, int64_t batch_stride, int ns, int D,
-                                                     int m_pad, int rows_per_split, float* __restrict__ Gx, const int* __restrict__ done) {
+template <int GSPLIT>
+__global__ __launch_bounds__(256, 2) void sgram6_kernel(const float* __restrict__ X, int64_t panel_stride, int64_t batch_stride, int ns, int D,
+                                                        int m_pad, int rows_per_split, float* __restrict__ Gx, const int* __restrict__ done) {
     __shared__ __attribute__((aligned(16))) float smem[SGRAM6_SMEM_FLOATS];
     const BlockCtx ctx{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, (int)gridDim.y, (int)gridDim.z};
-    sgram6_body(ctx, smem, X, panel_stride, batch_stride, ns, D, m_pad, rows_per_split, Gx, done);
+    sgram6_body<GSPLIT>(ctx, smem, X, panel_stride, batch_stride, ns, D, m_pad, rows_per_split, Gx, done);
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -207,19 +252,6 @@ __global__ __launch_bounds__(256, 2) void supdate_kernel(float* __restrict__ X, 
 // with fp32 accumulation: 6 x 8 = 48 v_mfma_f32_32x32x16_bf16 (32 cycles each) per 32x128 tile and wave instead of 64
 // v_mfma_f32_32x32x2_f32 (64 cycles each): 2.7x less matrix-pipe time for the kernel that holds 4/5 of the sweep's flops.
 // Bitwise it is not the fp32 MFMA result (different summation tree), numerically it is equivalent (tests compare both with fp64).
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ void split3(float x0, float x1, unsigned& p1, unsigned& p2, unsigned& p3) {
-    const unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
-    p1 = __builtin_amdgcn_perm(u1, u0, 0x07060302u);  // {hi16(x1) : hi16(x0)}
-    const float r0 = x0 - __uint_as_float(u0 & 0xffff0000u), r1 = x1 - __uint_as_float(u1 & 0xffff0000u);  // exact
-    const unsigned v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
-    p2 = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
-    const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u), s1 = r1 - __uint_as_float(v1 & 0xffff0000u);  // exact, <= 8 bits left
-    p3 = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
-}
-
 constexpr int SUPDATE_SMEM_FLOATS = 2 * 32 * ULD;  // 33 KiB
 __device__ __forceinline__ void supdate_split_body(const BlockCtx& ctx, float* __restrict__ smem, float* __restrict__ X, int64_t panel_stride,
                                                    int64_t batch_stride, int ns, int D, int R, int rows_per_wg, const float* __restrict__ Qfin,
@@ -371,6 +403,6 @@ __global__ __launch_bounds__(256, 3) void dual_gram_kernel(SolveArgs sa, GramArg
     } else {
         id -= nsolve;
         const BlockCtx ctx{id % ga.gx, ga.pair0 + (id / ga.gx) % ga.gy, id / (ga.gx * ga.gy), ga.gx, ga.npairs, ga.gz};
-        sgram6_body(ctx, smem, ga.X, ga.panel_stride, ga.batch_stride, ga.ns, ga.D, ga.m_pad, ga.rows_per_split, ga.Gx, ga.done);
+        sgram6_body<0>(ctx, smem, ga.X, ga.panel_stride, ga.batch_stride, ga.ns, ga.D, ga.m_pad, ga.rows_per_split, ga.Gx, ga.done);
     }
 }

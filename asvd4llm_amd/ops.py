@@ -55,6 +55,36 @@ def absstat_accum(x2d, acc, method):
     return acc
 
 
+def _stat_mode(method):
+    return L.STAT_SQ_MEAN if method == "sq_mean" else (L.STAT_ABS_MEAN if "abs_mean" in method else L.STAT_ABS_MAX)
+
+
+def absstat_partial(x2d, method):
+    """first half of absstat_accum: ONE pass over x2d, fp32 partial statistics in a workspace tensor (returned) that
+    absstat_finalize applies to any number of accumulators (Linears that share this input)"""
+    lib = L.load(True)
+    _dev(x2d, "x")
+    assert x2d.dim() == 2 and x2d.stride(1) == 1
+    rows, cols = x2d.shape
+    nb = ctypes.c_size_t()
+    L.check(lib.asvd_absstat_worksize(rows, cols, ctypes.byref(nb)), "asvd_absstat_worksize")
+    work = _work(nb.value, x2d.device)
+    with torch.cuda.device(x2d.device):
+        L.check(lib.asvd_absstat_partial(_ptr(x2d), _dt(x2d), rows, cols, x2d.stride(0), _stat_mode(method), _ptr(work), work.numel(), _stream(x2d)),
+                "asvd_absstat_partial")
+    return work
+
+
+def absstat_finalize(work, rows, cols, acc, method):
+    lib = L.load(True)
+    _dev(acc, "acc")
+    assert acc.is_contiguous() and acc.numel() == cols
+    with torch.cuda.device(acc.device):
+        L.check(lib.asvd_absstat_finalize(_ptr(work), work.numel(), rows, cols, _ptr(acc), _dt(acc), _stat_mode(method), _stream(acc)),
+                "asvd_absstat_finalize")
+    return acc
+
+
 def make_scale(scaling, fisher=None, alpha=1.0, eps=1e-6):
     """s = scaling**alpha [* fisher**alpha] + eps in the dtype of `scaling` (svd_linear.py:48-59)"""
     lib = L.load(True)
@@ -67,6 +97,24 @@ def make_scale(scaling, fisher=None, alpha=1.0, eps=1e-6):
         L.check(lib.asvd_make_scale(_ptr(scaling), _ptr(fisher), _dt(scaling), scaling.numel(), float(alpha), float(eps), _ptr(out),
                                     _stream(scaling)), "asvd_make_scale")
     return out
+
+
+def make_scale_batched(scalings, fishers=None, alpha=1.0, eps=1e-6):
+    """batched make_scale (asvd_make_scale_batched): one ABI call for a list of same-length, same-dtype statistics vectors"""
+    lib = L.load(True)
+    B = len(scalings)
+    scalings = [_dev(s, "scaling").contiguous() for s in scalings]
+    n, dt = scalings[0].numel(), scalings[0].dtype
+    assert all(s.numel() == n and s.dtype == dt for s in scalings)
+    if fishers is not None:
+        fishers = [None if f is None else f.to(dt).contiguous() for f in fishers]
+    outs = [torch.empty_like(s) for s in scalings]
+    arr = ctypes.c_void_p * B
+    f_p = arr(*[(f.data_ptr() if f is not None else None) for f in fishers]) if fishers is not None else None
+    with torch.cuda.device(scalings[0].device):
+        L.check(lib.asvd_make_scale_batched(B, arr(*[s.data_ptr() for s in scalings]), f_p, _dt(scalings[0]), n, float(alpha), float(eps),
+                                            arr(*[o.data_ptr() for o in outs]), _stream(scalings[0])), "asvd_make_scale_batched")
+    return outs
 
 
 def scale_cols(w, s=None):
@@ -194,6 +242,30 @@ def truncate_split(U, S, V, s, r, sigma_fuse, out_dtype):
                                         m, n, r, L.FUSE[sigma_fuse], _ptr(A), _ptr(Bm), _DT[out_dtype], _ptr(flags), _stream(U)),
                 "asvd_truncate_split")
     return A, Bm, flags
+
+
+def truncate_split_batched(Us, Ss, Vs, ss, r, sigma_fuse, out_dtype):
+    """batched truncate_split (asvd_truncate_split_batched) over same-shape problems: returns ([A], [B], flags [batch, 3])"""
+    lib = L.load(True)
+    B = len(Us)
+    m, n = Us[0].shape[0], Vs[0].shape[0]
+    dev = Us[0].device
+    for U, S, V in zip(Us, Ss, Vs):
+        _dev(U, "U")
+        assert U.shape[0] == m and V.shape[0] == n and U.stride(1) == 1 and V.stride(1) == 1 and U.stride(0) == Us[0].stride(0) and V.stride(0) == Vs[0].stride(0)
+        assert U.shape[1] >= r and V.shape[1] >= r and S.numel() >= r
+    As = [torch.empty((m, r), dtype=out_dtype, device=dev) for _ in range(B)]
+    Bs = [torch.empty((r, n), dtype=out_dtype, device=dev) for _ in range(B)]
+    flags = torch.zeros((B, 3), dtype=torch.int32, device=dev)
+    arr = ctypes.c_void_p * B
+    s_p = arr(*[(x.data_ptr() if x is not None else None) for x in ss]) if ss is not None else None
+    sdt = _dt(ss[0]) if ss is not None and ss[0] is not None else 0
+    with torch.cuda.device(dev):
+        L.check(lib.asvd_truncate_split_batched(B, arr(*[u.data_ptr() for u in Us]), Us[0].stride(0), arr(*[x.data_ptr() for x in Ss]),
+                                                arr(*[v.data_ptr() for v in Vs]), Vs[0].stride(0), s_p, sdt, m, n, r, L.FUSE[sigma_fuse],
+                                                arr(*[a.data_ptr() for a in As]), arr(*[b.data_ptr() for b in Bs]), _DT[out_dtype], _ptr(flags),
+                                                _stream(Us[0])), "asvd_truncate_split_batched")
+    return As, Bs, flags
 
 
 def fro_norm_sq(w):

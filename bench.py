@@ -116,9 +116,10 @@ def main():
     torch.cuda.synchronize()
 
     def step():
-        scales = [ops.make_scale(st, alpha=0.5) for st in stats]
+        scales = ops.make_scale_batched(stats, alpha=0.5)
         U, S, V, infos = ops.svd_batched(mats, scales)
-        outs = [ops.truncate_split(U[b], S[b], V[b], scales[b], r, "UV", torch.float16) for b in range(B)]
+        As, Bs, flags = ops.truncate_split_batched(U, S, V, scales, r, "UV", torch.float16)
+        outs = [(As[b], Bs[b], flags[b]) for b in range(B)]
         return U, S, V, scales, outs, infos
 
     # A fresh process on a fresh box runs its first ~2 s below steady state (clock ramp, first-touch of the multi-GB workspace):

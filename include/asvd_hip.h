@@ -73,6 +73,14 @@ int asvd_device_count(void);
 int asvd_absstat_worksize(int64_t rows, int64_t cols, size_t* bytes);
 int asvd_absstat_accum(const void* x, int x_dtype, int64_t rows, int64_t cols, int64_t ld,
                        void* acc, int acc_dtype, int mode, void* work, size_t work_bytes, void* stream);
+/* The two halves of asvd_absstat_accum, for Linears that are called with the SAME input tensor (q/k/v_proj, gate/up_proj: the
+ * reference's hook re-reads X for each of them, act_aware_utils.py:78-81): asvd_absstat_partial makes the one pass over X
+ * (fp32 partial column statistics into `work`), asvd_absstat_finalize applies them to one accumulator with the arithmetic
+ * described above — call it once per Linear sharing the input.  Both asynchronous on `stream`. */
+int asvd_absstat_partial(const void* x, int x_dtype, int64_t rows, int64_t cols, int64_t ld, int mode,
+                         void* work, size_t work_bytes, void* stream);
+int asvd_absstat_finalize(const void* work, size_t work_bytes, int64_t rows, int64_t cols,
+                          void* acc, int acc_dtype, int mode, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K3a  scale vector.  Replaces svd_linear.py:48-59:
@@ -82,6 +90,10 @@ int asvd_absstat_accum(const void* x, int x_dtype, int64_t rows, int64_t cols, i
  */
 int asvd_make_scale(const void* scaling, const void* fisher, int dtype, int64_t n, float alpha, float eps,
                     void* out, void* stream);
+/* batched form: host arrays [batch] of device pointers (fisher_host may be NULL or hold NULL entries); one call for the
+ * q/k/v/o (gate/up) Linears of a layer or a whole same-shape batch of asvd_svd_batched.  Asynchronous. */
+int asvd_make_scale_batched(int batch, const void* const* scaling_host, const void* const* fisher_host, int dtype, int64_t n,
+                            float alpha, float eps, void* const* out_host, void* stream);
 
 /* K3b  w_scaled[i][j] = float(w[i][j]) * float(s[j]).  Replaces svd_linear.py:47,60
  * (`w = linear.weight.data.float(); w = w * scaling_diag_matrix.view(1,-1)`).  s may be NULL (plain
@@ -96,9 +108,12 @@ int asvd_scale_cols(const void* w, int w_dtype, int64_t m, int64_t n, int64_t ld
  * oracle named by BASELINE.json is the exact `torch.linalg.svd(w, full_matrices=False)`), and, with
  * U = V = NULL, the values-only `torch.svd(w.float(), compute_uv=False)` at sensitivity.py:101.
  *
- * Algorithm: one-sided block Jacobi (Hestenes) on 32-column panels.  Per round-robin step and panel
- * pair: 64x64 Gram matrix by fp32 MFMA, 64x64 symmetric eigen-solve by two-sided Jacobi in LDS,
- * panel <- panel * Q by fp32 MFMA; V is accumulated by the same update; sigma_j = |a_j| / |v_j|.
+ * Algorithm: the oriented matrix (rows >= cols) is reduced to a square one by a Cholesky-QR in fp64 (Gram matrix
+ * by fp64 MFMA, columns ordered by norm), then one-sided block Jacobi runs on R^T: XOR pair schedule over 32-column panels;
+ * dense sweeps work on 64-column super-panels (one 6-tile Gram pass, two launches of 64x64 eigen-solves in LDS, one 128-wide
+ * update pass in split-bf16 arithmetic per step), tail sweeps rotate only the pairs a blocked X^T X snapshot marks.  Right
+ * vectors are the rotated columns, left vectors X V by one GEMM, sigma_j = |X v_j| in fp64.  No vector is accumulated during
+ * the sweeps.  Problems too small or rank-deficient for the reduction take the same sweeps on the matrix itself.
  *
  *   batch       number of same-shape problems solved concurrently (fills the 256 CUs)
  *   a_host      host array [batch] of device pointers to A_b  [m, n] row-major, leading dim lda
@@ -111,7 +126,11 @@ int asvd_scale_cols(const void* w, int w_dtype, int64_t m, int64_t n, int64_t ld
  *               the leading part is done (the discarded tail converges last and would cost 2-4 more sweeps)
  *   max_sweeps  <=0: default (30);  tol <=0: default (1e-6) on max |cos(a_i, a_j)|
  *   info_host   optional host int[4*batch]: {status, sweeps, rotated pairs in last sweep, float bits of the last sweep's max |cos|}
- * Host-synchronous (one stream sync per sweep).  Returns worst status over the batch.
+ * Host-synchronous: the call returns when S/U/V are complete.  Sync points: one after the reduction (Cholesky breakdown flag),
+ * one per Jacobi sweep (convergence flags; a second one when a sparse sweep reads back its pair marks), one at the end.
+ * Everything is enqueued on `stream` (no other stream is used unless ASVD_GROUPS / ASVD_EPI_STREAMS ask for it); concurrent
+ * calls from different host threads on different streams and workspaces are safe (no shared mutable state; the profiling
+ * counters are per thread).  Returns worst status over the batch.
  */
 int asvd_svd_worksize(int batch, int64_t m, int64_t n, int want_vectors, size_t* bytes);
 int asvd_svd_batched(int batch, const void* const* a_host, int a_dtype, int64_t m, int64_t n, int64_t lda,
@@ -158,6 +177,12 @@ int asvd_sigma_max_batched(int batch, const void* const* a_host, int a_dtype, in
 int asvd_truncate_split(const float* U, int64_t ldu, const float* S, const float* V, int64_t ldv,
                         const void* s, int s_dtype, int64_t m, int64_t n, int64_t r, int sigma_fuse,
                         void* A, void* B, int out_dtype, int* nan_flags, void* stream);
+/* batched form over same-shape problems: host arrays [batch] of device pointers; nan_flags: device int[3 * batch] (3 per
+ * problem, caller zero-initialises) or NULL.  Asynchronous. */
+int asvd_truncate_split_batched(int batch, const float* const* U_host, int64_t ldu, const float* const* S_host,
+                                const float* const* V_host, int64_t ldv, const void* const* s_host, int s_dtype, int64_t m,
+                                int64_t n, int64_t r, int sigma_fuse, void* const* A_host, void* const* B_host, int out_dtype,
+                                int* nan_flags, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K8  squared Frobenius norm (sensitivity.py:100 `torch.norm(w, p="fro") ** 2`), fp32 accumulate in
@@ -173,6 +198,21 @@ int asvd_fro_norm_sq(const void* w, int w_dtype, int64_t m, int64_t n, int64_t l
 int asvd_reconstruct_worksize(int64_t m, int64_t n, size_t* bytes);
 int asvd_reconstruct_err(const void* W, int w_dtype, int64_t ldw, const void* A, const void* B, int ab_dtype,
                          int64_t m, int64_t n, int64_t r, double* out, void* work, size_t work_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * C1  collective for the one exchange step of the multi-GPU path: all-gather of the per-layer sensitivities over
+ * RCCL (xGMI).  The reference has no distributed path; a maintainer who binds only this library gets the collective here, the
+ * Python host side uses torch.distributed (same RCCL) for it.  RCCL is resolved at run time from the process (torch's
+ * librccl when loaded, else librccl.so) — the library has no link-time dependency on it.
+ *   asvd_comm_init     rank 0 creates the unique id and writes it to `id_path` (a file visible to all ranks of the node); the
+ *                      other ranks wait for the file (up to timeout_s) and read it; all call ncclCommInitRank on `device`.
+ *   asvd_comm_allgather_f32 / _f64   send [count] values, recv [count * nranks], device pointers, asynchronous on `stream`.
+ *   asvd_comm_destroy  releases the communicator (rank 0 removes the id file).
+ * Return ASVD_E_HIP when RCCL is missing or a call fails. */
+int asvd_comm_init(void** comm_out, int rank, int nranks, int device, const char* id_path, int timeout_s);
+int asvd_comm_allgather_f32(void* comm, const float* send, float* recv, int64_t count, void* stream);
+int asvd_comm_allgather_f64(void* comm, const double* send, double* recv, int64_t count, void* stream);
+int asvd_comm_destroy(void* comm);
 
 /* ---------------------------------------------------------------------------------------------
  * Instrumentation: per-kernel-class wall time of the last asvd_svd_batched call, measured with HIP

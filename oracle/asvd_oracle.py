@@ -73,6 +73,11 @@ def fisher_update(acc, grad):
     return g2 if acc is None else acc + g2
 
 
+def fisher_finish(acc, n_batches):
+    """act_aware_utils.py:33-35: `module.fisher_info = module.fisher_info.div(len(calib_loader)).sqrt()`"""
+    return acc.div(n_batches).sqrt()
+
+
 def hook_update_numpy(acc, x, method):
     """Independent numpy restatement of the same update (float64 column sums, one rounding to the activation dtype
     for .mean(), one for the += ), used to bound the rounding freedom of the fp32-accumulating device kernel."""

@@ -247,14 +247,17 @@ class TinyLM(nn.Module):
         self.lm_head = nn.Linear(d, vocab, bias=False)
         self.device = torch.device("cpu")
 
-    def forward(self, input_ids=None, **kw):
+    def forward(self, input_ids=None, labels=None, **kw):
         h = self.model.embed_tokens(input_ids)
         for l in self.model.layers:
             a = l.self_attn
             h = h + a.o_proj(torch.tanh(a.q_proj(h)) * torch.sigmoid(a.k_proj(h)) + a.v_proj(h))
             m = l.mlp
             h = h + m.down_proj(torch.nn.functional.silu(m.gate_proj(h)) * m.up_proj(h))
-        return (self.lm_head(h),)
+        logits = self.lm_head(h)
+        if labels is not None:  # the reference's calib_fisher_info calls model(input_ids=..., labels=...) and backpropagates out[0]
+            return (nn.functional.cross_entropy(logits.view(-1, logits.size(-1)), labels.reshape(-1)), logits)
+        return (logits,)
 
 
 def tiny_state(model):
@@ -341,13 +344,41 @@ def gen_order_hf():
     json.dump(res, open(os.path.join(OUT, "linear_order_hf.json"), "w"), indent=0)
 
 
+# ---- F-fisher: calib_fisher_info (act_aware_utils.py:8-44) on the tiny LM ------------------------------------------
+def gen_fisher():
+    """fisher_info of every Linear after the reference's calib_fisher_info over 3 calibration batches (fp32 model), with the weights and
+    token ids that produced it: pins oracle.fisher_update / fisher_finish and the build's calib_fisher_info (sq_mean hook kernel)."""
+    model = TinyLM(seed=3)
+    g = torch.Generator().manual_seed(17)
+    calib = [{"input_ids": torch.randint(0, 50, (1, 24), generator=g)} for _ in range(3)]
+    with tempfile.TemporaryDirectory() as d, contextlib.redirect_stderr(io.StringIO()):
+        cwd = os.getcwd()
+        os.chdir(d)
+        os.makedirs("cache")  # the reference saves cache/{model_id}_calib_fisher_info.pt unconditionally
+        try:
+            act_aware_utils.calib_fisher_info(model, calib, use_cache=False)
+        finally:
+            os.chdir(cwd)
+    out = {"ids": np.stack([npy(c["input_ids"][0]) for c in calib])}
+    for k, v in tiny_state(model).items():
+        out["state::" + k] = v
+    for name, m in model.named_modules():
+        if isinstance(m, nn.Linear):
+            out["fisher::" + name] = npy(m.fisher_info)
+    np.savez_compressed(os.path.join(OUT, "fisher.npz"), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "fisher":  # regenerate only the fisher fixture
+        gen_fisher()
+        sys.exit(0)
     gen_rank()
     gen_hook()
     gen_svd()
     gen_svd_mid()
     gen_search()
     gen_order_hf()
+    gen_fisher()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -188,3 +188,70 @@ def test_fisher_sq_mean_statistic(gpu, dtype):
         ops.absstat_accum(grad.to(gpu), acc, "sq_mean")
         want = O.fisher_update(want, grad)
     _ulp_close(acc, want, dtype, n_ulp=3, frac_exact=0.9)
+
+
+def test_batched_aux_forms_equal_single(gpu):
+    """asvd_make_scale_batched / asvd_truncate_split_batched == their single-problem forms, bit for bit"""
+    from asvd4llm_amd import ops
+    g = torch.Generator().manual_seed(3)
+    stats = [(32 * torch.randn(200, generator=g).abs()).half().to(gpu) for _ in range(3)]
+    outs = ops.make_scale_batched(stats, alpha=0.5)
+    for st, o in zip(stats, outs):
+        assert torch.equal(o, ops.make_scale(st, alpha=0.5))
+    Us = [torch.randn(96, 64, generator=g).to(gpu) for _ in range(3)]
+    Ss = [torch.rand(64, generator=g).sort(descending=True).values.to(gpu) for _ in range(3)]
+    Vs = [torch.randn(200, 64, generator=g).to(gpu) for _ in range(3)]
+    Vs[1][5, 3] = float("nan")
+    As, Bs, flags = ops.truncate_split_batched(Us, Ss, Vs, outs, 40, "UV", torch.float16)
+    for b in range(3):
+        A, Bm, f = ops.truncate_split(Us[b], Ss[b], Vs[b], outs[b], 40, "UV", torch.float16)
+        assert torch.equal(As[b], A) and torch.equal(Bs[b].nan_to_num(7.0), Bm.nan_to_num(7.0)) and torch.equal(flags[b], f)
+    assert flags[1].tolist() == [0, 0, 1] and flags[0].tolist() == [0, 0, 0]
+
+
+def test_svd_two_host_threads_two_streams_bit_identical(gpu):
+    """boundary contract: concurrent asvd_svd_batched calls from two host threads, each on its own stream and workspace, give the
+    results of the same calls made one after the other"""
+    import threading
+    from asvd4llm_amd import ops
+    g = torch.Generator().manual_seed(11)
+    probs = [[(torch.randn(384, 320, generator=g) * 0.02).to(gpu) for _ in range(2)] for _ in range(2)]
+    ref = [ops.svd_batched(p) for p in probs]
+    out = [None, None]
+
+    def work(i):
+        st = torch.cuda.Stream(device=gpu)
+        with torch.cuda.stream(st):
+            for _ in range(3):
+                out[i] = ops.svd_batched(probs[i])
+        st.synchronize()
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for i in range(2):
+        for b in range(2):
+            assert torch.equal(out[i][1][b], ref[i][1][b]) and torch.equal(out[i][0][b], ref[i][0][b]) and torch.equal(out[i][2][b], ref[i][2][b])
+            assert out[i][3][b].status == 0
+
+
+def test_comm_rccl_world1_allgather(gpu, tmp_path):
+    """asvd_comm_* (C1): world-size-1 communicator over RCCL resolved from the process, fp32 and fp64 all-gather"""
+    import ctypes
+    from asvd4llm_amd import _lib as L
+    lib = L.load(True)
+    comm = ctypes.c_void_p()
+    path = str(tmp_path / "nccl_id.bin").encode()
+    assert lib.asvd_comm_init(ctypes.byref(comm), 0, 1, 0, path, 30) == 0
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    a = torch.arange(7, dtype=torch.float32, device=gpu) + 0.25
+    o = torch.zeros(7, dtype=torch.float32, device=gpu)
+    assert lib.asvd_comm_allgather_f32(comm, ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(o.data_ptr()), 7, st) == 0
+    d = torch.tensor([1.000000123, float("nan"), float("inf")], dtype=torch.float64, device=gpu)
+    od = torch.zeros(3, dtype=torch.float64, device=gpu)
+    assert lib.asvd_comm_allgather_f64(comm, ctypes.c_void_p(d.data_ptr()), ctypes.c_void_p(od.data_ptr()), 3, st) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(o, a) and od[0].item() == 1.000000123 and od[1].isnan() and od[2].isinf()
+    assert lib.asvd_comm_destroy(comm) == 0

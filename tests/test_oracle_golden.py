@@ -113,3 +113,33 @@ def test_mid_size_fixtures_pin_the_oracle(golden):
         y_ref, wx = torch.from_numpy(g[f"m{ci}_probe_y"]), torch.from_numpy(g[f"m{ci}_probe_wx"])
         assert torch.allclose(W.float() @ X, wx, rtol=1e-5, atol=1e-6)
         assert ((y - y_ref).norm() / wx.norm()).item() <= 1e-3
+
+
+def _fisher_fixture_model(golden):
+    from tests.tiny_lm import TinyLM
+    fx = golden.npz("fisher.npz")
+    model = TinyLM()
+    model.load_state_dict({k[len("state::"):]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("state::")})
+    model.config._name_or_path = "tiny-fisher"
+    calib = [{"input_ids": torch.from_numpy(row)[None]} for row in fx["ids"]]
+    want = {k[len("fisher::"):]: fx[k] for k in fx.files if k.startswith("fisher::")}
+    return model, calib, want
+
+
+def test_fisher_restatement_vs_reference_fixture(golden):
+    """oracle.fisher_update / fisher_finish replayed over the same three backward passes reproduce the fisher_info the imported
+    calib_fisher_info (act_aware_utils.py:8-44) left on every Linear (tests/golden/fisher.npz, oracle/make_golden.py gen_fisher)."""
+    model, calib, want = _fisher_fixture_model(golden)
+    model.eval()
+    acc = {n: 0 for n, m in model.named_modules() if isinstance(m, torch.nn.Linear)}
+    for batch in calib:
+        ids = batch["input_ids"]
+        model(input_ids=ids[:, :-1], labels=ids[:, 1:])[0].backward()
+        for n, m in model.named_modules():
+            if isinstance(m, torch.nn.Linear):
+                acc[n] = O.fisher_update(acc[n], m.weight.grad)
+        model.zero_grad()
+    assert set(acc) == set(want) and len(want) == 15
+    for n in want:
+        got = O.fisher_finish(acc[n], len(calib)).numpy()
+        np.testing.assert_allclose(got, want[n], rtol=2e-6, atol=1e-12, err_msg=n)

@@ -43,11 +43,14 @@ class TinyLM(nn.Module):
     def device(self):
         return self.lm_head.weight.device if isinstance(self.lm_head, nn.Linear) else next(self.parameters()).device
 
-    def forward(self, input_ids=None, **kw):
+    def forward(self, input_ids=None, labels=None, **kw):
         h = self.model.embed_tokens(input_ids)
         for l in self.model.layers:
             h = l(h)
-        return (self.lm_head(h),)
+        logits = self.lm_head(h)
+        if labels is not None:  # HF convention used by calib_fisher_info: (loss, logits)
+            return (nn.functional.cross_entropy(logits.view(-1, logits.size(-1)), labels.reshape(-1)), logits)
+        return (logits,)
 
 
 def load_golden_tiny(golden):
