@@ -41,11 +41,15 @@ SIGNATURES = {
     "asvd_comm_allgather_f32": (_i, [_vp, _vp, _vp, _i64, _vp]),
     "asvd_comm_allgather_f64": (_i, [_vp, _vp, _vp, _i64, _vp]),
     "asvd_comm_destroy": (_i, [_vp]),
+    "asvd_lowrank_padded_rank": (_i64, [_i64]),
+    "asvd_lowrank_work_bytes": (_sz, [_i64, _i64]),
+    "asvd_lowrank_forward_f16": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
     "asvd_fro_worksize": (_i, [_i64, _i64, _c.POINTER(_sz)]),
     "asvd_fro_norm_sq": (_i, [_vp, _i, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
     "asvd_reconstruct_worksize": (_i, [_i64, _i64, _c.POINTER(_sz)]),
     "asvd_reconstruct_err": (_i, [_vp, _i, _i64, _vp, _vp, _i, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
     "asvd_test_supdate": (_i, [_i, _vp, _i64, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "asvd_test_supgram": (_i, [_vp, _i64, _i64, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "asvd_svd_set_profiling": (None, [_i]),
     "asvd_svd_get_profile": (_i, [_c.POINTER(_f), _c.POINTER(_i)]),
     "asvd_svd_get_pair_counts": (_i, [_c.POINTER(_c.c_longlong)]),

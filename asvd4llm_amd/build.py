@@ -6,7 +6,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["svd_jacobi.hip", "aux_kernels.hip", "sigma_max.hip", "comm.hip"]
+SOURCES = ["svd_jacobi.hip", "aux_kernels.hip", "sigma_max.hip", "comm.hip", "lowrank_forward.hip"]
 LIB = os.path.join(HERE, "libasvd_hip.so")
 
 

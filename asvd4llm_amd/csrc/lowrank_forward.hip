@@ -1,0 +1,174 @@
+// lowrank_forward.hip — K9: fused SVDLinear forward  y = (x Bᵀ) Aᵀ + bias  for small token counts (decode / short prefill).
+//
+// Replaces the two dependent nn.Linear launches of /root/reference/modules/svd_linear.py:105-109
+//     y = self.BLinear(inp); y = self.ALinear(y)
+// by ONE persistent launch.  At T <= 128 tokens the op is a pure weight stream (r(K+N) fp16 values, read exactly once) so the design
+// goal is: every byte of B and A crosses HBM once in >=128-byte row segments, the r-wide intermediate z never goes to HBM as a
+// tensor of its own launch, and there is no second launch / no hipBLASLt heuristics call on the critical path.
+//
+//   phase 1   unit = (32-token tile, slice of SL ranks):  z[t, r0:r0+SL] = fp16( sum_k x[t,k] B[r0+j,k] )   (fp32 MFMA accumulate,
+//             rounded to fp16 exactly where the reference's BLinear output is rounded)
+//   grid barrier (all workgroups are co-resident: grid <= number of CUs)
+//   phase 2   unit = (32-token tile, tile of SL2 output features):  y[t, n] = fp16( sum_j z[t,j] A[n,j] + bias[n] )
+//
+// z ([Tpad, rp] fp16, <= 0.5 MB) lives in a caller-provided scratch buffer; it is produced and consumed inside the launch and stays in
+// L2 / MALL.  Both phases use v_mfma_f32_32x32x16_f16 with operands loaded STRAIGHT from global memory: the reduction index of an MFMA
+// may be permuted freely as long as both operands use the same permutation, so lane (i, g) of a wave loads the 64 contiguous
+// bytes  row i, k = 64*it + 32*g .. +31  and feeds 8-value chunk m of them to MFMA m of the iteration — a row is read in
+// 128-byte segments with no LDS staging.  The four waves of a workgroup split the k iterations and reduce through LDS (16 KB).
+// With few tokens the 32-wide MFMA tile is half-masked (SL = 16) to get twice the workgroups streaming: the op is bandwidth-,
+// not MFMA-bound.
+//
+// Layout contract (the Python module pads once at construction):  Bp [rp, K] = B with zero rows appended, Ap [N, rp] = A with zero
+// columns appended, rp a multiple of 64, K a multiple of 64.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ void grid_barrier(unsigned* bar, unsigned nwg) {
+    // sense-reversing barrier on two words: bar[0] arrivals, bar[1] generation.  Zero-initialised once by the caller; reusable.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // every wave: its z stores reach L2 and the L2 is written back (other XCDs)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned gen = __hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned prev = __hip_atomic_fetch_add(&bar[0], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev == nwg - 1) {
+            __hip_atomic_store(&bar[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(&bar[1], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            while (__hip_atomic_load(&bar[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == gen) __builtin_amdgcn_s_sleep(2);
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // every wave: drop stale L1 / non-local L2 lines before reading z
+}
+
+// One 32 x 32 output tile  C[i][j] = sum_k P[prow0+i][k] * Q[qrow0+j][k]  over k in [0, 64*nk), fp32, all four waves.
+// Rows i >= pvalid of P and j >= qvalid of Q read as zero.  Result is left in red[] (sum of the 4 wave partials is done by the caller).
+__device__ __forceinline__ void tile_partial(f32x16& acc, const uint16_t* __restrict__ P, int64_t ldp, int pvalid,
+                                             const uint16_t* __restrict__ Q, int64_t ldq, int qvalid, int nk, int wave, int lane) {
+    const int i = lane & 31, g = lane >> 5;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    // masked rows load a valid (clamped) row and are zeroed in registers: no divergent loads
+    const unsigned pm = i < pvalid ? 0xffffffffu : 0u, qm = i < qvalid ? 0xffffffffu : 0u;
+    const uint4* prow = (const uint4*)(P + (int64_t)min(i, pvalid - 1) * ldp + 32 * g);
+    const uint4* qrow = (const uint4*)(Q + (int64_t)min(i, qvalid - 1) * ldq + 32 * g);
+    // One workgroup per CU means one wave per SIMD: latency is hidden only by loads in flight, so each wave issues the loads of FOUR
+    // of its iterations (32 x 16 bytes per lane) before the first MFMA.  A group's tail iterations re-load a valid one and are masked.
+    for (int base = wave; base < nk; base += 16) {
+        uint4 pv[4][4], qv[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int it = (base + 4 * u < nk) ? base + 4 * u : base;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                pv[u][m] = prow[it * 8 + m];  // 64 halfs = 8 uint4 per iteration per row; this lane's 4 start at 4*g (folded into prow)
+                qv[u][m] = qrow[it * 8 + m];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned live = (base + 4 * u < nk) ? 0xffffffffu : 0u;
+            const unsigned pmu = pm & live;  // masking one operand is enough to drop the product
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                uint4 pw = pv[u][m], qw = qv[u][m];
+                pw.x &= pmu, pw.y &= pmu, pw.z &= pmu, pw.w &= pmu;
+                qw.x &= qm, qw.y &= qm, qw.z &= qm, qw.w &= qm;
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, pw), __builtin_bit_cast(f16x8, qw), acc, 0, 0, 0);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void lowrank_forward_kernel(const uint16_t* __restrict__ x, int T, const uint16_t* __restrict__ Bp,
+                                                                 const uint16_t* __restrict__ Ap, const uint16_t* __restrict__ bias, int N,
+                                                                 int K, int rp, uint16_t* __restrict__ y, uint16_t* __restrict__ z,
+                                                                 unsigned* bar, int sl1, int sl2) {
+    __shared__ float red[4][16 * 64];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int nT = (T + 31) / 32;
+    const int G = gridDim.x;
+
+    // ---- phase 1: z = fp16(x Bᵀ) ---------------------------------------------------------------------------------------------
+    const int ns1 = rp / sl1;
+    for (int u = blockIdx.x; u < nT * ns1; u += G) {
+        const int t0 = (u / ns1) * 32, r0 = (u % ns1) * sl1;
+        f32x16 acc;
+        tile_partial(acc, x + (int64_t)t0 * K, K, T - t0, Bp + (int64_t)r0 * K, K, sl1, K / 64, wave, lane);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) red[wave][q * 64 + lane] = acc[q];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + 256 * q, reg = e >> 6, l = e & 63;
+            const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (l >> 5), col = l & 31;
+            const float v = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+            if (col < sl1) z[(int64_t)(t0 + row) * rp + r0 + col] = f32_to_f16_bits(v);  // z has 32*nT rows: no token mask needed
+        }
+        __syncthreads();
+    }
+
+    grid_barrier(bar, (unsigned)G);
+
+    // ---- phase 2: y = fp16(z Aᵀ + bias) --------------------------------------------------------------------------------------
+    const int ns2 = (N + sl2 - 1) / sl2;
+    for (int u = blockIdx.x; u < nT * ns2; u += G) {
+        const int t0 = (u / ns2) * 32, n0 = (u % ns2) * sl2;
+        const int nvalid = min(sl2, N - n0);
+        f32x16 acc;
+        tile_partial(acc, z + (int64_t)t0 * rp, rp, 32, Ap + (int64_t)n0 * rp, rp, nvalid, rp / 64, wave, lane);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) red[wave][q * 64 + lane] = acc[q];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + 256 * q, reg = e >> 6, l = e & 63;
+            const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (l >> 5), col = l & 31;
+            if (col < nvalid && t0 + row < T) {
+                float v = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+                if (bias) v += f16_bits_to_f32(bias[n0 + col]);
+                y[(int64_t)(t0 + row) * N + n0 + col] = f32_to_f16_bits(v);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t asvd_lowrank_padded_rank(int64_t r) { return round_up64(r, 64); }
+
+size_t asvd_lowrank_work_bytes(int64_t T, int64_t rp) {
+    // [barrier: 256 bytes][z: 32*ceil(T/32) x rp fp16]
+    return 256 + (size_t)(round_up64(T, 32) * rp) * sizeof(uint16_t);
+}
+
+int asvd_lowrank_forward_f16(const void* x, int64_t T, const void* Bp, const void* Ap, const void* bias, int64_t N, int64_t K, int64_t rp,
+                             void* y, void* work, size_t work_bytes, void* stream) {
+    if (!x || !Bp || !Ap || !y || !work) return ASVD_E_BADARG;
+    if (T < 1 || T > ASVD_LOWRANK_MAX_TOKENS || N < 1 || K < 64 || (K % 64) || rp < 64 || (rp % 64)) return ASVD_E_BADARG;
+    if (work_bytes < asvd_lowrank_work_bytes(T, rp)) return ASVD_E_WORKSPACE;
+    if ((((uintptr_t)x) | ((uintptr_t)Bp) | ((uintptr_t)Ap) | ((uintptr_t)work)) & 15) return ASVD_E_BADARG;
+    int dev = 0, cus = 0;
+    ASVD_HIP_CHECK(hipGetDevice(&dev));
+    ASVD_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const int nT = (int)((T + 31) / 32);
+    // half-masked tiles when full ones would leave more than half of the CUs without a unit (bandwidth-bound: more streams win)
+    const int sl1 = (nT * (rp / 32) >= cus / 2) ? 32 : 16;
+    const int sl2 = (nT * ((N + 31) / 32) >= cus / 2) ? 32 : 16;
+    const int64_t units = (int64_t)nT * ((rp / sl1) > ((N + sl2 - 1) / sl2) ? (rp / sl1) : ((N + sl2 - 1) / sl2));
+    const int grid = (int)(units < cus ? units : cus);  // <= one workgroup per CU: co-resident, the in-kernel barrier cannot deadlock
+    unsigned* bar = (unsigned*)work;
+    uint16_t* z = (uint16_t*)((char*)work + 256);
+    hipLaunchKernelGGL(lowrank_forward_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, (int)T,
+                       (const uint16_t*)Bp, (const uint16_t*)Ap, (const uint16_t*)bias, (int)N, (int)K, (int)rp, (uint16_t*)y, z, bar, sl1,
+                       sl2);
+    ASVD_HIP_CHECK(hipGetLastError());
+    return ASVD_OK;
+}
+
+}  // extern "C"

@@ -832,6 +832,9 @@ __global__ __launch_bounds__(256) void update_kernel(float* __restrict__ X, int6
     ASVD_KERNEL_RELEASE();
 }
 
+// bit surgery for the XOR schedule: pair slot <-> lower member, quad index -> representative
+__device__ __forceinline__ int insert_zero_bit(int v, int pos) { return ((v >> pos) << (pos + 1)) | (v & ((1 << pos) - 1)); }
+__device__ __forceinline__ int remove_bit(int v, int pos) { return ((v >> (pos + 1)) << pos) | (v & ((1 << pos) - 1)); }
 #include "twolevel.h"
 
 // --------------------------------------------------------------------------------------------------
@@ -1000,8 +1003,6 @@ __global__ __launch_bounds__(256) void fullcheck_kernel(const float* __restrict_
 // + prefetch 64 VGPRs) and prefetches the next tile into registers while the current one is in the matrix pipe.
 constexpr int TLQ = 4 * PB + 4;  // LDS row stride of the quad tile in floats (528 B: 16-B multiple, conflict-free b128 row reads)
 
-__device__ __forceinline__ int insert_zero_bit(int v, int pos) { return ((v >> pos) << (pos + 1)) | (v & ((1 << pos) - 1)); }
-__device__ __forceinline__ int remove_bit(int v, int pos) { return ((v >> (pos + 1)) << pos) | (v & ((1 << pos) - 1)); }
 
 __global__ __launch_bounds__(256, 1) void upgram_kernel(float* __restrict__ X, int64_t panel_stride, int64_t batch_stride, int nb,
                                                         int d, int e, int R, int m_pad, int rows_per_wg,
@@ -1682,7 +1683,7 @@ struct Plan {
     int nsplit, rows_per_split, rows_per_wg, nchunks;
     int fused, nchunks_f, rows_per_wg_f;  // upgram path (XOR ordering, power-of-two panel count)
     // two-level dense sweeps (twolevel.h): ns super-panels of 64 columns, npairs_s pair slots per super-step (power-of-two padded)
-    int two, ns, npairs_s, nsplit_s, rows_per_split_s, nchunks_s, rows_per_wg_s;
+    int two, ns, npairs_s, nsplit_s, rows_per_split_s, nchunks_s, rows_per_wg_s, nchunks_q, rows_per_wg_q;
     size_t off_gd32, off_gx6, off_q0, off_d0, off_qfin, off_subact;
     int64_t panel_stride, batch_stride;
     // workspace offsets in bytes
@@ -1781,6 +1782,13 @@ int make_plan(int batch, int64_t m, int64_t n, int want_u, int want_vv, Plan& p)
         int64_t nc = std::max<int64_t>(1, std::min<int64_t>(wantc, ceil_div64(tiles, 4)));
         p.rows_per_wg_s = (int)(ceil_div64(tiles, nc) * 32);
         p.nchunks_s = (int)ceil_div64(p.R_upd, p.rows_per_wg_s);
+        // supgram (update of a step fused with the Gram tiles of the next): one 512-thread workgroup per CU and quad of four
+        // super-panels; >= 1024 workgroups per launch where the rows allow >= 8 tiles each
+        const int64_t quads = std::max<int64_t>(1, pw2 / 4) * launch_batch;
+        int64_t nq = std::max<int64_t>(1, std::min<int64_t>(ceil_div64(1024, quads), std::max<int64_t>(1, tiles / 8)));
+        if (getenv("ASVD_SUPGRAM_CHUNKS")) nq = std::max<int64_t>(1, std::min<int64_t>(atoi(getenv("ASVD_SUPGRAM_CHUNKS")), tiles));
+        p.rows_per_wg_q = (int)(ceil_div64(tiles, nq) * 32);
+        p.nchunks_q = (int)ceil_div64(p.R_upd, p.rows_per_wg_q);
     }
     p.panel_stride = (int64_t)p.R * PB;
     p.batch_stride = p.panel_stride * p.nb;
@@ -1800,7 +1808,7 @@ int make_plan(int batch, int64_t m, int64_t n, int want_u, int want_vv, Plan& p)
     p.off_plist = take((size_t)batch * p.nb * p.nb * sizeof(int));  // per-step lists of marked pairs (bound: steps x nb/2 slots per problem)
     const size_t t2 = p.two ? 1 : 0;
     p.off_gd32 = take(t2 * batch * p.nb * 1024 * sizeof(float));                          // carried 32x32 diagonal blocks, one per panel
-    p.off_gx6 = take(t2 * batch * p.npairs_s * p.nsplit_s * 6 * 1024 * sizeof(float));    // sgram6 partial tiles
+    p.off_gx6 = take(t2 * batch * p.npairs_s * std::max(p.nsplit_s, p.nchunks_q) * 6 * 1024 * sizeof(float));  // sgram6 / supgram partial tiles
     p.off_q0 = take(t2 * batch * p.npairs_s * 2 * PW * PW * sizeof(float));               // Q of the two step-0 solves
     p.off_d0 = take(t2 * batch * p.npairs_s * 4 * 1024 * sizeof(float));                  // diagonal blocks after step 0
     p.off_qfin = take(t2 * batch * p.npairs_s * SP * SP * sizeof(float));                 // Q^(0) Q^(1) of every super-pair
@@ -1814,7 +1822,7 @@ int make_plan(int batch, int64_t m, int64_t n, int want_u, int want_vv, Plan& p)
 thread_local bool g_prof_enabled = false;
 // classes: 0 pack / reduce, 1 two-level Gram pass, 2 eigen-solves, 3 two-level update pass, 4 finalize, 5 coupling snapshot,
 //          6 single-level Gram, 7 single-level update
-constexpr int NPROF = 8;
+constexpr int NPROF = 9;
 thread_local float g_prof_ms[NPROF] = {0};
 thread_local int g_prof_launches[NPROF] = {0};
 thread_local long long g_prof_pairs[3] = {0, 0, 0};  // 32-panel pair visits, rotated 32-panel pairs, updated super-pairs (two-level sweeps)
@@ -2094,18 +2102,52 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
             ASVD_HIP_CHECK(hipMemcpyAsync(hflag.data(), pflag, hflag.size(), hipMemcpyDeviceToHost, st));
             ASVD_HIP_CHECK(hipStreamSynchronize(st));
             if (debug) fprintf(stderr, "[asvd_svd]   snapshot + readback %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - sweep_t0).count());
-            // 2. marks -> per-step lists (step d-1 holds the pairs with I ^ J == d: disjoint by construction)
+            // 2. marks -> lists of disjoint pairs.  The pairs of one XOR step (I ^ J == d) are disjoint by construction, but late in the
+            // iteration a step holds a handful of pairs and a sweep of nb-1 three-launch steps is all launch latency.  The marked
+            // pairs are therefore packed first-fit, in schedule order (step, then I), into ROUNDS whose pairs share no panel (per
+            // problem: a bitmask of used panels per round); a round is launched like a step.  Any order of disjoint rotations is a
+            // valid Jacobi sweep; first-fit keeps the nearest-neighbour-first order of the XOR schedule among conflicting pairs.
+            // ASVD_SPARSE_ROUNDS=0 keeps one list per XOR step.  (The list slots are indexed by `step` below in both cases.)
             hlist.clear();
-            std::vector<std::vector<int>> tmp;  // [b_local * nsteps + step]
+            std::vector<std::vector<int>> tmp;  // [b_local * nsteps + round]
+            const bool pack_rounds = !(getenv("ASVD_SPARSE_ROUNDS") && atoi(getenv("ASVD_SPARSE_ROUNDS")) == 0);
+            const int words = (p.nb + 63) / 64;
+            std::vector<uint64_t> used;  // [round][words] of the problem being packed
             for (int g = 0; g < ngroups; ++g) {
                 const int b0 = gb0[g], nbg = gnb[g];
                 tmp.assign((size_t)nbg * nsteps, std::vector<int>());
                 for (int bl = 0; bl < nbg; ++bl) {
                     if (host_done[b0 + bl]) continue;
                     const unsigned char* f = hflag.data() + (size_t)(b0 + bl) * p.nb * p.nb;
-                    for (int I = 0; I < p.nb; ++I)
-                        for (int J = I + 1; J < p.nb; ++J)
-                            if (f[(size_t)I * p.nb + J]) { tmp[(size_t)bl * nsteps + ((I ^ J) - 1)].push_back((I << 16) | J); ++marked_total; }
+                    bool packed = pack_rounds;
+                    if (pack_rounds) {
+                        used.assign((size_t)nsteps * words, 0);
+                        long long cnt = 0;
+                        for (int d = 1; d <= nsteps && packed; ++d)
+                            for (int I = 0; I < p.nb && packed; ++I) {
+                                const int J = I ^ d;
+                                if (J <= I || J >= p.nb || !f[(size_t)I * p.nb + J]) continue;
+                                int r = 0;
+                                for (; r < nsteps; ++r) {
+                                    uint64_t* u = &used[(size_t)r * words];
+                                    if (!((u[I >> 6] >> (I & 63)) & 1) && !((u[J >> 6] >> (J & 63)) & 1)) {
+                                        u[I >> 6] |= 1ull << (I & 63);
+                                        u[J >> 6] |= 1ull << (J & 63);
+                                        break;
+                                    }
+                                }
+                                if (r == nsteps) { packed = false; break; }  // cannot happen below ~nsteps/2 marks per panel; fall back
+                                tmp[(size_t)bl * nsteps + r].push_back((I << 16) | J);
+                                ++cnt;
+                            }
+                        if (packed) marked_total += cnt;
+                        else
+                            for (int r = 0; r < nsteps; ++r) tmp[(size_t)bl * nsteps + r].clear();
+                    }
+                    if (!packed)
+                        for (int I = 0; I < p.nb; ++I)
+                            for (int J = I + 1; J < p.nb; ++J)
+                                if (f[(size_t)I * p.nb + J]) { tmp[(size_t)bl * nsteps + ((I ^ J) - 1)].push_back((I << 16) | J); ++marked_total; }
                 }
                 for (int step = 0; step < nsteps; ++step) {
                     size_t mx = 0;
@@ -2283,8 +2325,19 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
             const bool gram_split = split_on && getenv("ASVD_GRAM_SPLIT") && atoi(getenv("ASVD_GRAM_SPLIT")) == 1;
             // local super-levels D = 1..L run twice at the start of the sweep (the two-level form of ASVD_DUP; ASVD_DUP2=L)
             const int dup2 = std::min(nsuper, getenv("ASVD_DUP2") ? atoi(getenv("ASVD_DUP2")) : 0);
+            // supgram: the update of step D also leaves the Gram tiles of the step that follows (one pass instead of two); the
+            // stand-alone Gram pass then runs only in front of the first super-step.  Needs split-bf16; ASVD_SUPGRAM=0 turns it off.
+            const bool fuse_ug = split_bf16 && p.npairs_s >= 2 && !(getenv("ASVD_SUPGRAM") && atoi(getenv("ASVD_SUPGRAM")) == 0);
+            if (fuse_ug)
+                ASVD_HIP_CHECK(hipFuncSetAttribute((const void*)supgram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   (int)(SUPGRAM_SMEM_FLOATS * sizeof(float))));
+            const int gx_slots = std::max(p.nsplit_s, p.nchunks_q);  // partial-tile slots per super-pair in the buffer
+            auto level_of = [&](int di) { return di < dup2 ? di + 1 : di - dup2 + 1; };
             for (int di = 0; di < nsuper + dup2; ++di) {
-                const int D = di < dup2 ? di + 1 : di - dup2 + 1;
+                const int D = level_of(di);
+                const int E = (di + 1 < nsuper + dup2) ? level_of(di + 1) : 0;  // 0: last super-step of the sweep
+                const bool gram_in = !(fuse_ug && di > 0 && level_of(di - 1) != D);   // tiles of this step not left by the previous launch
+                const bool gram_out = fuse_ug && E != 0 && E != D;
                 for (int g = 0; g < ngroups; ++g) {
                     const int b0 = gb0[g], nbg = gnb[g];
                     hipStream_t s2 = gst[g];
@@ -2292,15 +2345,15 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
                     EvdV3 v3{};
                     v3.ns = p.ns;
                     v3.nbpan = p.nb;
-                    v3.nsplit6 = p.nsplit_s;
-                    float* Gx6g = (float*)(wb + p.off_gx6) + (int64_t)b0 * p.npairs_s * p.nsplit_s * 6 * 1024;
+                    v3.nsplit6 = gram_in ? p.nsplit_s : p.nchunks_q;
+                    float* Gx6g = (float*)(wb + p.off_gx6) + (int64_t)b0 * p.npairs_s * gx_slots * 6 * 1024;
                     v3.Gx6 = Gx6g;
                     v3.Gd32 = (float*)(wb + p.off_gd32) + (int64_t)b0 * p.nb * 1024;
                     v3.Q0 = (float*)(wb + p.off_q0) + (int64_t)b0 * p.npairs_s * 2 * PW * PW;
                     v3.D0 = (float*)(wb + p.off_d0) + (int64_t)b0 * p.npairs_s * 4 * 1024;
                     v3.Qfin = (float*)(wb + p.off_qfin) + (int64_t)b0 * p.npairs_s * SP * SP;
                     v3.subact = (int*)(wb + p.off_subact) + (int64_t)b0 * p.npairs_s * 4;
-                    {
+                    if (gram_in) {
                         ProfScope ps(1, s2);
                         if (gram_split)
                             sgram6_kernel<1><<<dim3(p.nsplit_s, p.npairs_s, nbg), 256, 0, s2>>>(Xg, p.panel_stride, p.batch_stride, p.ns, D, p.m_pad,
@@ -2317,8 +2370,12 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
                                                                                    inner_sweeps, p.nb, D - 1, kb, hist_dev, nullptr, 0, v3);
                     }
                     {
-                        ProfScope ps(3, s2);
-                        if (split_bf16)
+                        ProfScope ps(gram_out ? 8 : 3, s2);
+                        if (gram_out)
+                            supgram_kernel<<<dim3(p.nchunks_q, (2 * p.npairs_s) / 4, nbg), 512, SUPGRAM_SMEM_FLOATS * sizeof(float), s2>>>(
+                                Xg, p.panel_stride, p.batch_stride, p.ns, D, E, p.R_upd, p.m_pad, p.rows_per_wg_q, v3.Qfin, v3.subact, Gx6g, done + b0,
+                                nupd + b0, p.npairs_s);
+                        else if (split_bf16)
                             supdate_split_kernel<<<dim3(p.nchunks_s, p.npairs_s, nbg), 256, 0, s2>>>(Xg, p.panel_stride, p.batch_stride, p.ns, D,
                                                                                                     p.R_upd, p.rows_per_wg_s, v3.Qfin, v3.subact, done + b0, nupd + b0);
                         else
@@ -2647,6 +2704,25 @@ int asvd_test_supdate(int split, float* X, int64_t panel_stride, int64_t batch_s
         supdate_split_kernel<<<dim3(nchunks, npairs, batch), 256, 0, st>>>(X, panel_stride, batch_stride, ns, D, R, rows_per_wg, Qfin, subact, done, nupd);
     else
         supdate_kernel<<<dim3(nchunks, npairs, batch), 256, 0, st>>>(X, panel_stride, batch_stride, ns, D, R, rows_per_wg, Qfin, subact, done, nupd);
+    ASVD_HIP_CHECK(hipGetLastError());
+    return ASVD_OK;
+}
+
+// Test hook: ONE launch of the fused update + next-step Gram kernel (supgram_kernel) on caller-built panels.  Gx: [batch][npairs][nchunks][6][1024]
+// partial tiles of super-step E, indexed by E's pair slots.  E != D, both in [1, 2 * npairs).
+int asvd_test_supgram(float* X, int64_t panel_stride, int64_t batch_stride, int ns, int D, int E, int R, int m_pad, int rows_per_wg,
+                      const float* Qfin, const int* subact, float* Gx, const int* done, int* nupd, int nchunks, int npairs, int batch, void* stream) {
+    if (!X || !Qfin || !subact || !Gx || !done || !nupd || ns < 3 || npairs < 2 || D < 1 || E < 1 || D == E || D >= 2 * npairs || E >= 2 * npairs ||
+        R < 32 || (R % 32) || (m_pad % 32) || rows_per_wg < 32 || (rows_per_wg % 32))
+        return ASVD_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    {
+        const int order = 1;
+        ASVD_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_pair_order), &order, sizeof(int), 0, hipMemcpyHostToDevice));
+    }
+    ASVD_HIP_CHECK(hipFuncSetAttribute((const void*)supgram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SUPGRAM_SMEM_FLOATS * sizeof(float))));
+    supgram_kernel<<<dim3(nchunks, (2 * npairs) / 4, batch), 512, SUPGRAM_SMEM_FLOATS * sizeof(float), st>>>(X, panel_stride, batch_stride, ns, D, E, R, m_pad,
+                                                                                                           rows_per_wg, Qfin, subact, Gx, done, nupd, npairs);
     ASVD_HIP_CHECK(hipGetLastError());
     return ASVD_OK;
 }

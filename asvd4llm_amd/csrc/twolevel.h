@@ -355,6 +355,241 @@ __global__ __launch_bounds__(256, 2) void supdate_split_kernel(float* __restrict
     supdate_split_body(ctx, smem, X, panel_stride, batch_stride, ns, D, R, rows_per_wg, Qfin, subact, done, nupd);
 }
 
+// --------------------------------------------------------------------------------------------------
+// supgram: the update of super-step D fused with the Gram tiles of super-step E (the step that follows) — the two-level form of
+// upgram_kernel.  Under the XOR ordering the four super-panels {a, a^D, a^E, a^D^E} (a QUAD) are closed under both steps: the pairs
+// (a, a^D) and (a^E, a^D^E) rotate now, the pairs (a, a^E) and (a^D, a^D^E) meet next.  One workgroup of EIGHT waves streams a row
+// chunk of a quad ONCE: 32-row tiles of the eight panels go through a double-buffered LDS image; wave w owns output panel w
+// (waves 0-3: first pair, 4-7: second pair; its 128x32 slice of Qfin sits pre-split in 96 VGPRs), writes it back, and leaves it —
+// already split into three bf16 parts, in MFMA operand order — in LDS.  The C layout of the update (lane = column, registers =
+// rows) IS the A/B operand layout of the Gram product over rows (the reduction index may be permuted freely as long as both
+// operands agree), so the twelve 32x32 tiles of the two next pairs are accumulated from those images without any transpose:
+// 24 half-tiles (tile x 16-row k-step), three per wave, held in registers over the whole chunk.
+// HBM traffic of a super-step drops from read + (read + write) to one read + one write: the separate sgram6 pass (1/3 of the
+// streaming bytes, and an fp32-MFMA-bound one) disappears; MFMA work per tile: 8 x 48 (update) + 8 x 18 (Gram) bf16 instructions.
+// Super-panels beyond ns (power-of-two padding of the schedule) read as absent: no loads, no stores, their pairs are skipped.
+constexpr int QLD = 4 * SW + 4;                                    // LDS row stride of the quad tile (1040 B)
+constexpr int SUPGRAM_TILE_FLOATS = 32 * QLD;                      // one 32-row image of the eight panels
+constexpr int SUPGRAM_OPND_WORDS = 8 * 2 * 3 * 64 * 4;             // [panel][k-step][part][lane] x 16 B
+constexpr int SUPGRAM_SMEM_FLOATS = 2 * SUPGRAM_TILE_FLOATS + SUPGRAM_OPND_WORDS;  // 115,712 B
+static_assert(SUPGRAM_SMEM_FLOATS >= 24 * 1024, "the final reduction reuses the whole buffer");
+
+__global__ __launch_bounds__(512, 1) void supgram_kernel(float* __restrict__ X, int64_t panel_stride, int64_t batch_stride, int ns, int D,
+                                                         int E, int R, int m_pad, int rows_per_wg, const float* __restrict__ Qfin,
+                                                         const int* __restrict__ subact, float* __restrict__ Gx, const int* __restrict__ done,
+                                                         int* __restrict__ nupd, int npairs) {
+    extern __shared__ __attribute__((aligned(16))) float sg_smem[];
+    const int chunk = blockIdx.x, quad = blockIdx.y, b = blockIdx.z, nsplit = gridDim.x;
+    ASVD_KERNEL_ACQUIRE();
+    if (done[b]) return;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5, c = lane & 31;
+    // ---- quad geometry (uniform) ----
+    const int h1 = 31 - __clz(D);
+    const int e1 = ((E >> h1) & 1) ? (E ^ D) : E;
+    const int h2 = 31 - __clz(e1);
+    const int a0 = insert_zero_bit(insert_zero_bit(quad, min(h1, h2)), max(h1, h2));
+    const int P0 = a0, P1 = a0 ^ D, P2 = a0 ^ E, P3 = a0 ^ D ^ E;  // super-panels in tile slots 0..3
+    auto Pof = [&](int slot) { return slot == 0 ? P0 : (slot == 1 ? P1 : (slot == 2 ? P2 : P3)); };  // no indexed arrays: they go to scratch
+    // current pairs (step D): A = slots (0,1), B = slots (2,3); Q order is (lower, upper) = (bit h1 clear, set)
+    const bool swapB = (P2 >> h1) & 1;
+    const int curS1 = swapB ? 3 : 2, curT1 = swapB ? 2 : 3;  // pair A: S = slot 0, T = slot 1
+    const int kcur0 = remove_bit(P0, h1), kcur1 = remove_bit(Pof(curS1), h1);
+    const bool act0 = P0 < ns && P1 < ns && pair_active(subact, (int64_t)b * npairs + kcur0);
+    const bool act1 = P2 < ns && P3 < ns && pair_active(subact, (int64_t)b * npairs + kcur1);
+    // next pairs (step E): C = slots (0,2), D' = slots (1,3)
+    const int hE = 31 - __clz(E);
+    const bool swapD = (P1 >> hE) & 1;
+    const int nxtS1 = swapD ? 3 : 1, nxtT1 = swapD ? 1 : 3;  // pair C: S = slot 0, T = slot 2
+    const int knxt0 = remove_bit(P0, hE), knxt1 = remove_bit(Pof(nxtS1), hE);
+    const bool have0 = P0 < ns && P2 < ns, have1 = P1 < ns && P3 < ns;
+    if (chunk == 0 && tid == 0) {
+        const int n = (act0 ? 1 : 0) + (act1 ? 1 : 0);
+        if (n) atomicAdd(&nupd[b], n);  // instrumentation: super-pairs updated in this sweep
+    }
+
+    float* __restrict__ Xb = X + (int64_t)b * batch_stride;
+    const int mypr = w >> 2, ob = w & 3;                      // this wave's pair and output block in Q order
+    const int mS = mypr ? curS1 : 0, mT = mypr ? curT1 : 1;   // tile slots of this wave's pair in Q order
+    const int oslot = ob < 2 ? mS : mT;                       // tile slot and panel (0..7) it owns
+    const int otp = 2 * oslot + (ob & 1);
+    const bool mine = mypr ? act1 : act0;
+    float* __restrict__ Pw = Xb + (int64_t)(2 * min(Pof(oslot), ns - 1) + (ob & 1)) * panel_stride;
+    // B operand of k-step s: lane (j = c, group h) holds Q[16 s + 8 h + e][32 ob + c], e = 0..7, in three bf16 parts
+    u32x4 q1[8], q2[8], q3[8];
+    if (mine) {
+        const float* __restrict__ Qp = Qfin + ((int64_t)b * npairs + (mypr ? kcur1 : kcur0)) * (SP * SP);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = Qp[(16 * s + 8 * h + e) * SP + 32 * ob + c];
+#pragma unroll
+            for (int e2 = 0; e2 < 4; ++e2) {
+                unsigned x, y, z;
+                split3(v[2 * e2], v[2 * e2 + 1], x, y, z);
+                q1[s][e2] = x; q2[s][e2] = y; q3[s][e2] = z;
+            }
+        }
+    }
+    // A operand of k-step s comes from tile columns of slot (s < 4 ? S : T) of this wave's pair
+    const int colS = 64 * mS, colT = 64 * mT;
+
+    float* tile0 = sg_smem;
+    float* tile1 = sg_smem + SUPGRAM_TILE_FLOATS;
+    u32x4* opnd = (u32x4*)(sg_smem + 2 * SUPGRAM_TILE_FLOATS);
+
+    // ---- this wave's three Gram half-tiles: unit u = w + 8 j -> tile u >> 1 (0..5 pair C, 6..11 pair D'), k-step u & 1 ----
+    // sgram6 tile order [0,2] [0,3] [1,2] [1,3] [0,1] [2,3] over the pair's panels (0,1 = lower super-panel, 2,3 = upper)
+    auto unit = [&](int j, int& pa, int& pb, bool& on) {
+        const int u = w + 8 * j, tt = u >> 1, np = tt >= 6 ? 1 : 0, t6 = tt - 6 * np;
+        const int xa = t6 < 2 ? 0 : (t6 < 4 ? 1 : (t6 == 4 ? 0 : 2));
+        const int xb = t6 == 0 ? 2 : (t6 == 1 ? 3 : (t6 == 2 ? 2 : (t6 == 3 ? 3 : (t6 == 4 ? 1 : 3))));
+        const int sS = np ? nxtS1 : 0, sT = np ? nxtT1 : 2;
+        pa = 2 * (xa < 2 ? sS : sT) + (xa & 1);
+        pb = 2 * (xb < 2 ? sS : sT) + (xb & 1);
+        on = np ? have1 : have0;
+    };
+    int ga0, gb0, ga1, gb1, ga2, gb2;
+    bool gon0, gon1, gon2;
+    unit(0, ga0, gb0, gon0);
+    unit(1, ga1, gb1, gon1);
+    unit(2, ga2, gb2, gon2);
+    const int kh = w & 1;
+    f32x16 g0 = {0}, g1 = {0}, g2 = {0};
+
+    const int r_begin = chunk * rows_per_wg;
+    const int r_end = min(r_begin + rows_per_wg, R);
+    if (r_begin < r_end) {
+        f32x4 pre[4];
+        auto fetch = [&](int r0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int q = tid + 512 * j, tp = q >> 8, idx = q & 255;
+                const int sp = Pof(tp >> 1);
+                if (sp < ns)
+                    pre[j] = *(const f32x4*)(Xb + (int64_t)(2 * sp + (tp & 1)) * panel_stride + (int64_t)r0 * PB + idx * 4);
+                else
+                    pre[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        };
+        auto stash = [&](float* t) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int q = tid + 512 * j, tp = q >> 8, idx = q & 255;
+                *(f32x4*)(t + (idx >> 3) * QLD + tp * 32 + (idx & 7) * 4) = pre[j];
+            }
+        };
+        auto gram = [&]() {
+            auto mm = [&](int pa, int pb, f32x16 acc) {
+                const u32x4* oa = opnd + ((pa * 2 + kh) * 3) * 64 + lane;
+                const u32x4* ob_ = opnd + ((pb * 2 + kh) * 3) * 64 + lane;
+                const bf16x8 a1 = __builtin_bit_cast(bf16x8, oa[0]), a2 = __builtin_bit_cast(bf16x8, oa[64]), a3 = __builtin_bit_cast(bf16x8, oa[128]);
+                const bf16x8 b1 = __builtin_bit_cast(bf16x8, ob_[0]), b2 = __builtin_bit_cast(bf16x8, ob_[64]), b3 = __builtin_bit_cast(bf16x8, ob_[128]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc, 0, 0, 0);
+                return acc;
+            };
+            if (gon0) g0 = mm(ga0, gb0, g0);
+            if (gon1) g1 = mm(ga1, gb1, g1);
+            if (gon2) g2 = mm(ga2, gb2, g2);
+        };
+        int cur = 0;
+        fetch(r_begin);
+        stash(tile0);
+        __syncthreads();
+        bool pending = false;  // Gram of the previous tile not yet accumulated (its operands are in opnd)
+        for (int r0 = r_begin; r0 < r_end; r0 += 32) {
+            const bool more = r0 + 32 < r_end;
+            if (more) fetch(r0 + 32);
+            const float* tl = cur ? tile1 : tile0;
+            if (pending) gram();  // reads opnd of the previous tile
+            f32x16 acc;
+            if (mine) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    const float* my = tl + c * QLD + (s < 4 ? colS : colT) + 16 * (s & 3) + 8 * h;
+                    const f32x4 v0 = *(const f32x4*)(my);
+                    const f32x4 v1 = *(const f32x4*)(my + 4);
+                    u32x4 a1, a2, a3;
+                    {
+                        unsigned x, y, z;
+                        split3(v0[0], v0[1], x, y, z); a1[0] = x; a2[0] = y; a3[0] = z;
+                        split3(v0[2], v0[3], x, y, z); a1[1] = x; a2[1] = y; a3[1] = z;
+                        split3(v1[0], v1[1], x, y, z); a1[2] = x; a2[2] = y; a3[2] = z;
+                        split3(v1[2], v1[3], x, y, z); a1[3] = x; a2[3] = y; a3[3] = z;
+                    }
+                    const bf16x8 A1 = __builtin_bit_cast(bf16x8, a1), A2 = __builtin_bit_cast(bf16x8, a2), A3 = __builtin_bit_cast(bf16x8, a3);
+                    const bf16x8 B1 = __builtin_bit_cast(bf16x8, q1[s]), B2 = __builtin_bit_cast(bf16x8, q2[s]), B3 = __builtin_bit_cast(bf16x8, q3[s]);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A3, B1, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B3, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, B2, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, B1, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B2, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B1, acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int i = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                    Pw[(int64_t)(r0 + i) * PB + c] = acc[reg];
+                }
+            } else {  // pair at rest (or absent: zeros): the panel as it is, in the C layout
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int i = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                    acc[reg] = tl[i * QLD + otp * 32 + c];
+                }
+            }
+            __syncthreads();  // every wave is done with the previous tile's operands (and with tile[cur] as far as the stash below matters)
+            const bool gram_rows = r0 < m_pad;  // rows of the matrix proper only, not accumulated V rows
+            if (gram_rows) {
+#pragma unroll
+                for (int k2 = 0; k2 < 2; ++k2) {
+                    u32x4 p1, p2, p3;
+#pragma unroll
+                    for (int e2 = 0; e2 < 4; ++e2) {
+                        unsigned x, y, z;
+                        split3(acc[8 * k2 + 2 * e2], acc[8 * k2 + 2 * e2 + 1], x, y, z);
+                        p1[e2] = x; p2[e2] = y; p3[e2] = z;
+                    }
+                    u32x4* o = opnd + ((otp * 2 + k2) * 3) * 64 + lane;
+                    o[0] = p1; o[64] = p2; o[128] = p3;
+                }
+            }
+            if (more) stash(cur ? tile0 : tile1);
+            __syncthreads();
+            pending = gram_rows;
+            cur ^= 1;
+        }
+        if (pending) gram();
+    }
+
+    // ---- the two k-steps of a tile sit in waves 2t and 2t+1 (j = 0), 2t-8 .. (j = 1), ...: sum through LDS, coalesced store ----
+    __syncthreads();
+    float* red = sg_smem;  // [unit u = 0..23][16 x 64]
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        red[(w + 0) * 1024 + reg * 64 + lane] = g0[reg];
+        red[(w + 8) * 1024 + reg * 64 + lane] = g1[reg];
+        red[(w + 16) * 1024 + reg * 64 + lane] = g2[reg];
+    }
+    __syncthreads();
+    for (int o = tid; o < 12 * 1024; o += 512) {
+        const int tt = o >> 10, e = o & 1023, np = tt >= 6 ? 1 : 0;
+        if (!(np ? have1 : have0)) continue;
+        const float v = red[(2 * tt) * 1024 + e] + red[(2 * tt + 1) * 1024 + e];
+        const int reg = e >> 6, ln = e & 63;
+        const int i = (reg & 3) + 8 * (reg >> 2) + 4 * (ln >> 5), j = ln & 31;
+        Gx[((((int64_t)b * npairs + (np ? knxt1 : knxt0)) * nsplit + chunk) * 6 + (tt - 6 * np)) * 1024 + i * 32 + j] = v;
+    }
+    ASVD_KERNEL_RELEASE();
+}
+
 // ==================================================================================================
 // Dual launches: software pipelining on ONE stream.  The phases of a super-step — Gram pass (G), eigen-solves of inner step 0 and 1
 // (E1, E2), update pass (U) — are bound by different resources: G and U stream panels through HBM and the matrix pipe, E1 and E2 are

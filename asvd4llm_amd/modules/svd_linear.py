@@ -22,6 +22,10 @@ def _strict():
     return os.environ.get("ASVD_STRICT", "0") == "1"
 
 
+def _fused_forward_enabled():  # ASVD_FUSED_FORWARD=0 keeps every forward on the two nn.Linear launches
+    return os.environ.get("ASVD_FUSED_FORWARD", "1") != "0"
+
+
 class SVDLinear(nn.Module):
     """nn.Module{ALinear: Linear(r->out, bias?), BLinear: Linear(in->r, no bias), truncation_rank} (svd_linear.py:7-24)."""
 
@@ -209,8 +213,27 @@ class SVDLinear(nn.Module):
         new_linear.to(dtype)
         return new_linear
 
+    def _fused_state(self):
+        """Padded copies of the two factors for the one-launch forward (ops.lowrank_pack), rebuilt when either weight changes."""
+        A, B = self.ALinear.weight, self.BLinear.weight
+        key = (A.data_ptr(), A._version, B.data_ptr(), B._version, A.device)
+        st = getattr(self, "_fused", None)
+        if st is None or st[0] != key:
+            st = (key,) + ops.lowrank_pack(A.detach(), B.detach())
+            self._fused = st
+        return st[1:]
+
     def forward(self, inp):
-        # compute USV^Tx + b  (svd_linear.py:105-109); two skinny GEMMs, ordinary nn.Linear forward
+        # compute USV^Tx + b  (svd_linear.py:105-109).  Few tokens (decode, short prefill), fp16, no autograd: ONE persistent launch that
+        # streams B and A once and keeps the r-wide intermediate on chip (K10, csrc/lowrank_forward.hip).  Otherwise the reference's
+        # two skinny GEMMs through nn.Linear (hipBLASLt), where the weights are amortised over many tokens.
+        if (inp.is_cuda and inp.dtype == torch.float16 and self.BLinear.weight.dtype == torch.float16 and inp.shape[-1] % 64 == 0
+                and 0 < inp.numel() // inp.shape[-1] <= ops.LOWRANK_MAX_TOKENS and self.BLinear.bias is None and _fused_forward_enabled()
+                and not (torch.is_grad_enabled() and (inp.requires_grad or self.ALinear.weight.requires_grad or self.BLinear.weight.requires_grad))):
+            Ap, Bp, work = self._fused_state()
+            x2d = inp.reshape(-1, inp.shape[-1])
+            y = ops.lowrank_forward(x2d if x2d.is_contiguous() else x2d.contiguous(), Ap, Bp, self.ALinear.bias, work)
+            return y.view(*inp.shape[:-1], y.shape[-1])
         y = self.BLinear(inp)
         y = self.ALinear(y)
         return y

@@ -268,6 +268,42 @@ def truncate_split_batched(Us, Ss, Vs, ss, r, sigma_fuse, out_dtype):
     return As, Bs, flags
 
 
+LOWRANK_MAX_TOKENS = 256  # ASVD_LOWRANK_MAX_TOKENS
+
+
+def lowrank_pack(A, B):
+    """Pad ALinear.weight [N, r] / BLinear.weight [r, K] (fp16, CUDA) to the layout asvd_lowrank_forward_f16 streams:
+    (Ap [N, rp], Bp [rp, K], work) with rp = asvd_lowrank_padded_rank(r); work carries the zeroed barrier words."""
+    lib = L.load(True)
+    _dev(A, "A")
+    N, r = A.shape
+    K = B.shape[1]
+    assert A.dtype == torch.float16 and B.dtype == torch.float16 and B.shape[0] == r
+    if K % 64:
+        raise ValueError(f"fused low-rank forward needs in_features % 64 == 0 (got {K})")
+    rp = int(lib.asvd_lowrank_padded_rank(r))
+    Ap = torch.zeros((N, rp), dtype=torch.float16, device=A.device)
+    Ap[:, :r] = A
+    Bp = torch.zeros((rp, K), dtype=torch.float16, device=A.device)
+    Bp[:r] = B
+    work = torch.zeros(int(lib.asvd_lowrank_work_bytes(LOWRANK_MAX_TOKENS, rp)), dtype=torch.uint8, device=A.device)
+    return Ap, Bp, work
+
+
+def lowrank_forward(x2d, Ap, Bp, bias, work):
+    """y = fp16(fp16(x Bp^T) Ap^T + bias) in one launch (K10, svd_linear.py:105-109) for x2d [T <= 256, K] fp16"""
+    lib = L.load(True)
+    _dev(x2d, "x")
+    T, K = x2d.shape
+    N, rp = Ap.shape
+    assert x2d.dtype == torch.float16 and x2d.is_contiguous() and Bp.shape == (rp, K) and 1 <= T <= LOWRANK_MAX_TOKENS
+    y = torch.empty((T, N), dtype=torch.float16, device=x2d.device)
+    with torch.cuda.device(x2d.device):
+        L.check(lib.asvd_lowrank_forward_f16(_ptr(x2d), T, _ptr(Bp), _ptr(Ap), _ptr(bias), N, K, rp, _ptr(y), _ptr(work), work.numel(),
+                                             _stream(x2d)), "asvd_lowrank_forward_f16")
+    return y
+
+
 def fro_norm_sq(w):
     lib = L.load(True)
     _dev(w, "w")
@@ -306,11 +342,11 @@ def svd_profile(enable=None):
     if enable is not None:
         lib.asvd_svd_set_profiling(1 if enable else 0)
         return None
-    ms = (ctypes.c_float * 8)()
-    n = (ctypes.c_int * 8)()
+    names = ["pack", "sgram", "evd", "supdate", "finalize", "snapshot", "gram1", "update1", "supgram"]
+    ms = (ctypes.c_float * len(names))()
+    n = (ctypes.c_int * len(names))()
     lib.asvd_svd_get_profile(ms, n)
-    names = ["pack", "sgram", "evd", "supdate", "finalize", "snapshot", "gram1", "update1"]
-    out = {names[i]: {"ms": ms[i], "launches": n[i]} for i in range(8)}
+    out = {names[i]: {"ms": ms[i], "launches": n[i]} for i in range(len(names))}
     cnt = (ctypes.c_longlong * 3)()
     lib.asvd_svd_get_pair_counts(cnt)
     out["pairs"] = {"visited": int(cnt[0]), "rotated": int(cnt[1]), "super_updates": int(cnt[2])}

@@ -184,17 +184,18 @@ def main():
         #   sgram   (two-level Gram pass)    reads the 128 columns of every super-pair of the step:             rows * 128 * 4 B each
         #   update1 / gram1 (single-level kernels: internal step, sparse tail sweeps): 64 columns per rotated / visited 32-panel pair
         nb_ = cols_pad // 32
-        two_level = classes["supdate"]["launches"] > 0
+        two_level = classes["supdate"]["launches"] + classes["supgram"]["launches"] > 0
         alg = {}
         if two_level:
             ns_ = nb_ // 2
-            sp2 = 1
-            while sp2 < ns_: sp2 *= 2
-            dense_sweeps = classes["sgram"]["launches"] / max(1, sp2 - 1)
-            alg["supdate"] = 2.0 * rows_j * 128 * 4 * pairs_cnt["super_updates"] / classes["supdate"]["launches"]
-            alg["sgram"] = 1.0 * rows_j * 128 * 4 * (B * (ns_ // 2)) * 1.0  # every launch visits all super-pairs of all problems of the batch
-        dom = max((k for k in ("supdate", "sgram", "update1", "gram1") if classes[k]["launches"]), key=lambda k: classes[k]["ms_per_step"])
-        dom_all = max(("sgram", "evd", "supdate", "gram1", "update1", "snapshot"), key=lambda k: classes[k]["ms_per_step"])
+            upd_launches = classes["supdate"]["launches"] + classes["supgram"]["launches"]
+            wr = 1.0 * rows_j * 128 * 4 * pairs_cnt["super_updates"] / upd_launches  # bytes written per update launch (rotated super-pairs only)
+            all_x = 1.0 * rows_j * 128 * 4 * (B * (ns_ // 2))  # one read of every panel of every problem of the batch
+            alg["supdate"] = 2.0 * wr             # plain update pass: reads what it writes
+            alg["sgram"] = all_x                  # stand-alone Gram pass (first super-step of a sweep only, when the fused kernel is on)
+            alg["supgram"] = all_x + wr           # fused update + next-step Gram: ONE read of everything, writes the rotated pairs
+        dom = max((k for k in ("supgram", "supdate", "sgram", "update1", "gram1") if classes[k]["launches"]), key=lambda k: classes[k]["ms_per_step"])
+        dom_all = max(("sgram", "evd", "supdate", "supgram", "gram1", "update1", "snapshot"), key=lambda k: classes[k]["ms_per_step"])
         traffic, traffic_src = None, None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
@@ -205,7 +206,7 @@ def main():
             pass
         if dom in alg:
             ach = alg[dom] / (classes[dom]["avg_us"] * 1e-6) / 1e9
-            roofline = {"bound": "hbm", "kernel": {"supdate": "supdate_split_kernel", "sgram": "sgram6_kernel"}[dom], "achieved": ach, "peak": 8000.0,
+            roofline = {"bound": "hbm", "kernel": {"supdate": "supdate_split_kernel", "sgram": "sgram6_kernel", "supgram": "supgram_kernel"}[dom], "achieved": ach, "peak": 8000.0,
                         "unit": "GB/s", "frac": ach / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
                         "algorithmic_bytes_per_launch": alg[dom], "avg_launch_us": classes[dom]["avg_us"],
                         "note": "dominant streaming kernel by total time; bytes from the library's own counters of the profiled step, duration = HIP "
@@ -219,7 +220,8 @@ def main():
                                  "note": "fp32-MFMA peak as the yardstick (SURVEY 8d); the update pass itself runs split-bf16 on the bf16 matrix pipe"}
         if two_level:
             roofline["streaming_kernels"] = {k: {"GBps": alg[k] / (classes[k]["avg_us"] * 1e-6) / 1e9, "frac_of_8TBps": alg[k] / (classes[k]["avg_us"] * 1e-6) / 8e12,
-                                                 "avg_launch_us": classes[k]["avg_us"], "algorithmic_bytes_per_launch": alg[k]} for k in ("supdate", "sgram")}
+                                                 "avg_launch_us": classes[k]["avg_us"], "algorithmic_bytes_per_launch": alg[k]}
+                                             for k in ("supgram", "supdate", "sgram") if classes[k]["launches"]}
         roofline["dominant_by_total_time"] = dom_all
         roofline["pairs"] = pairs_cnt
         roofline["sweep_wall_ms"] = sweep_ms

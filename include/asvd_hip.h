@@ -200,6 +200,23 @@ int asvd_reconstruct_err(const void* W, int w_dtype, int64_t ldw, const void* A,
                          int64_t m, int64_t n, int64_t r, double* out, void* work, size_t work_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * K10  fused SVDLinear forward for few tokens (modules/svd_linear.py:105-109 `y = self.BLinear(inp); y = self.ALinear(y)`):
+ *        y[T, N] = fp16( fp16(x Bp^T) Ap^T + bias )
+ *   ONE persistent launch (phase 1 z = x Bp^T, in-kernel grid barrier, phase 2 y = z Ap^T + bias); the r-wide intermediate z is
+ *   rounded to fp16 exactly where BLinear's output is, lives in `work` and never leaves L2/MALL; B and A cross HBM once.
+ *   x [T, K] fp16 contiguous, 1 <= T <= ASVD_LOWRANK_MAX_TOKENS;  K % 64 == 0;
+ *   Bp [rp, K] = BLinear.weight [r, K] with zero rows appended, Ap [N, rp] = ALinear.weight [N, r] with zero columns appended,
+ *   rp = asvd_lowrank_padded_rank(r) (multiple of 64);  bias [N] fp16 or NULL;  y [T, N] fp16 contiguous.
+ *   work: asvd_lowrank_work_bytes(T, rp) bytes, 16-byte aligned, whose first 256 bytes the caller zeroes ONCE (barrier state; the
+ *   kernel leaves them reusable); one `work` must not be used by two launches in flight at the same time.  Asynchronous.
+ *   For larger T the reference's two GEMMs are the right shape (weights amortised over tokens); this entry refuses them. */
+#define ASVD_LOWRANK_MAX_TOKENS 256
+int64_t asvd_lowrank_padded_rank(int64_t r);
+size_t asvd_lowrank_work_bytes(int64_t T, int64_t rp);
+int asvd_lowrank_forward_f16(const void* x, int64_t T, const void* Bp, const void* Ap, const void* bias, int64_t N, int64_t K,
+                             int64_t rp, void* y, void* work, size_t work_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * C1  collective for the one exchange step of the multi-GPU path: all-gather of the per-layer sensitivities over
  * RCCL (xGMI).  The reference has no distributed path; a maintainer who binds only this library gets the collective here, the
  * Python host side uses torch.distributed (same RCCL) for it.  RCCL is resolved at run time from the process (torch's
@@ -218,7 +235,8 @@ int asvd_comm_destroy(void* comm);
  * Instrumentation: per-kernel-class wall time of the last asvd_svd_batched call, measured with HIP
  * events on the call's stream when enabled.  classes: 0 pack + Cholesky-QR reduction, 1 two-level Gram pass (sgram6),
  * 2 eigen-solves, 3 two-level update pass (supdate), 4 finalize, 5 snapshot (the blocked X^T X pass that opens a sparse sweep),
- * 6 single-level Gram, 7 single-level update.  ms_host: float[8] total milliseconds; launches_host: int[8].  */
+ * 6 single-level Gram, 7 single-level update, 8 fused two-level update + next-step Gram pass (supgram).
+ * ms_host: float[9] total milliseconds; launches_host: int[9].  */
 void asvd_svd_set_profiling(int enabled);
 int asvd_svd_get_profile(float* ms_host, int* launches_host);
 /* Test hook: one launch of the two-level update kernel ([X_S X_T] <- [X_S X_T] Qfin for every super-pair of XOR step D) on
@@ -226,6 +244,12 @@ int asvd_svd_get_profile(float* ms_host, int* launches_host);
  * set); done, nupd [batch] ints.  split != 0: split-bf16 arithmetic.  Used by tests/test_gpu_twolevel.py only. */
 int asvd_test_supdate(int split, float* X, int64_t panel_stride, int64_t batch_stride, int ns, int D, int R, int rows_per_wg,
                       const float* Qfin, const int* subact, const int* done, int* nupd, int nchunks, int npairs, int batch, void* stream);
+/* Test hook: one launch of the fused kernel of the two-level sweep (update of XOR super-step D + partial Gram tiles of super-step E,
+ * E != D) on caller-built panels.  Gx [batch][npairs][nchunks][6][32*32]: tiles [0,2] [0,3] [1,2] [1,3] [0,1] [2,3] of E's super-pairs
+ * over the first m_pad rows, one partial per row chunk.  Other arguments as asvd_test_supdate.  tests/test_gpu_twolevel.py only. */
+int asvd_test_supgram(float* X, int64_t panel_stride, int64_t batch_stride, int ns, int D, int E, int R, int m_pad, int rows_per_wg,
+                      const float* Qfin, const int* subact, float* Gx, const int* done, int* nupd, int nchunks, int npairs, int batch,
+                      void* stream);
 /* counts_host: long long[3] = {32-column panel-pair visits (one 64x64 eigen-solve each), pairs actually rotated, 128-column
  * super-pairs updated by the two-level sweeps (one 128-wide update pass over the rows each)} summed over the sweeps and problems of
  * the last profiled call: the algorithmic byte counts of the streaming kernels follow from these. */

@@ -1,0 +1,90 @@
+"""K10 fused SVDLinear forward (csrc/lowrank_forward.hip) against the reference's two-nn.Linear forward
+(/root/reference/modules/svd_linear.py:105-109) and against fp64."""
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+
+
+def _two_linear(x, A, B, bias):
+    """the reference forward: fp16 BLinear then fp16 ALinear (+bias)"""
+    return nn.functional.linear(nn.functional.linear(x, B), A, bias)
+
+
+def _exact(x, A, B, bias):
+    """fp64 evaluation of the SAME rounding points: z rounded to fp16 after the first product"""
+    z = (x.double() @ B.double().T).half().double()
+    y = z @ A.double().T
+    return y + bias.double() if bias is not None else y
+
+
+@pytest.mark.parametrize("T,K,r,N,with_bias", [
+    (1, 4096, 1843, 4096, False),     # decode, llama-7b attention projection at ratio 0.9 (rank not a multiple of anything)
+    (16, 4096, 1024, 4096, True),
+    (33, 4096, 2686, 11008, False),   # up_proj at 0.9: two token tiles, rank > 2048
+    (7, 11008, 1500, 4096, True),     # down_proj: K = 172 * 64
+    (256, 768, 345, 3072, True),      # opt-125m fc1, the largest token count the entry accepts
+    (5, 64, 3, 70, True),             # smallest legal K, rank < one slice, N not a multiple of the tile
+])
+def test_fused_forward_vs_two_linears_and_fp64(gpu, T, K, r, N, with_bias):
+    from asvd4llm_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(T * 7 + r)
+    x = torch.randn(T, K, device="cuda", generator=g).half()
+    B = (torch.randn(r, K, device="cuda", generator=g) / K ** 0.5).half()
+    A = (torch.randn(N, r, device="cuda", generator=g) / r ** 0.5).half()
+    bias = torch.randn(N, device="cuda", generator=g).half() if with_bias else None
+    Ap, Bp, work = ops.lowrank_pack(A, B)
+    y = ops.lowrank_forward(x, Ap, Bp, bias, work)
+    y2 = ops.lowrank_forward(x, Ap, Bp, bias, work)  # the barrier words are reusable, and the result is deterministic
+    assert torch.equal(y, y2)
+    ref = _two_linear(x, A, B, bias)
+    exact = _exact(x, A, B, bias)
+    scale = exact.abs().max().item()
+    err_fused = (y.double() - exact).abs().max().item() / scale
+    err_ref = (ref.double() - exact).abs().max().item() / scale
+    # both paths round z to fp16 and y to fp16 with fp32 accumulation: the fused kernel must be as accurate as hipBLASLt's two GEMMs
+    # (z can differ by one fp16 ulp where the fp32 sums straddle a rounding boundary, which moves y by ~2^-11 |A| — hence 2x + 1 ulp).
+    assert err_fused <= 2 * err_ref + 2 ** -10, (err_fused, err_ref)
+    assert (y.float() - ref.float()).abs().max().item() <= 4e-3 * scale
+
+
+def test_svdlinear_forward_dispatch(gpu, monkeypatch):
+    """SVDLinear.forward takes the fused launch for few fp16 tokens and the two nn.Linear GEMMs otherwise; repacks when a weight changes."""
+    from asvd4llm_amd.modules.svd_linear import SVDLinear
+    torch.manual_seed(0)
+    lin = nn.Linear(256, 192, bias=True).half().cuda()
+    m = SVDLinear.from_linear(lin, 0.6, act_aware=False)
+    x = torch.randn(2, 9, 256, device="cuda").half()
+    with torch.no_grad():
+        y = m(x)
+        assert getattr(m, "_fused", None) is not None and y.shape == (2, 9, 192)
+        monkeypatch.setenv("ASVD_FUSED_FORWARD", "0")
+        y_ref = m(x)
+        monkeypatch.delenv("ASVD_FUSED_FORWARD")
+        assert (y.float() - y_ref.float()).abs().max().item() <= 4e-3 * y_ref.float().abs().max().item()
+        m.ALinear.weight.mul_(2.0)  # in-place edit bumps _version: the padded copy must follow
+        y2 = m(x)
+        b = m.ALinear.bias.float()
+        assert torch.allclose(y2.float() - b, 2 * (y.float() - b), rtol=0, atol=8e-3 * y_ref.float().abs().max().item())
+        big = torch.randn(300, 256, device="cuda").half()  # > ASVD_LOWRANK_MAX_TOKENS: nn.Linear path
+        assert m(big).shape == (300, 192)
+    xg = x.clone().requires_grad_(True)
+    m(xg).sum().backward()  # autograd path stays on nn.Linear
+    assert xg.grad is not None
+
+
+def test_fused_forward_rejects_bad_arguments(gpu):
+    from asvd4llm_amd import ops, _lib
+    A = torch.zeros(64, 8, device="cuda").half()
+    B = torch.zeros(8, 64, device="cuda").half()
+    Ap, Bp, work = ops.lowrank_pack(A, B)
+    with pytest.raises(AssertionError):
+        ops.lowrank_forward(torch.zeros(257, 64, device="cuda").half(), Ap, Bp, None, work)
+    lib = _lib.load(True)
+    x = torch.zeros(4, 64, device="cuda").half()
+    y = torch.empty(4, 64, device="cuda").half()
+    rc = lib.asvd_lowrank_forward_f16(x.data_ptr(), 4, Bp.data_ptr(), Ap.data_ptr(), None, 64, 64, 64, y.data_ptr(), work.data_ptr(), 16, None)
+    assert rc == _lib.ASVD_E_WORKSPACE if hasattr(_lib, "ASVD_E_WORKSPACE") else rc == -2
+    with pytest.raises(ValueError):
+        ops.lowrank_pack(torch.zeros(64, 8, device="cuda").half(), torch.zeros(8, 72, device="cuda").half())

@@ -58,3 +58,84 @@ def test_supdate_vs_fp64(gpu, split, D):
 def test_supdate_graded_columns_near_identity(gpu, split):
     """late-sweep regime: column norms spanning 1e5, rotations of 1e-3 — every column keeps fp32-level relative accuracy"""
     assert _run(gpu, split, batch=2, D=3, near_identity=True) <= 2e-6
+
+
+def _pair_of_slot(k, d):
+    h = d.bit_length() - 1
+    S = ((k >> h) << (h + 1)) | (k & ((1 << h) - 1))
+    return S, S ^ d
+
+
+def _run_supgram(gpu, batch, D, E, ns, R=512, m_pad=None, rows_per_wg=128, seed=0, rest=(1,)):
+    """one launch of the fused kernel: X <- X Qfin per super-pair of step D, and the six partial Gram tiles of every super-pair of
+    step E from the UPDATED panels; both against fp64."""
+    from asvd4llm_amd import _lib as L
+    lib = L.load(True)
+    nb = 2 * ns
+    pw2 = 1 << (ns - 1).bit_length()
+    npairs = pw2 // 2
+    m_pad = R if m_pad is None else m_pad
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    X = torch.randn(batch, nb, R, 32, generator=g) * 0.05
+    Q = torch.linalg.qr(torch.randn(batch, npairs, 128, 128, generator=g))[0].contiguous()
+    X, Q = X.to(gpu), Q.to(gpu)
+    flags = torch.ones(batch, npairs, 4, dtype=torch.int32, device=gpu)
+    for k in rest:
+        flags[:, k] = 0  # super-pairs at rest: must stay untouched, and still feed the next step's tiles
+    done = torch.zeros(batch, dtype=torch.int32, device=gpu)
+    nupd = torch.zeros(batch, dtype=torch.int32, device=gpu)
+    ref = X.double().clone()
+    n_upd = 0
+    for k in range(npairs):
+        S, T = _pair_of_slot(k, D)
+        if T >= ns or k in rest:
+            continue
+        n_upd += 1
+        idx = [2 * S, 2 * S + 1, 2 * T, 2 * T + 1]
+        out = torch.cat([ref[:, i] for i in idx], dim=2) @ Q[:, k].double()
+        for j, i in enumerate(idx):
+            ref[:, i] = out[:, :, 32 * j:32 * j + 32]
+    nchunks = R // rows_per_wg
+    Gx = torch.full((batch, npairs, nchunks, 6, 1024), float("nan"), device=gpu)
+    Xw = X.clone()
+    vp = ctypes.c_void_p
+    rc = lib.asvd_test_supgram(vp(Xw.data_ptr()), R * 32, nb * R * 32, ns, D, E, R, m_pad, rows_per_wg, vp(Q.data_ptr()), vp(flags.data_ptr()),
+                               vp(Gx.data_ptr()), vp(done.data_ptr()), vp(nupd.data_ptr()), nchunks, npairs, batch,
+                               vp(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert nupd.tolist() == [n_upd] * batch
+    err_x = ((Xw.double() - ref).norm(dim=2) / ref.norm(dim=2).clamp_min(1e-300)).max().item()
+    err_g = 0.0
+    order = [(0, 2), (0, 3), (1, 2), (1, 3), (0, 1), (2, 3)]
+    for k in range(npairs):
+        S, T = _pair_of_slot(k, E)
+        if T >= ns:
+            assert torch.isnan(Gx[:, k]).all()  # padding pair of the schedule: never written
+            continue
+        pn = [ref[:, 2 * S, :m_pad], ref[:, 2 * S + 1, :m_pad], ref[:, 2 * T, :m_pad], ref[:, 2 * T + 1, :m_pad]]
+        got = Gx[:, k].double().sum(dim=1).view(batch, 6, 32, 32)
+        for t, (a, b) in enumerate(order):
+            want = pn[a].transpose(1, 2) @ pn[b]
+            scale = (pn[a].norm(dim=1).unsqueeze(2) * pn[b].norm(dim=1).unsqueeze(1)).clamp_min(1e-300)  # |x_i| |y_j|: error as a cosine
+            err_g = max(err_g, ((got[:, t] - want).abs() / scale).max().item())
+    return err_x, err_g
+
+
+@pytest.mark.parametrize("D,E", [(1, 2), (2, 3), (3, 4), (5, 6), (7, 8), (14, 15), (15, 1), (6, 3)])
+def test_supgram_update_and_next_tiles_vs_fp64(gpu, D, E):
+    err_x, err_g = _run_supgram(gpu, batch=2, D=D, E=E, ns=16)
+    assert err_x <= 2e-6 and err_g <= 2e-6, (err_x, err_g)
+
+
+@pytest.mark.parametrize("D,E", [(1, 2), (3, 4), (4, 5), (8, 9), (11, 12), (15, 1)])
+def test_supgram_padded_schedule(gpu, D, E):
+    """ns = 12 super-panels in a schedule padded to 16: quads with absent members, pairs that do not exist"""
+    err_x, err_g = _run_supgram(gpu, batch=2, D=D, E=E, ns=12, rest=(0, 3))
+    assert err_x <= 2e-6 and err_g <= 2e-6, (err_x, err_g)
+
+
+def test_supgram_gram_rows_stop_at_m_pad(gpu):
+    """rows beyond m_pad (the accumulated right factor) are rotated but do not enter the Gram tiles"""
+    err_x, err_g = _run_supgram(gpu, batch=1, D=2, E=3, ns=8, R=512, m_pad=256, rows_per_wg=128)
+    assert err_x <= 2e-6 and err_g <= 2e-6, (err_x, err_g)

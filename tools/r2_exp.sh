@@ -10,6 +10,7 @@ import json, sys
 try:
     r = json.loads([l for l in open(sys.argv[2]) if l.startswith("{")][-1])
     print(sys.argv[1], "| SVD/s", round(r["value"], 2), "sweeps", r["roofline"]["sweeps"][:3], "sweep_ms", [round(x, 1) for x in r["roofline"]["sweep_wall_ms"]])
+    print("     parity", r.get("parity"), "lat1", r.get("latency_batch1_ms"))
     print("     classes", {k: (round(v["ms_per_step"], 1), v["launches"]) for k, v in r["roofline"]["classes"].items()})
 except Exception as e:
     print(sys.argv[1], "failed", e)
