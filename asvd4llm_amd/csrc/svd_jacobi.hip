@@ -1783,9 +1783,10 @@ int make_plan(int batch, int64_t m, int64_t n, int want_u, int want_vv, Plan& p)
         p.rows_per_wg_s = (int)(ceil_div64(tiles, nc) * 32);
         p.nchunks_s = (int)ceil_div64(p.R_upd, p.rows_per_wg_s);
         // supgram (update of a step fused with the Gram tiles of the next): one 512-thread workgroup per CU and quad of four
-        // super-panels; >= 1024 workgroups per launch where the rows allow >= 8 tiles each
-        const int64_t quads = std::max<int64_t>(1, pw2 / 4) * launch_batch;
-        int64_t nq = std::max<int64_t>(1, std::min<int64_t>(ceil_div64(1024, quads), std::max<int64_t>(1, tiles / 8)));
+        // super-panels; ~512 workgroups per launch where the rows allow >= 8 tiles each
+        // measured (16 x 4096^2): 2 chunks (512 workgroups) beat 4 and 8 — longer streams per workgroup, fewer partial tiles for the solves to sum
+        const int64_t quads = std::max<int64_t>(1, pw2 / 4) * batch;
+        int64_t nq = std::max<int64_t>(1, std::min<int64_t>(ceil_div64(512, quads), std::max<int64_t>(1, tiles / 8)));
         if (getenv("ASVD_SUPGRAM_CHUNKS")) nq = std::max<int64_t>(1, std::min<int64_t>(atoi(getenv("ASVD_SUPGRAM_CHUNKS")), tiles));
         p.rows_per_wg_q = (int)(ceil_div64(tiles, nq) * 32);
         p.nchunks_q = (int)ceil_div64(p.R_upd, p.rows_per_wg_q);

@@ -368,10 +368,14 @@ __global__ __launch_bounds__(256, 2) void supdate_split_kernel(float* __restrict
 // HBM traffic of a super-step drops from read + (read + write) to one read + one write: the separate sgram6 pass (1/3 of the
 // streaming bytes, and an fp32-MFMA-bound one) disappears; MFMA work per tile: 8 x 48 (update) + 8 x 18 (Gram) bf16 instructions.
 // Super-panels beyond ns (power-of-two padding of the schedule) read as absent: no loads, no stores, their pairs are skipped.
-constexpr int QLD = 4 * SW + 4;                                    // LDS row stride of the quad tile (1040 B)
-constexpr int SUPGRAM_TILE_FLOATS = 32 * QLD;                      // one 32-row image of the eight panels
-constexpr int SUPGRAM_OPND_WORDS = 8 * 2 * 3 * 64 * 4;             // [panel][k-step][part][lane] x 16 B
-constexpr int SUPGRAM_SMEM_FLOATS = 2 * SUPGRAM_TILE_FLOATS + SUPGRAM_OPND_WORDS;  // 115,712 B
+// The incoming tile is split ONCE, by the thread that fetched it, and stored as the A operands of the update (the four waves of a pair
+// would otherwise each split the same 32x128 values): image [pair][k-step][part][lane] of 16-byte operands, double buffered.
+// A 32-lane half block is padded to 36 operands (one (k-step, part) block = 72): the stash writes of a quarter wave — four rows x
+// four (k-step, lane group) targets — then fall on distinct banks; the reads are lane-contiguous either way.
+constexpr int SG_HB = 36, SG_BLK = 2 * SG_HB;
+constexpr int SUPGRAM_AIMG_WORDS = 2 * 8 * 3 * SG_BLK * 4;         // one 32-row image of the eight panels, as bf16x3 A operands (54 KiB)
+constexpr int SUPGRAM_OPND_WORDS = 8 * 2 * 3 * 64 * 4;             // updated panels as Gram operands [panel][k-step][part][lane] x 16 B
+constexpr int SUPGRAM_SMEM_FLOATS = 2 * SUPGRAM_AIMG_WORDS + SUPGRAM_OPND_WORDS;  // 159,744 B of the CU's 160 KiB
 static_assert(SUPGRAM_SMEM_FLOATS >= 24 * 1024, "the final reduction reuses the whole buffer");
 
 __global__ __launch_bounds__(512, 1) void supgram_kernel(float* __restrict__ X, int64_t panel_stride, int64_t batch_stride, int ns, int D,
@@ -415,14 +419,16 @@ __global__ __launch_bounds__(512, 1) void supgram_kernel(float* __restrict__ X, 
     const bool mine = mypr ? act1 : act0;
     float* __restrict__ Pw = Xb + (int64_t)(2 * min(Pof(oslot), ns - 1) + (ob & 1)) * panel_stride;
     // B operand of k-step s: lane (j = c, group h) holds Q[16 s + 8 h + e][32 ob + c], e = 0..7, in three bf16 parts
+    // A pair at rest (or one with an absent member) goes through the same arithmetic with Q = I — exact in split-bf16 — and is not
+    // written back: its panels still feed the tiles of the next step.
     u32x4 q1[8], q2[8], q3[8];
-    if (mine) {
+    {
         const float* __restrict__ Qp = Qfin + ((int64_t)b * npairs + (mypr ? kcur1 : kcur0)) * (SP * SP);
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             float v[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = Qp[(16 * s + 8 * h + e) * SP + 32 * ob + c];
+            for (int e = 0; e < 8; ++e) v[e] = mine ? Qp[(16 * s + 8 * h + e) * SP + 32 * ob + c] : ((16 * s + 8 * h + e == 32 * ob + c) ? 1.0f : 0.0f);
 #pragma unroll
             for (int e2 = 0; e2 < 4; ++e2) {
                 unsigned x, y, z;
@@ -431,12 +437,10 @@ __global__ __launch_bounds__(512, 1) void supgram_kernel(float* __restrict__ X, 
             }
         }
     }
-    // A operand of k-step s comes from tile columns of slot (s < 4 ? S : T) of this wave's pair
-    const int colS = 64 * mS, colT = 64 * mT;
 
-    float* tile0 = sg_smem;
-    float* tile1 = sg_smem + SUPGRAM_TILE_FLOATS;
-    u32x4* opnd = (u32x4*)(sg_smem + 2 * SUPGRAM_TILE_FLOATS);
+    u32x4* aimg0 = (u32x4*)sg_smem;
+    u32x4* aimg1 = (u32x4*)(sg_smem + SUPGRAM_AIMG_WORDS);
+    u32x4* opnd = (u32x4*)(sg_smem + 2 * SUPGRAM_AIMG_WORDS);
 
     // ---- this wave's three Gram half-tiles: unit u = w + 8 j -> tile u >> 1 (0..5 pair C, 6..11 pair D'), k-step u & 1 ----
     // sgram6 tile order [0,2] [0,3] [1,2] [1,3] [0,1] [2,3] over the pair's panels (0,1 = lower super-panel, 2,3 = upper)
@@ -460,23 +464,44 @@ __global__ __launch_bounds__(512, 1) void supgram_kernel(float* __restrict__ X, 
     const int r_begin = chunk * rows_per_wg;
     const int r_end = min(r_begin + rows_per_wg, R);
     if (r_begin < r_end) {
-        f32x4 pre[4];
+        // a thread fetches two 8-column pieces (32 B) of the tile: piece q = tid + 512 jj -> panel q >> 7, row (q & 127) >> 2, columns
+        // 8 (q & 3) .. +7; as an A operand that is k-step / lane group (k >> 4, (k >> 3) & 1) of its pair, k = its column in Q order
+        f32x4 pre[2][2];
+        int dst[2];
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int q = tid + 512 * jj, tp = q >> 7, row = (q & 127) >> 2, slot = tp >> 1;
+            const int pr = (slot >= 2) ? 1 : 0;
+            const bool isT = pr ? (slot == curT1) : (slot == 1);
+            const int k = (isT ? 64 : 0) + (tp & 1) * 32 + 8 * (q & 3);
+            dst[jj] = ((pr * 8 + (k >> 4)) * 3) * SG_BLK + ((k >> 3) & 1) * SG_HB + row;
+        }
         auto fetch = [&](int r0) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int q = tid + 512 * j, tp = q >> 8, idx = q & 255;
+            for (int jj = 0; jj < 2; ++jj) {
+                const int q = tid + 512 * jj, tp = q >> 7, idx = q & 127;
                 const int sp = Pof(tp >> 1);
-                if (sp < ns)
-                    pre[j] = *(const f32x4*)(Xb + (int64_t)(2 * sp + (tp & 1)) * panel_stride + (int64_t)r0 * PB + idx * 4);
-                else
-                    pre[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (sp < ns) {
+                    const float* src = Xb + (int64_t)(2 * sp + (tp & 1)) * panel_stride + (int64_t)r0 * PB + idx * 8;
+                    pre[jj][0] = *(const f32x4*)(src);
+                    pre[jj][1] = *(const f32x4*)(src + 4);
+                } else {
+                    pre[jj][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    pre[jj][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
             }
         };
-        auto stash = [&](float* t) {
+        auto stash = [&](u32x4* img) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int q = tid + 512 * j, tp = q >> 8, idx = q & 255;
-                *(f32x4*)(t + (idx >> 3) * QLD + tp * 32 + (idx & 7) * 4) = pre[j];
+            for (int jj = 0; jj < 2; ++jj) {
+                u32x4 p1, p2, p3;
+                unsigned x, y, z;
+                split3(pre[jj][0][0], pre[jj][0][1], x, y, z); p1[0] = x; p2[0] = y; p3[0] = z;
+                split3(pre[jj][0][2], pre[jj][0][3], x, y, z); p1[1] = x; p2[1] = y; p3[1] = z;
+                split3(pre[jj][1][0], pre[jj][1][1], x, y, z); p1[2] = x; p2[2] = y; p3[2] = z;
+                split3(pre[jj][1][2], pre[jj][1][3], x, y, z); p1[3] = x; p2[3] = y; p3[3] = z;
+                u32x4* o = img + dst[jj];
+                o[0] = p1; o[SG_BLK] = p2; o[2 * SG_BLK] = p3;
             }
         };
         auto gram = [&]() {
@@ -499,50 +524,34 @@ __global__ __launch_bounds__(512, 1) void supgram_kernel(float* __restrict__ X, 
         };
         int cur = 0;
         fetch(r_begin);
-        stash(tile0);
+        stash(aimg0);
         __syncthreads();
         bool pending = false;  // Gram of the previous tile not yet accumulated (its operands are in opnd)
         for (int r0 = r_begin; r0 < r_end; r0 += 32) {
             const bool more = r0 + 32 < r_end;
             if (more) fetch(r0 + 32);
-            const float* tl = cur ? tile1 : tile0;
+            const u32x4* img = (cur ? aimg1 : aimg0) + (mypr * 8 * 3) * SG_BLK + h * SG_HB + c;
             if (pending) gram();  // reads opnd of the previous tile
             f32x16 acc;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const bf16x8 A1 = __builtin_bit_cast(bf16x8, img[(3 * s + 0) * SG_BLK]), A2 = __builtin_bit_cast(bf16x8, img[(3 * s + 1) * SG_BLK]),
+                             A3 = __builtin_bit_cast(bf16x8, img[(3 * s + 2) * SG_BLK]);
+                const bf16x8 B1 = __builtin_bit_cast(bf16x8, q1[s]), B2 = __builtin_bit_cast(bf16x8, q2[s]), B3 = __builtin_bit_cast(bf16x8, q3[s]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A3, B1, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B3, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, B2, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, B1, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B2, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B1, acc, 0, 0, 0);
+            }
             if (mine) {
-#pragma unroll
-                for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-#pragma unroll
-                for (int s = 0; s < 8; ++s) {
-                    const float* my = tl + c * QLD + (s < 4 ? colS : colT) + 16 * (s & 3) + 8 * h;
-                    const f32x4 v0 = *(const f32x4*)(my);
-                    const f32x4 v1 = *(const f32x4*)(my + 4);
-                    u32x4 a1, a2, a3;
-                    {
-                        unsigned x, y, z;
-                        split3(v0[0], v0[1], x, y, z); a1[0] = x; a2[0] = y; a3[0] = z;
-                        split3(v0[2], v0[3], x, y, z); a1[1] = x; a2[1] = y; a3[1] = z;
-                        split3(v1[0], v1[1], x, y, z); a1[2] = x; a2[2] = y; a3[2] = z;
-                        split3(v1[2], v1[3], x, y, z); a1[3] = x; a2[3] = y; a3[3] = z;
-                    }
-                    const bf16x8 A1 = __builtin_bit_cast(bf16x8, a1), A2 = __builtin_bit_cast(bf16x8, a2), A3 = __builtin_bit_cast(bf16x8, a3);
-                    const bf16x8 B1 = __builtin_bit_cast(bf16x8, q1[s]), B2 = __builtin_bit_cast(bf16x8, q2[s]), B3 = __builtin_bit_cast(bf16x8, q3[s]);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A3, B1, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B3, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, B2, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, B1, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B2, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B1, acc, 0, 0, 0);
-                }
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
                     const int i = (reg & 3) + 8 * (reg >> 2) + 4 * h;
                     Pw[(int64_t)(r0 + i) * PB + c] = acc[reg];
-                }
-            } else {  // pair at rest (or absent: zeros): the panel as it is, in the C layout
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int i = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                    acc[reg] = tl[i * QLD + otp * 32 + c];
                 }
             }
             __syncthreads();  // every wave is done with the previous tile's operands (and with tile[cur] as far as the stash below matters)
@@ -561,7 +570,7 @@ __global__ __launch_bounds__(512, 1) void supgram_kernel(float* __restrict__ X, 
                     o[0] = p1; o[64] = p2; o[128] = p3;
                 }
             }
-            if (more) stash(cur ? tile0 : tile1);
+            if (more) stash(cur ? aimg0 : aimg1);
             __syncthreads();
             pending = gram_rows;
             cur ^= 1;

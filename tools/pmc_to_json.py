@@ -13,7 +13,7 @@ def table(path):
             out[(p[0], p[1])] = {"calls": int(p[-3]), "avg": float(p[-2]), "avg_dur_us": float(p[-1])}
     return out
 fetch, write = table(os.path.join(d, "pmc_FETCH_SIZE.txt")), table(os.path.join(d, "pmc_WRITE_SIZE.txt"))
-names = {"supdate": "supdate_split_kernel", "sgram": "sgram6_kernel", "evd": "evd_kernel", "snapshot": "fullcheck_kernel"}
+names = {"supgram": "supgram_kernel", "supdate": "supdate_split_kernel", "sgram": "sgram6_kernel", "evd": "evd_kernel", "snapshot": "fullcheck_kernel"}
 res = {"batch": 16, "source": "profiles/" + os.path.basename(d).replace("prof_", "") + "_pmc_*.txt",
        "note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes of `python bench.py --no_cpu_baseline --no_latency --steps 1 --warmup 0 --prewarm_s 0` "
                "(16 x 4096x4096 fp32, one stream); mean per dispatch over all launches of the run; FETCH doubled (gfx950 half-count), WRITE as reported",
