@@ -1610,6 +1610,106 @@ __global__ __launch_bounds__(256) void nn_gemm_kernel(const float* __restrict__ 
     }
 }
 
+// Split-bf16 form of nn_gemm_kernel (twolevel.h arithmetic: every fp32 operand = three bf16 exactly, six products per fp32 product on
+// the bf16 matrix pipe, fp32 accumulation): the long-side GEMM was 62 % of the fp32-MFMA peak and 22 ms per 16 problems.  The
+// fetching thread splits its 8 consecutive k-values once and stores them as ready MFMA operands ([block][k-step][part][lane] images,
+// 36-operand half blocks so the scattered A writes fall on distinct banks); a wave then issues 48 bf16 MFMAs per 32-column panel
+// against 30 ds_read_b128, no VALU in the inner loop.  Same tiling (128 x 128 per workgroup, wave w = rows 32 w ..), same epilogue.
+constexpr int NG_HB = 36, NG_BLK = 2 * NG_HB;
+__global__ __launch_bounds__(256, 2) void nn_gemm_split_kernel(const float* __restrict__ X, int64_t panel_stride, int nb, int rows, int cols,
+                                                               const float* __restrict__ Vr, int64_t ldv, const float* __restrict__ S, int k,
+                                                               float* __restrict__ out, int64_t ldo) {
+    __shared__ u32x4 Aimg[4 * 2 * 3 * NG_BLK];
+    __shared__ u32x4 Bimg[4 * 2 * 3 * NG_BLK];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, tid = threadIdx.x;
+    const int h = lane >> 5, c = lane & 31;
+    const int r0 = blockIdx.y * 128;
+    const int c0 = blockIdx.x * 128;
+    f32x16 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = (f32x16){0};
+    // A pieces: q = tid + 256 j -> row q >> 2 of the 128, k-chunk q & 3 (8 values = 32 B); B pieces: column tid & 127, k-chunk (tid >> 7) + 2 j
+    f32x4 pa[2][2];
+    float pb[2][8];
+    int adst[2], bdst[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int q = tid + 256 * j, row = q >> 2, kc = q & 3;
+        adst[j] = (((row >> 5) * 2 + (kc >> 1)) * 3) * NG_BLK + (kc & 1) * NG_HB + (row & 31);
+        const int cc = tid & 127, kb = (tid >> 7) + 2 * j;
+        bdst[j] = (((cc >> 5) * 2 + (kb >> 1)) * 3) * NG_BLK + (kb & 1) * NG_HB + (cc & 31);
+    }
+    auto fetch = [&](int p) {
+        const float* P = X + (int64_t)p * panel_stride;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int q = tid + 256 * j, row = q >> 2, kc = q & 3;
+            if (r0 + row < rows) {
+                const float* src = P + (int64_t)(r0 + row) * PB + 8 * kc;
+                pa[j][0] = *(const f32x4*)src;
+                pa[j][1] = *(const f32x4*)(src + 4);
+            } else {
+                pa[j][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+                pa[j][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            const int cc = tid & 127, kb = (tid >> 7) + 2 * j, vc = c0 + cc;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int vr = p * PB + 8 * kb + e;
+                pb[j][e] = (vr < cols && vc < k) ? Vr[(int64_t)vr * ldv + vc] : 0.0f;
+            }
+        }
+    };
+    auto put = [&](u32x4* dst, float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7) {
+        u32x4 p1, p2, p3;
+        unsigned x, y, z;
+        split3(v0, v1, x, y, z); p1[0] = x; p2[0] = y; p3[0] = z;
+        split3(v2, v3, x, y, z); p1[1] = x; p2[1] = y; p3[1] = z;
+        split3(v4, v5, x, y, z); p1[2] = x; p2[2] = y; p3[2] = z;
+        split3(v6, v7, x, y, z); p1[3] = x; p2[3] = y; p3[3] = z;
+        dst[0] = p1; dst[NG_BLK] = p2; dst[2 * NG_BLK] = p3;
+    };
+    fetch(0);
+    for (int p = 0; p < nb; ++p) {
+        __syncthreads();  // previous panel's images fully consumed
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            put(Aimg + adst[j], pa[j][0][0], pa[j][0][1], pa[j][0][2], pa[j][0][3], pa[j][1][0], pa[j][1][1], pa[j][1][2], pa[j][1][3]);
+            put(Bimg + bdst[j], pb[j][0], pb[j][1], pb[j][2], pb[j][3], pb[j][4], pb[j][5], pb[j][6], pb[j][7]);
+        }
+        __syncthreads();
+        if (p + 1 < nb) fetch(p + 1);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const u32x4* ap = Aimg + ((w * 2 + s2) * 3) * NG_BLK + h * NG_HB + c;
+            const bf16x8 A1 = __builtin_bit_cast(bf16x8, ap[0]), A2 = __builtin_bit_cast(bf16x8, ap[NG_BLK]), A3 = __builtin_bit_cast(bf16x8, ap[2 * NG_BLK]);
+#pragma unroll
+            for (int tl = 0; tl < 4; ++tl) {
+                const u32x4* bp = Bimg + ((tl * 2 + s2) * 3) * NG_BLK + h * NG_HB + c;
+                const bf16x8 B1 = __builtin_bit_cast(bf16x8, bp[0]), B2 = __builtin_bit_cast(bf16x8, bp[NG_BLK]), B3 = __builtin_bit_cast(bf16x8, bp[2 * NG_BLK]);
+                acc[tl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A3, B1, acc[tl], 0, 0, 0);
+                acc[tl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B3, acc[tl], 0, 0, 0);
+                acc[tl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, B2, acc[tl], 0, 0, 0);
+                acc[tl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, B1, acc[tl], 0, 0, 0);
+                acc[tl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B2, acc[tl], 0, 0, 0);
+                acc[tl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B1, acc[tl], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int tl = 0; tl < 4; ++tl) {
+        const int col = c0 + tl * 32 + c;
+        if (col >= k) continue;
+        const float sv = S ? S[col] : 1.0f;
+        const float inv = sv > 0.0f ? 1.0f / sv : 0.0f;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int row = r0 + 32 * w + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            if (row < rows) out[(int64_t)row * ldo + col] = acc[tl][reg] * inv;
+        }
+    }
+}
+
 // sigma refinement of the tall path: Y = X Vr (unscaled) -> sigma_j = |y_j| (fp64, fixed order), u_j = y_j / sigma_j.
 // |X v_j| is second-order accurate in the error of v_j and does not see the fp32 rounding of R.
 __global__ __launch_bounds__(256) void colsumsq_kernel(const float* __restrict__ Y, int64_t ldy, int rows, int k, int rows_per_split,
@@ -1786,7 +1886,8 @@ int make_plan(int batch, int64_t m, int64_t n, int want_u, int want_vv, Plan& p)
         // super-panels; ~512 workgroups per launch where the rows allow >= 8 tiles each
         // measured (16 x 4096^2): 2 chunks (512 workgroups) beat 4 and 8 — longer streams per workgroup, fewer partial tiles for the solves to sum
         const int64_t quads = std::max<int64_t>(1, pw2 / 4) * batch;
-        int64_t nq = std::max<int64_t>(1, std::min<int64_t>(ceil_div64(512, quads), std::max<int64_t>(1, tiles / 8)));
+        // (and 1 chunk = exactly one workgroup per CU beats 2 once the quads alone fill the chip: 170.7 vs 174.0 ms per step, solves 97 vs 100)
+        int64_t nq = std::max<int64_t>(1, std::min<int64_t>(quads >= 256 ? 1 : ceil_div64(512, quads), std::max<int64_t>(1, tiles / 8)));
         if (getenv("ASVD_SUPGRAM_CHUNKS")) nq = std::max<int64_t>(1, std::min<int64_t>(atoi(getenv("ASVD_SUPGRAM_CHUNKS")), tiles));
         p.rows_per_wg_q = (int)(ceil_div64(tiles, nq) * 32);
         p.nchunks_q = (int)ceil_div64(p.R_upd, p.rows_per_wg_q);
@@ -2658,13 +2759,18 @@ static int svd_tall(int batch, const void* const* a_host, int a_dtype, int64_t m
                 ASVD_HIP_CHECK(hipEventCreateWithFlags(&e_join[i], hipEventDisableTiming));
             }
         }
+        const bool gemm_split = !(getenv("ASVD_SPLIT") && atoi(getenv("ASVD_SPLIT")) == 0);  // split-bf16 arithmetic, as in the sweeps
         for (int b = 0; b < batch; ++b) {
             hipStream_t se = nes > 1 ? s_epi[b % nes] : st;
             row_unpermute_kernel<<<dim3((unsigned)ceil_div64(k, 256), p.cols), 256, 0, se>>>(vperm[b], cperm + (int64_t)b * p.n_pad, p.cols, (int)k, vr[b]);
             float* long_out = p.transposed ? (V_host ? V_host[b] : nullptr) : (U_host ? U_host[b] : nullptr);
             if (!long_out) continue;
-            nn_gemm_kernel<<<dim3((unsigned)ceil_div64(k, 128), (unsigned)ceil_div64(p.rows, 128)), 256, 0, se>>>(
-                Xp + (int64_t)b * p.batch_stride, p.panel_stride, p.nb, p.rows, p.cols, vr[b], k, nullptr, (int)k, long_out, k);
+            if (gemm_split)
+                nn_gemm_split_kernel<<<dim3((unsigned)ceil_div64(k, 128), (unsigned)ceil_div64(p.rows, 128)), 256, 0, se>>>(
+                    Xp + (int64_t)b * p.batch_stride, p.panel_stride, p.nb, p.rows, p.cols, vr[b], k, nullptr, (int)k, long_out, k);
+            else
+                nn_gemm_kernel<<<dim3((unsigned)ceil_div64(k, 128), (unsigned)ceil_div64(p.rows, 128)), 256, 0, se>>>(
+                    Xp + (int64_t)b * p.batch_stride, p.panel_stride, p.nb, p.rows, p.cols, vr[b], k, nullptr, (int)k, long_out, k);
             // sigma_j = |X v_j| and unit left vectors
             const int nsp = (int)std::min<int64_t>(64, ceil_div64(p.rows, 256));
             const int rps = (int)ceil_div64(p.rows, nsp);
