@@ -30,26 +30,7 @@ __global__ __launch_bounds__(256) void absstat_partial_kernel(const void* __rest
 #pragma unroll
     for (int v = 0; v < VEC; ++v) acc[v] = 0.0f;
     const bool full = (c0 + VEC <= cols) && ((ld % VEC) == 0) && ((((uintptr_t)x) & 15) == 0);
-    for (int64_t r = rb + w; r < re; r += 4) {
-        float vals[VEC];
-        if (full) {
-            if (DT == ASVD_F32) {
-                const f32x4 t = *(const f32x4*)((const float*)x + r * ld + c0);
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) vals[v] = t[v % 4];
-            } else {
-                const uint4 t = *(const uint4*)((const uint16_t*)x + r * ld + c0);
-                const uint32_t wds[4] = {t.x, t.y, t.z, t.w};
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) {
-                    const uint16_t bits = (uint16_t)(wds[(v >> 1) & 3] >> (16 * (v & 1)));
-                    vals[v] = (DT == ASVD_F16) ? f16_bits_to_f32(bits) : bf16_bits_to_f32(bits);
-                }
-            }
-        } else {
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) vals[v] = (c0 + v < cols) ? elem<DT>::ld(x, r * ld + c0 + v) : 0.0f;
-        }
+    auto consume = [&](const float* vals) {
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
             const float a = (MODE == ASVD_STAT_SQ_MEAN) ? elem<DT>::rnd(vals[v] * vals[v]) : fabsf(vals[v]);
@@ -59,6 +40,59 @@ __global__ __launch_bounds__(256) void absstat_partial_kernel(const void* __rest
                 else acc[v] = fmaxf(acc[v], a);
             }
         }
+    };
+    auto unpack16 = [&](const uint4& t, float* vals) {
+        const uint32_t wds[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            const uint16_t bits = (uint16_t)(wds[(v >> 1) & 3] >> (16 * (v & 1)));
+            vals[v] = (DT == ASVD_F16) ? f16_bits_to_f32(bits) : bf16_bits_to_f32(bits);
+        }
+    };
+    int64_t r = rb + w;
+    if (full) {
+        // four rows of this wave per iteration, all four 16-byte loads issued before the first use: a wave only has rows/(4 splits) rows
+        // to read, so the kernel's length is the number of DEPENDENT load latencies, not the bytes (rows are summed in the same order)
+        for (; r + 12 < re; r += 16) {
+            float vals[VEC];
+            if (DT == ASVD_F32) {
+                f32x4 t[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) t[u] = *(const f32x4*)((const float*)x + (r + 4 * u) * ld + c0);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) vals[v] = t[u][v % 4];
+                    consume(vals);
+                }
+            } else {
+                uint4 t[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) t[u] = *(const uint4*)((const uint16_t*)x + (r + 4 * u) * ld + c0);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    unpack16(t[u], vals);
+                    consume(vals);
+                }
+            }
+        }
+    }
+    for (; r < re; r += 4) {
+        float vals[VEC];
+        if (full) {
+            if (DT == ASVD_F32) {
+                const f32x4 t = *(const f32x4*)((const float*)x + r * ld + c0);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) vals[v] = t[v % 4];
+            } else {
+                const uint4 t = *(const uint4*)((const uint16_t*)x + r * ld + c0);
+                unpack16(t, vals);
+            }
+        } else {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) vals[v] = (c0 + v < cols) ? elem<DT>::ld(x, r * ld + c0 + v) : 0.0f;
+        }
+        consume(vals);
     }
     __shared__ float red[4][64 * VEC];
     __shared__ int rnan[4][64];

@@ -35,6 +35,8 @@ constexpr int PW = 2 * PB;   // pair width
 //    and 14 -> 9 on the row-scaled wide layers against the round-robin tournament (CPU prototype at n = 1024: 8 -> 6).
 //  * c_pair_order = 0 (ASVD_ORDER=rr, for A/B measurements): round-robin tournament (circle method), nb-1 steps of nb/2 pairs.
 __constant__ int c_pair_order = 1;
+// phase pairs per inner sweep of the 64x64 eigen-solve: 32 = one full odd-even cycle (every column pair meets once).  ASVD_EVD_PAIRS (experiments).
+__constant__ int c_evd_pairs = 32;
 
 __device__ __forceinline__ void rr_pair(int nb, int step, int k, int& I, int& J) {
     if (c_pair_order) {  // pair space padded to the next power of two: callers skip pairs with J >= nb
@@ -648,7 +650,7 @@ __device__ __forceinline__ void evd_body(const BlockCtx& ctx, float* __restrict_
         __syncthreads();
         cur = nxt;
     };
-    for (int ph2 = 0; ph2 < (rotate ? nsw * (PW / 2) : 0); ++ph2) {
+    for (int ph2 = 0; ph2 < (rotate ? nsw * c_evd_pairs : 0); ++ph2) {
         phase(std::integral_constant<int, 0>{});
         phase(std::integral_constant<int, 1>{});
     }
@@ -2095,6 +2097,8 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
         ASVD_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_pair_order), &order, sizeof(int), 0, hipMemcpyHostToDevice));
         const int fence = stream_groups_for(batch) > 1 ? 1 : 0;
         ASVD_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_fence), &fence, sizeof(int), 0, hipMemcpyHostToDevice));
+        const int evp = getenv("ASVD_EVD_PAIRS") ? std::max(1, std::min(64, atoi(getenv("ASVD_EVD_PAIRS")))) : PW / 2;
+        ASVD_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_evd_pairs), &evp, sizeof(int), 0, hipMemcpyHostToDevice));
     }
     const int nsteps = pair_order_xor() ? 2 * p.npairs - 1 : p.nb - 1;
     // panels whose convergence is enforced: those holding the k leading columns, plus one panel of margin

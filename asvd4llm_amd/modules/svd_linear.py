@@ -87,22 +87,33 @@ class SVDLinear(nn.Module):
 
     @staticmethod
     def _cache_key(linear, act_aware, alpha):
-        """(key, contiguous weight).  Content signature: `.data` edits do not bump Parameter._version, so the values are hashed
-        (sum of squares by the K8 kernel) - one tiny launch + one host sync per call."""
+        """(key, contiguous weight).  Content signature: `.data` edits do not bump Parameter._version, so the values are hashed:
+        sum of squares of every element (K8 kernel) AND a position-weighted fp64 checksum over a strided sample of <= 8192 elements
+        (sign flips and permutations keep the first and change the second), plus Parameter._version — all read back in ONE host sync."""
         w = linear.weight.data
         if not w.is_cuda:
             raise AsvdHipError(f"weight of {linear} is on {w.device}; the ASVD hot path runs on gfx950 only (no CPU fallback)")
         stat = getattr(linear, "scaling_diag_matrix", None) if act_aware else None
         fis = getattr(linear, "fisher_info", None) if act_aware else None
         wc = w if w.stride(1) == 1 else w.contiguous()
+        pend = []  # device scalars (fp64) to read back together
 
         def _sig(t):
             if t is None:
                 return None
             t2 = t.to(w.device).reshape(1, -1) if t.dim() != 2 else t
-            return (tuple(t.shape), t.dtype, float(ops.fro_norm_sq(t2 if t2.stride(-1) == 1 else t2.contiguous()).item()))
+            t2 = t2 if t2.stride(-1) == 1 else t2.contiguous()
+            flat = t2.reshape(-1) if t2.is_contiguous() else t2.contiguous().reshape(-1)
+            step = max(1, flat.numel() // 8192)
+            samp = flat[::step].double()
+            pend.append(ops.fro_norm_sq(t2).double().reshape(()))
+            pend.append((samp * torch.arange(1, samp.numel() + 1, dtype=torch.float64, device=samp.device)).sum())
+            return (tuple(t.shape), t.dtype, len(pend) - 2)
 
-        key = (w.data_ptr(), _sig(wc), bool(act_aware), float(alpha) if act_aware else None, _sig(stat), _sig(fis))
+        sigs = [_sig(wc), _sig(stat), _sig(fis)]
+        vals = torch.stack(pend).tolist()  # the one host sync
+        sigs = [None if sg is None else (sg[0], sg[1], vals[sg[2]], vals[sg[2] + 1]) for sg in sigs]
+        key = (w.data_ptr(), int(linear.weight._version), sigs[0], bool(act_aware), float(alpha) if act_aware else None, sigs[1], sigs[2])
         return key, wc
 
     @staticmethod

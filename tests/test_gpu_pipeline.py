@@ -77,6 +77,18 @@ def test_svd_is_cached_once_per_layer(gpu):
         lin.weight.data.add_(1.0)  # in-place change bumps the version -> re-factorised
         SVDLinear.from_linear(lin, 0.5, act_aware=True, alpha=0.5)
         assert calls["n"] == 2
+        # edits that KEEP the sum of squares: a sign flip of one row, a permutation of two rows, a changed statistic
+        lin.weight.data[3].neg_()
+        SVDLinear.from_linear(lin, 0.5, act_aware=True, alpha=0.5)
+        assert calls["n"] == 3
+        lin.weight.data[[0, 1]] = lin.weight.data[[1, 0]]
+        SVDLinear.from_linear(lin, 0.5, act_aware=True, alpha=0.5)
+        assert calls["n"] == 4
+        lin.scaling_diag_matrix[[0, 1]] = lin.scaling_diag_matrix[[1, 0]]
+        SVDLinear.from_linear(lin, 0.5, act_aware=True, alpha=0.5)
+        assert calls["n"] == 5
+        SVDLinear.from_linear(lin, 0.6, act_aware=True, alpha=0.5)  # untouched: cached
+        assert calls["n"] == 5
     finally:
         ops.svd = real
 

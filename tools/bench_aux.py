@@ -48,6 +48,20 @@ for (m, n, r) in ((4096, 4096, 512), (4096, 4096, 1843), (11008, 4096, 2686)):
     out.append({"kernel": "scale_cols", "shape": [m, n], "us": t * 1e6, "alg_bytes": b, "GBps": b / t / 1e9})
     t = timeit(lambda: ops.fro_norm_sq(W))
     out.append({"kernel": "fro_norm_sq", "shape": [m, n], "us": t * 1e6, "alg_bytes": m * n * 2, "GBps": m * n * 2 / t / 1e9})
+# K10 one-launch SVDLinear forward against the reference's two nn.Linear launches (hipBLASLt), Llama-2-7B projection at ratio 0.9.
+# Wall time per call on the stream (back-to-back calls, so launch cost is included for both); kernel-only times: rocprofv3 of this script.
+import torch.nn as nn
+for (K, r, N) in ((4096, 1843, 4096), (4096, 2686, 11008)):
+    Bw = (torch.randn(r, K, device=dev) / K ** 0.5).half()
+    Aw = (torch.randn(N, r, device=dev) / r ** 0.5).half()
+    Ap, Bp, work = ops.lowrank_pack(Aw, Bw)
+    for T in (1, 16, 64, 256):
+        x = torch.randn(T, K, device=dev).half()
+        t_f = timeit(lambda: ops.lowrank_forward(x, Ap, Bp, None, work), reps=50)
+        t_2 = timeit(lambda: nn.functional.linear(nn.functional.linear(x, Bw), Aw), reps=50)
+        b = 2 * r * (K + N) + 2 * T * (K + N)
+        out.append({"kernel": "lowrank_forward (K10)", "shape": [T, K, r, N], "us": t_f * 1e6, "us_two_nn_linear": t_2 * 1e6, "alg_bytes": b,
+                    "GBps": b / t_f / 1e9, "GBps_two_nn_linear": b / t_2 / 1e9})
 # K4s sigma_max (Lanczos): algorithmic bytes = 2 passes over W per step (the second pass re-reads the 64-row chunk from L2)
 import time
 for (m, n, B) in ((4096, 4096, 16), (11008, 4096, 16), (4096, 11008, 16), (4096, 4096, 1)):
