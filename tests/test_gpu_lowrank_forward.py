@@ -50,25 +50,29 @@ def test_fused_forward_vs_two_linears_and_fp64(gpu, T, K, r, N, with_bias):
 
 
 def test_svdlinear_forward_dispatch(gpu, monkeypatch):
-    """SVDLinear.forward takes the fused launch for few fp16 tokens and the two nn.Linear GEMMs otherwise; repacks when a weight changes."""
+    """With ASVD_FUSED_FORWARD=1 SVDLinear.forward takes the fused launch for decode-sized fp16 inputs and the two nn.Linear GEMMs otherwise; repacks
+    when a weight changes."""
     from asvd4llm_amd.modules.svd_linear import SVDLinear
     torch.manual_seed(0)
     lin = nn.Linear(256, 192, bias=True).half().cuda()
     m = SVDLinear.from_linear(lin, 0.6, act_aware=False)
-    x = torch.randn(2, 9, 256, device="cuda").half()
+    x = torch.randn(2, 7, 256, device="cuda").half()
     with torch.no_grad():
+        y_ref = m(x)  # default: the reference's two GEMMs
+        assert getattr(m, "_fused", None) is None
+        monkeypatch.setenv("ASVD_FUSED_FORWARD", "1")
         y = m(x)
-        assert getattr(m, "_fused", None) is not None and y.shape == (2, 9, 192)
-        monkeypatch.setenv("ASVD_FUSED_FORWARD", "0")
-        y_ref = m(x)
-        monkeypatch.delenv("ASVD_FUSED_FORWARD")
+        assert getattr(m, "_fused", None) is not None and y.shape == (2, 7, 192)
         assert (y.float() - y_ref.float()).abs().max().item() <= 4e-3 * y_ref.float().abs().max().item()
         m.ALinear.weight.mul_(2.0)  # in-place edit bumps _version: the padded copy must follow
         y2 = m(x)
         b = m.ALinear.bias.float()
         assert torch.allclose(y2.float() - b, 2 * (y.float() - b), rtol=0, atol=8e-3 * y_ref.float().abs().max().item())
-        big = torch.randn(300, 256, device="cuda").half()  # > ASVD_LOWRANK_MAX_TOKENS: nn.Linear path
+        big = torch.randn(300, 256, device="cuda").half()  # more tokens than the dispatch takes: nn.Linear path
         assert m(big).shape == (300, 192)
+        m._fused = None
+        m(torch.randn(17, 256, device="cuda").half())
+        assert m._fused is None  # 17 tokens: two GEMMs, nothing packed
     xg = x.clone().requires_grad_(True)
     m(xg).sum().backward()  # autograd path stays on nn.Linear
     assert xg.grad is not None
