@@ -117,26 +117,50 @@ __global__ __launch_bounds__(256) void absstat_partial_kernel(const void* __rest
     }
 }
 
+// 64 columns per workgroup; the four waves each fold every fourth partial (four independent loads in flight), then wave 0 combines
+// the four in a fixed order: a dependent chain of nsplit/4 instead of nsplit loads (the finalize used to cost as much as the pass over X)
 template <int AT, int MODE>
-__global__ void absstat_final_kernel(const float* __restrict__ part, const int* __restrict__ nanflag, int nsplit, int64_t rows,
-                                     int64_t cols, void* __restrict__ acc) {
-    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= cols) return;
+__global__ __launch_bounds__(256) void absstat_final_kernel(const float* __restrict__ part, const int* __restrict__ nanflag, int nsplit, int64_t rows,
+                                                            int64_t cols, void* __restrict__ acc) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t c = (int64_t)blockIdx.x * 64 + lane;
+    const bool ok = c < cols;
+    float s = 0.0f;
+    int nn = 0;
+    if (ok) {
+        int k = w;
+        for (; k + 12 < nsplit; k += 16) {
+            const float v0 = part[(int64_t)k * cols + c], v1 = part[(int64_t)(k + 4) * cols + c], v2 = part[(int64_t)(k + 8) * cols + c],
+                        v3 = part[(int64_t)(k + 12) * cols + c];
+            if (MODE != ASVD_STAT_ABS_MAX) s = (((s + v0) + v1) + v2) + v3;
+            else {
+                s = fmaxf(fmaxf(s, v0), fmaxf(v1, fmaxf(v2, v3)));
+                nn |= nanflag[(int64_t)k * cols + c] | nanflag[(int64_t)(k + 4) * cols + c] | nanflag[(int64_t)(k + 8) * cols + c] |
+                      nanflag[(int64_t)(k + 12) * cols + c];
+            }
+        }
+        for (; k < nsplit; k += 4) {
+            const float v = part[(int64_t)k * cols + c];
+            if (MODE != ASVD_STAT_ABS_MAX) s += v;
+            else { s = fmaxf(s, v); nn |= nanflag[(int64_t)k * cols + c]; }
+        }
+    }
+    __shared__ float red[4][64];
+    __shared__ int rnan[4][64];
+    red[w][lane] = s;
+    rnan[w][lane] = nn;
+    __syncthreads();
+    if (w != 0 || !ok) return;
     const float old = elem<AT>::ld(acc, c);
     if (MODE != ASVD_STAT_ABS_MAX) {
-        float s = 0.0f;
-        for (int k = 0; k < nsplit; ++k) s += part[(int64_t)k * cols + c];
-        const float mean = elem<AT>::rnd(__fdiv_rn(s, (float)rows));  // .mean() result in the activation dtype
-        elem<AT>::st(acc, c, old + mean);                   // `+=` in that dtype (one rounding)
+        const float tot = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        const float mean = elem<AT>::rnd(__fdiv_rn(tot, (float)rows));  // .mean() result in the activation dtype
+        elem<AT>::st(acc, c, old + mean);                               // `+=` in that dtype (one rounding)
     } else {
-        float mx = 0.0f;
-        int nn = 0;
-        for (int k = 0; k < nsplit; ++k) {
-            mx = fmaxf(mx, part[(int64_t)k * cols + c]);
-            nn |= nanflag[(int64_t)k * cols + c];
-        }
+        const float mx = fmaxf(fmaxf(red[0][lane], red[1][lane]), fmaxf(red[2][lane], red[3][lane]));
+        const int anynan = rnan[0][lane] | rnan[1][lane] | rnan[2][lane] | rnan[3][lane];
         // torch.where(abs_max > acc, abs_max, acc): a NaN abs_max never wins
-        if (!nn && mx > old) elem<AT>::st(acc, c, mx);
+        if (!anynan && mx > old) elem<AT>::st(acc, c, mx);
     }
 }
 
@@ -407,7 +431,7 @@ int asvd_absstat_finalize(const void* work, size_t work_bytes, int64_t rows, int
     hipStream_t st = (hipStream_t)stream;
     const float* part = (const float*)work;
     const int* nanflag = (const int*)(part + (int64_t)ns * cols);
-    const unsigned fg = (unsigned)ceil_div64(cols, 256);
+    const unsigned fg = (unsigned)ceil_div64(cols, 64);
     ASVD_DISPATCH_DTYPE(acc_dtype, AT, {
         if (mode != ASVD_STAT_ABS_MAX) absstat_final_kernel<AT, ASVD_STAT_ABS_MEAN><<<fg, 256, 0, st>>>(part, nanflag, ns, rows, cols, acc);
         else absstat_final_kernel<AT, ASVD_STAT_ABS_MAX><<<fg, 256, 0, st>>>(part, nanflag, ns, rows, cols, acc);

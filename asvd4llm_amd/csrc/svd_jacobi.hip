@@ -53,6 +53,28 @@ __device__ __forceinline__ void rr_pair(int nb, int step, int k, int& I, int& J)
     J = a < b ? b : a;
 }
 
+// Pair ordering at the SUPER-PANEL level of the two-level sweeps (twolevel.h): XOR like the panel level when the super-panel count is a
+// power of two; otherwise (c_super_order = 0) the round-robin tournament over ns (+1 if odd) super-panels — a padded XOR schedule runs
+// P-1 super-steps with many empty slots (13B: 80 super-panels -> 127 steps, 37 % empty), the tournament ns-1 full ones.  Pairs with
+// T >= ns (padding / the bye) are skipped by the callers.  `step` counts from 0.
+__constant__ int c_super_order = 1;
+__device__ __forceinline__ void super_pair(int ns, int step, int k, int& S, int& T) {
+    if (c_super_order) {
+        const int d = step + 1;
+        const int h = 31 - __clz(d);
+        S = ((k >> h) << (h + 1)) | (k & ((1 << h) - 1));
+        T = S ^ d;
+        return;
+    }
+    const int n = ns + (ns & 1);  // even player count; player n-1 is the bye when ns is odd
+    if (k >= n / 2) { S = ns; T = ns; return; }
+    const int a = (k == 0) ? 0 : 1 + (k - 1 + step) % (n - 1);
+    const int pb = n - 1 - k;
+    const int b = 1 + (pb - 1 + step) % (n - 1);
+    S = a < b ? a : b;
+    T = a < b ? b : a;
+}
+
 // Pair handled by a workgroup: from the schedule (plist == nullptr) or, in sparse sweeps, from an explicit per-problem list of
 // marked pairs (code = I << 16 | J, -1 = empty slot).  Returns false when there is nothing to do for this slot.
 __device__ __forceinline__ bool get_pair(const int* __restrict__ plist, int list_stride, int b, int nb, int step, int pair, int& I, int& J) {
@@ -369,7 +391,7 @@ __device__ __forceinline__ void evd_body(const BlockCtx& ctx, float* __restrict_
     } else {
         act_flag = v3.subact + slot * 4 + (MODE - 1) * 2 + sp;
         qo = v3.Q0 + (slot * 2 + sp) * (PW * PW);
-        rr_pair(v3.ns, step, pair, S, T);
+        super_pair(v3.ns, step, pair, S, T);
         if (T >= v3.ns) {  // padding super-pair
             if (tid == 0) *act_flag = 0;
             return;
@@ -1921,6 +1943,13 @@ int make_plan(int batch, int64_t m, int64_t n, int want_u, int want_vv, Plan& p)
     return ASVD_OK;
 }
 
+// super-panel pairs by round-robin tournament instead of a padded XOR schedule: only where the super-panel count is not a power of two
+static bool super_rr_for(const Plan& p) {
+    if (!p.two || (p.ns & (p.ns - 1)) == 0) return false;
+    const char* e = getenv("ASVD_SUPER_RR");
+    return e && atoi(e) == 1;
+}
+
 // ---- optional per-class timing with HIP events on the call's stream ------------------------------
 // profiling state is per host thread: concurrent calls from different threads (on their own streams and workspaces) do not share it
 thread_local bool g_prof_enabled = false;
@@ -2097,6 +2126,8 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
         ASVD_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_pair_order), &order, sizeof(int), 0, hipMemcpyHostToDevice));
         const int fence = stream_groups_for(batch) > 1 ? 1 : 0;
         ASVD_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_fence), &fence, sizeof(int), 0, hipMemcpyHostToDevice));
+        const int sup = super_rr_for(p) ? 0 : 1;
+        ASVD_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_super_order), &sup, sizeof(int), 0, hipMemcpyHostToDevice));
         const int evp = getenv("ASVD_EVD_PAIRS") ? std::max(1, std::min(64, atoi(getenv("ASVD_EVD_PAIRS")))) : PW / 2;
         ASVD_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_evd_pairs), &evp, sizeof(int), 0, hipMemcpyHostToDevice));
     }
@@ -2358,7 +2389,7 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
             }
         }
         // pipelined two-level sweep (twolevel.h "dual launches"): two halves of the batch, two phases apart, on ONE stream
-        const bool piped = two_now && ngroups == 1 && batch >= 2 && split_piped;
+        const bool piped = two_now && ngroups == 1 && batch >= 2 && split_piped && !super_rr_for(p);
         if (piped) {
             const int nsuper = 2 * p.npairs_s - 1;
             const int dup2 = std::min(nsuper, getenv("ASVD_DUP2") ? atoi(getenv("ASVD_DUP2")) : 0);
@@ -2426,14 +2457,15 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
                 launch_u(0, D);
             }
         } else if (two_now) {
-            const int nsuper = 2 * p.npairs_s - 1;
+            const bool super_rr = super_rr_for(p);
+            const int nsuper = super_rr ? (p.ns + (p.ns & 1)) - 1 : 2 * p.npairs_s - 1;
             const bool split_bf16 = split_on;
             const bool gram_split = split_on && getenv("ASVD_GRAM_SPLIT") && atoi(getenv("ASVD_GRAM_SPLIT")) == 1;
             // local super-levels D = 1..L run twice at the start of the sweep (the two-level form of ASVD_DUP; ASVD_DUP2=L)
             const int dup2 = std::min(nsuper, getenv("ASVD_DUP2") ? atoi(getenv("ASVD_DUP2")) : 0);
             // supgram: the update of step D also leaves the Gram tiles of the step that follows (one pass instead of two); the
             // stand-alone Gram pass then runs only in front of the first super-step.  Needs split-bf16; ASVD_SUPGRAM=0 turns it off.
-            const bool fuse_ug = split_bf16 && p.npairs_s >= 2 && !(getenv("ASVD_SUPGRAM") && atoi(getenv("ASVD_SUPGRAM")) == 0);
+            const bool fuse_ug = split_bf16 && !super_rr && p.npairs_s >= 2 && !(getenv("ASVD_SUPGRAM") && atoi(getenv("ASVD_SUPGRAM")) == 0);
             if (fuse_ug)
                 ASVD_HIP_CHECK(hipFuncSetAttribute((const void*)supgram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                    (int)(SUPGRAM_SMEM_FLOATS * sizeof(float))));
@@ -2823,6 +2855,7 @@ int asvd_test_supdate(int split, float* X, int64_t panel_stride, int64_t batch_s
     {
         const int order = 1;
         ASVD_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_pair_order), &order, sizeof(int), 0, hipMemcpyHostToDevice));
+        ASVD_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_super_order), &order, sizeof(int), 0, hipMemcpyHostToDevice));
     }
     if (split)
         supdate_split_kernel<<<dim3(nchunks, npairs, batch), 256, 0, st>>>(X, panel_stride, batch_stride, ns, D, R, rows_per_wg, Qfin, subact, done, nupd);
@@ -2843,6 +2876,7 @@ int asvd_test_supgram(float* X, int64_t panel_stride, int64_t batch_stride, int 
     {
         const int order = 1;
         ASVD_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_pair_order), &order, sizeof(int), 0, hipMemcpyHostToDevice));
+        ASVD_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_super_order), &order, sizeof(int), 0, hipMemcpyHostToDevice));
     }
     ASVD_HIP_CHECK(hipFuncSetAttribute((const void*)supgram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SUPGRAM_SMEM_FLOATS * sizeof(float))));
     supgram_kernel<<<dim3(nchunks, (2 * npairs) / 4, batch), 512, SUPGRAM_SMEM_FLOATS * sizeof(float), st>>>(X, panel_stride, batch_stride, ns, D, E, R, m_pad,

@@ -55,7 +55,7 @@ __device__ __forceinline__ void sgram6_body(const BlockCtx& ctx, float* __restri
     ASVD_KERNEL_ACQUIRE();
     if (done[b]) return;
     int S, T;
-    rr_pair(ns, D - 1, pair, S, T);
+    super_pair(ns, D - 1, pair, S, T);
     if (T >= ns) return;
     const float* __restrict__ Xb = X + (int64_t)b * batch_stride;
     const float* __restrict__ P0 = Xb + (int64_t)(2 * S) * panel_stride;
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256, 2) void supdate_kernel(float* __restrict__ X, 
     ASVD_KERNEL_ACQUIRE();
     if (done[b] || !pair_active(subact, (int64_t)b * npairs + pair)) return;
     int S, T;
-    rr_pair(ns, D - 1, pair, S, T);
+    super_pair(ns, D - 1, pair, S, T);
     if (T >= ns) return;
     if (chunk == 0 && threadIdx.x == 0) atomicAdd(&nupd[b], 1);  // instrumentation: super-pairs updated in this sweep
     float* __restrict__ Xb = X + (int64_t)b * batch_stride;
@@ -260,7 +260,7 @@ __device__ __forceinline__ void supdate_split_body(const BlockCtx& ctx, float* _
     ASVD_KERNEL_ACQUIRE();
     if (done[b] || !pair_active(subact, (int64_t)b * npairs + pair)) return;
     int S, T;
-    rr_pair(ns, D - 1, pair, S, T);
+    super_pair(ns, D - 1, pair, S, T);
     if (T >= ns) return;
     if (chunk == 0 && threadIdx.x == 0) atomicAdd(&nupd[b], 1);  // instrumentation: super-pairs updated in this sweep
     float* __restrict__ Xb = X + (int64_t)b * batch_stride;
