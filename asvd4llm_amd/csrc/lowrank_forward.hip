@@ -136,6 +136,83 @@ __global__ __launch_bounds__(256, 1) void lowrank_forward_kernel(const uint16_t*
     }
 }
 
+// --------------------------------------------------------------------------------------------------
+// Decode-sized inputs (T <= 4 tokens): the same two phases as a pair of fused GEMVs.  A wave takes one weight ROW at a time and reads it
+// with fully coalesced 16-byte loads (1 KiB per wave-instruction, the whole row in flight at once); the T activation rows sit in LDS
+// (phase 1: x, phase 2: z); products are v_dot2_f32_f16 (exact fp16 products, fp32 accumulation), the 64 partial sums of a row are
+// folded with DPP/shuffle steps.  Eight waves per workgroup, one workgroup per CU (the grid barrier needs co-residency), rows
+// interleaved over all waves of the grid.  No MFMA: at <= 4 tokens the tile would be >= 87 % padding and the op is a pure weight stream.
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+template <int TT>
+__device__ __forceinline__ void gemv_rows(const uint4* __restrict__ W4, int64_t ldw4 /* row stride in uint4 */, int rows, int klen8 /* k length in uint4 */,
+                                          const uint4* __restrict__ xs /* LDS: [TT][klen8] */, int gw, int nw, int lane,
+                                          uint16_t* __restrict__ out, int64_t ldo, const uint16_t* __restrict__ bias, int T) {
+    constexpr int MAXC = 22;  // chunks of 64 uint4 (512 halfs) per row: K <= 11264
+    const int nch = (klen8 + 63) / 64;
+    for (int j = gw; j < rows; j += nw) {
+        const uint4* row = W4 + (int64_t)j * ldw4;
+        uint4 wv[MAXC];
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+            if (c < nch) {
+                const int k8 = c * 64 + lane;
+                wv[c] = k8 < klen8 ? row[k8] : make_uint4(0, 0, 0, 0);
+            }
+        float acc[TT];
+#pragma unroll
+        for (int t = 0; t < TT; ++t) acc[t] = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+            if (c < nch) {
+                const int k8 = min(c * 64 + lane, klen8 - 1);  // masked lanes hold zeros in wv: any valid x slot will do
+#pragma unroll
+                for (int t = 0; t < TT; ++t) {
+                    const uint4 xv = xs[t * klen8 + k8];
+                    acc[t] = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, wv[c].x), __builtin_bit_cast(f16x2, xv.x), acc[t], false);
+                    acc[t] = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, wv[c].y), __builtin_bit_cast(f16x2, xv.y), acc[t], false);
+                    acc[t] = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, wv[c].z), __builtin_bit_cast(f16x2, xv.z), acc[t], false);
+                    acc[t] = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, wv[c].w), __builtin_bit_cast(f16x2, xv.w), acc[t], false);
+                }
+            }
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            float v = acc[t];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (lane == 0 && t < T) {
+                if (bias) v += f16_bits_to_f32(bias[j]);
+                out[(int64_t)t * ldo + j] = f32_to_f16_bits(v);
+            }
+        }
+    }
+}
+
+template <int TT>
+__global__ __launch_bounds__(512, 1) void lowrank_gemv_kernel(const uint16_t* __restrict__ x, int T, const uint16_t* __restrict__ Bp,
+                                                              const uint16_t* __restrict__ Ap, const uint16_t* __restrict__ bias, int N, int K,
+                                                              int rp, uint16_t* __restrict__ y, uint16_t* __restrict__ z, unsigned* bar) {
+    extern __shared__ __attribute__((aligned(16))) uint4 gv_smem[];  // [TT][max(K, rp) / 8]
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int G = gridDim.x, gw = blockIdx.x * 8 + wave, nw = G * 8;
+    // ---- phase 1: z[t, j] = fp16( x[t, :] . B[j, :] ), j < rp (padded ranks have zero rows in Bp and give exact zeros) ----
+    const int k8 = K / 8;
+    for (int e = tid; e < TT * k8; e += 512) {
+        const int t = e / k8, kk = e - t * k8;
+        gv_smem[e] = t < T ? ((const uint4*)x)[(int64_t)t * k8 + kk] : make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
+    gemv_rows<TT>((const uint4*)Bp, k8, rp, k8, gv_smem, gw, nw, lane, z, rp, nullptr, TT);
+
+    grid_barrier(bar, (unsigned)G);
+
+    // ---- phase 2: y[t, n] = fp16( z[t, :] . A[n, :] + bias[n] ) ----
+    const int r8 = rp / 8;
+    for (int e = tid; e < TT * r8; e += 512) gv_smem[e] = ((const uint4*)z)[e];
+    __syncthreads();
+    gemv_rows<TT>((const uint4*)Ap, r8, N, r8, gv_smem, gw, nw, lane, y, N, bias, T);
+}
+
 }  // namespace
 
 extern "C" {
@@ -164,6 +241,23 @@ int asvd_lowrank_forward_f16(const void* x, int64_t T, const void* Bp, const voi
     const int grid = (int)(units < cus ? units : cus);  // <= one workgroup per CU: co-resident, the in-kernel barrier cannot deadlock
     unsigned* bar = (unsigned*)work;
     uint16_t* z = (uint16_t*)((char*)work + 256);
+    const size_t gv_lds = (size_t)(T <= 1 ? 1 : (T <= 2 ? 2 : 4)) * (size_t)(K > rp ? K : rp) * sizeof(uint16_t);
+    if (T <= 4 && K <= 11264 && rp <= 11264 && gv_lds <= 96 * 1024) {  // decode-sized: fused GEMV pair (see lowrank_gemv_kernel)
+        const int64_t rows = rp > N ? rp : N;
+        const int ggrid = (int)(ceil_div64(rows, 8) < cus ? ceil_div64(rows, 8) : cus);
+#define ASVD_GV_LAUNCH(TT)                                                                                                                    \
+    do {                                                                                                                                      \
+        ASVD_HIP_CHECK(hipFuncSetAttribute((const void*)lowrank_gemv_kernel<TT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gv_lds));     \
+        hipLaunchKernelGGL(lowrank_gemv_kernel<TT>, dim3(ggrid), dim3(512), gv_lds, (hipStream_t)stream, (const uint16_t*)x, (int)T,            \
+                           (const uint16_t*)Bp, (const uint16_t*)Ap, (const uint16_t*)bias, (int)N, (int)K, (int)rp, (uint16_t*)y, z, bar);     \
+    } while (0)
+        if (T <= 1) ASVD_GV_LAUNCH(1);
+        else if (T <= 2) ASVD_GV_LAUNCH(2);
+        else ASVD_GV_LAUNCH(4);
+#undef ASVD_GV_LAUNCH
+        ASVD_HIP_CHECK(hipGetLastError());
+        return ASVD_OK;
+    }
     hipLaunchKernelGGL(lowrank_forward_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, (int)T,
                        (const uint16_t*)Bp, (const uint16_t*)Ap, (const uint16_t*)bias, (int)N, (int)K, (int)rp, (uint16_t*)y, z, bar, sl1,
                        sl2);

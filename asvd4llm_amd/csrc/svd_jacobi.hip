@@ -1466,11 +1466,12 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ G,
         if (tid == 0) A[c * CLD + c] = r;
         for (int k = c + 1 + tid; k < CB; k += 256) A[c * CLD + k] *= rinv;
         __syncthreads();
-        // trailing update of the upper triangle: A[i][k] -= R[c][i] R[c][k], c < i <= k
-        const int rem = CB - 1 - c;
-        for (int e = tid; e < rem * rem; e += 256) {
-            const int i = c + 1 + e / rem, k = c + 1 + e % rem;
-            if (k >= i) A[i * CLD + k] -= A[c * CLD + i] * A[c * CLD + k];
+        // trailing update of the upper triangle: A[i][k] -= R[c][i] R[c][k], c < i <= k  (16 x 16 thread grid striding the block: no
+        // integer division per element, which cost more than the fp64 FMA it addressed)
+        for (int i = c + 1 + (tid >> 4); i < CB; i += 16) {
+            const double ri = A[c * CLD + i];
+            for (int k = c + 1 + (tid & 15); k < CB; k += 16)
+                if (k >= i) A[i * CLD + k] -= ri * A[c * CLD + k];
         }
         __syncthreads();
     }

@@ -150,7 +150,7 @@ class SVDLinear(nn.Module):
         return U, S, V, s
 
     @staticmethod
-    def prefactorize(linears, act_aware=False, alpha=1, ranks=None, max_batch=16):
+    def prefactorize(linears, act_aware=False, alpha=1, ranks=None, max_batch=32):
         """Factorise many Linears up front, same-shape ones CONCURRENTLY (asvd_svd_batched): independent matrices are what
         fills the 256 CUs during the 64-workgroup eigen-solve phase, and 288 GB of HBM hold the factors of a whole 7B/13B
         shard.  ranks: optional {linear: largest rank needed} (convergence is then only enforced for those leading triplets).

@@ -90,7 +90,7 @@ def calib_sensitivity_ppl(model, calib_loader, args, use_cache=True):
         l._asvd_rank_hint = max(SVDLinear.compute_rank(l, r, args.rank_align) for r in param_ratio_candidates)
     if keep_cache and getattr(args, "prefactorize", True) and all(l.weight.is_cuda for l in mine):
         SVDLinear.prefactorize(mine, act_aware=True, alpha=args.alpha, ranks={l: l._asvd_rank_hint for l in mine},
-                               max_batch=getattr(args, "svd_batch", 16))
+                               max_batch=getattr(args, "svd_batch", 32))
     # prefix-cached evaluation (sweep_eval.py): same perplexities, about half the forward work; --no_fused_sweep disables
     evaluator = None
     if getattr(args, "fused_sweep", True) and n_mine > 0:
@@ -168,7 +168,7 @@ def calib_sensitivity_stable_rank(model, calib_loader, args, use_cache=True):
         w = contiguous[l]
         groups.setdefault((tuple(w.shape), w.dtype, w.stride(0), w.device), []).append(l)
     sigma_max = {}
-    max_batch = getattr(args, "svd_batch", 16)
+    max_batch = getattr(args, "svd_batch", 32)
     for members in groups.values():
         for i in range(0, len(members), max_batch):
             chunk = members[i:i + max_batch]

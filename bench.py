@@ -63,7 +63,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=16, help="matrices factorised concurrently per step and GPU (same-shape problems share every launch; 16 = the q/k/v/o Linears of four layers)")
+    ap.add_argument("--batch", type=int, default=32, help="matrices factorised concurrently per step and GPU (same-shape problems share every launch; 32 = the q/k/v/o Linears of eight layers, the pipeline's default svd_batch)")
     ap.add_argument("--m", type=int, default=4096)
     ap.add_argument("--n", type=int, default=4096)
     ap.add_argument("--rank", type=int, default=512)

@@ -22,6 +22,9 @@ def _exact(x, A, B, bias):
 @pytest.mark.parametrize("T,K,r,N,with_bias", [
     (1, 4096, 1843, 4096, False),     # decode, llama-7b attention projection at ratio 0.9 (rank not a multiple of anything)
     (16, 4096, 1024, 4096, True),
+    (2, 4096, 1024, 4096, True),      # decode sizes take the fused GEMV pair
+    (3, 11008, 1500, 4096, True),
+    (4, 4096, 2686, 11008, False),
     (33, 4096, 2686, 11008, False),   # up_proj at 0.9: two token tiles, rank > 2048
     (7, 11008, 1500, 4096, True),     # down_proj: K = 172 * 64
     (256, 768, 345, 3072, True),      # opt-125m fc1, the largest token count the entry accepts

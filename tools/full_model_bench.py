@@ -49,7 +49,7 @@ def main():
     ap.add_argument("--layers", type=int, default=None, help="decoder layers to build (default: all + lm_head)")
     ap.add_argument("--ratio", type=float, default=0.9)
     ap.add_argument("--alpha", type=float, default=0.5)
-    ap.add_argument("--svd_batch", type=int, default=16)
+    ap.add_argument("--svd_batch", type=int, default=32)
     ap.add_argument("--stable_rank", action="store_true", help="time calib_sensitivity_stable_rank (values-only sigma_max per layer) instead")
     ap.add_argument("--full_rank", action="store_true", help="factorise all min(m,n) triplets instead of the rank needed at --ratio")
     ap.add_argument("--no_parity", action="store_true", help="skip the per-shape oracle spot-check")

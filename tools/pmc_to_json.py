@@ -14,9 +14,9 @@ def table(path):
     return out
 fetch, write = table(os.path.join(d, "pmc_FETCH_SIZE.txt")), table(os.path.join(d, "pmc_WRITE_SIZE.txt"))
 names = {"supgram": "supgram_kernel", "supdate": "supdate_split_kernel", "sgram": "sgram6_kernel", "evd": "evd_kernel", "snapshot": "fullcheck_kernel"}
-res = {"batch": 16, "source": "profiles/" + os.path.basename(d).replace("prof_", "") + "_pmc_*.txt",
+res = {"batch": int(os.environ.get("PMC_BATCH", "16")), "source": "profiles/" + os.path.basename(d).replace("prof_", "") + "_pmc_*.txt",
        "note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes of `python bench.py --no_cpu_baseline --no_latency --steps 1 --warmup 0 --prewarm_s 0` "
-               "(16 x 4096x4096 fp32, one stream); mean per dispatch over all launches of the run; FETCH doubled (gfx950 half-count), WRITE as reported",
+               "(" + os.environ.get("PMC_BATCH", "16") + " x 4096x4096 fp32, one stream); mean per dispatch over all launches of the run; FETCH doubled (gfx950 half-count), WRITE as reported",
        "kernels": {}}
 for key, kn in names.items():
     f = [v for (n, c), v in fetch.items() if kn in n and c == "FETCH_SIZE"]
