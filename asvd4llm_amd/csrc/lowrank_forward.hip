@@ -25,26 +25,39 @@
 
 namespace {
 
+// The intermediate z is the only data that crosses the grid barrier.  It is written with agent-scope (sc1) stores, which go through to
+// memory, and read back with agent-scope loads, which do not hit a stale line of another XCD's L2 — so the barrier itself needs NO
+// cache-wide fence.  (First version: an agent-scope release + acquire fence in every wave = a write-back / invalidate of the whole L2
+// per wave; 1024-2048 of them made the kernel 36-75 us long whatever the data path did.)
+__device__ __forceinline__ void z_store(uint16_t* p, uint16_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint4 z_load16(const uint4* p) {
+    const uint64_t* q = (const uint64_t*)p;
+    const uint64_t lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint64_t hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_uint4((unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32));
+}
+
 __device__ __forceinline__ void grid_barrier(unsigned* bar, unsigned nwg) {
     // sense-reversing barrier on two words: bar[0] arrivals, bar[1] generation.  Zero-initialised once by the caller; reusable.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // every wave: its z stores reach L2 and the L2 is written back (other XCDs)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's z stores have been acknowledged (s_waitcnt vmcnt(0)); no L2 write-back
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned gen = __hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned prev = __hip_atomic_fetch_add(&bar[0], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned prev = __hip_atomic_fetch_add(&bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (prev == nwg - 1) {
             __hip_atomic_store(&bar[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_fetch_add(&bar[1], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_s_waitcnt(0);  // the reset is out before the generation moves
+            __hip_atomic_fetch_add(&bar[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
-            while (__hip_atomic_load(&bar[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == gen) __builtin_amdgcn_s_sleep(2);
+            while (__hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) __builtin_amdgcn_s_sleep(1);
         }
     }
     __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // every wave: drop stale L1 / non-local L2 lines before reading z
 }
 
 // One 32 x 32 output tile  C[i][j] = sum_k P[prow0+i][k] * Q[qrow0+j][k]  over k in [0, 64*nk), fp32, all four waves.
 // Rows i >= pvalid of P and j >= qvalid of Q read as zero.  Result is left in red[] (sum of the 4 wave partials is done by the caller).
+template <bool PCOH>  // PCOH: P is the intermediate z — agent-scope loads (see z_load16)
 __device__ __forceinline__ void tile_partial(f32x16& acc, const uint16_t* __restrict__ P, int64_t ldp, int pvalid,
                                              const uint16_t* __restrict__ Q, int64_t ldq, int qvalid, int nk, int wave, int lane) {
     const int i = lane & 31, g = lane >> 5;
@@ -63,7 +76,7 @@ __device__ __forceinline__ void tile_partial(f32x16& acc, const uint16_t* __rest
             const int it = (base + 4 * u < nk) ? base + 4 * u : base;
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
-                pv[u][m] = prow[it * 8 + m];  // 64 halfs = 8 uint4 per iteration per row; this lane's 4 start at 4*g (folded into prow)
+                pv[u][m] = PCOH ? z_load16(prow + it * 8 + m) : prow[it * 8 + m];  // 64 halfs = 8 uint4 per iteration per row; this lane's 4 start at 4*g (folded into prow)
                 qv[u][m] = qrow[it * 8 + m];
             }
         }
@@ -96,7 +109,7 @@ __global__ __launch_bounds__(256, 1) void lowrank_forward_kernel(const uint16_t*
     for (int u = blockIdx.x; u < nT * ns1; u += G) {
         const int t0 = (u / ns1) * 32, r0 = (u % ns1) * sl1;
         f32x16 acc;
-        tile_partial(acc, x + (int64_t)t0 * K, K, T - t0, Bp + (int64_t)r0 * K, K, sl1, K / 64, wave, lane);
+        tile_partial<false>(acc, x + (int64_t)t0 * K, K, T - t0, Bp + (int64_t)r0 * K, K, sl1, K / 64, wave, lane);
 #pragma unroll
         for (int q = 0; q < 16; ++q) red[wave][q * 64 + lane] = acc[q];
         __syncthreads();
@@ -105,7 +118,7 @@ __global__ __launch_bounds__(256, 1) void lowrank_forward_kernel(const uint16_t*
             const int e = tid + 256 * q, reg = e >> 6, l = e & 63;
             const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (l >> 5), col = l & 31;
             const float v = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
-            if (col < sl1) z[(int64_t)(t0 + row) * rp + r0 + col] = f32_to_f16_bits(v);  // z has 32*nT rows: no token mask needed
+            if (col < sl1) z_store(z + (int64_t)(t0 + row) * rp + r0 + col, f32_to_f16_bits(v));  // z has 32*nT rows: no token mask needed
         }
         __syncthreads();
     }
@@ -118,7 +131,7 @@ __global__ __launch_bounds__(256, 1) void lowrank_forward_kernel(const uint16_t*
         const int t0 = (u / ns2) * 32, n0 = (u % ns2) * sl2;
         const int nvalid = min(sl2, N - n0);
         f32x16 acc;
-        tile_partial(acc, z + (int64_t)t0 * rp, rp, 32, Ap + (int64_t)n0 * rp, rp, nvalid, rp / 64, wave, lane);
+        tile_partial<true>(acc, z + (int64_t)t0 * rp, rp, 32, Ap + (int64_t)n0 * rp, rp, nvalid, rp / 64, wave, lane);
 #pragma unroll
         for (int q = 0; q < 16; ++q) red[wave][q * 64 + lane] = acc[q];
         __syncthreads();
@@ -144,7 +157,7 @@ __global__ __launch_bounds__(256, 1) void lowrank_forward_kernel(const uint16_t*
 // interleaved over all waves of the grid.  No MFMA: at <= 4 tokens the tile would be >= 87 % padding and the op is a pure weight stream.
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
-template <int TT>
+template <int TT, bool ZOUT>
 __device__ __forceinline__ void gemv_rows(const uint4* __restrict__ W4, int64_t ldw4 /* row stride in uint4 */, int rows, int klen8 /* k length in uint4 */,
                                           const uint4* __restrict__ xs /* LDS: [TT][klen8] */, int gw, int nw, int lane,
                                           uint16_t* __restrict__ out, int64_t ldo, const uint16_t* __restrict__ bias, int T) {
@@ -182,7 +195,8 @@ __device__ __forceinline__ void gemv_rows(const uint4* __restrict__ W4, int64_t 
             for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
             if (lane == 0 && t < T) {
                 if (bias) v += f16_bits_to_f32(bias[j]);
-                out[(int64_t)t * ldo + j] = f32_to_f16_bits(v);
+                if (ZOUT) z_store(out + (int64_t)t * ldo + j, f32_to_f16_bits(v));
+                else out[(int64_t)t * ldo + j] = f32_to_f16_bits(v);
             }
         }
     }
@@ -202,15 +216,15 @@ __global__ __launch_bounds__(512, 1) void lowrank_gemv_kernel(const uint16_t* __
         gv_smem[e] = t < T ? ((const uint4*)x)[(int64_t)t * k8 + kk] : make_uint4(0, 0, 0, 0);
     }
     __syncthreads();
-    gemv_rows<TT>((const uint4*)Bp, k8, rp, k8, gv_smem, gw, nw, lane, z, rp, nullptr, TT);
+    gemv_rows<TT, true>((const uint4*)Bp, k8, rp, k8, gv_smem, gw, nw, lane, z, rp, nullptr, TT);
 
     grid_barrier(bar, (unsigned)G);
 
     // ---- phase 2: y[t, n] = fp16( z[t, :] . A[n, :] + bias[n] ) ----
     const int r8 = rp / 8;
-    for (int e = tid; e < TT * r8; e += 512) gv_smem[e] = ((const uint4*)z)[e];
+    for (int e = tid; e < TT * r8; e += 512) gv_smem[e] = z_load16((const uint4*)z + e);
     __syncthreads();
-    gemv_rows<TT>((const uint4*)Ap, r8, N, r8, gv_smem, gw, nw, lane, y, N, bias, T);
+    gemv_rows<TT, false>((const uint4*)Ap, r8, N, r8, gv_smem, gw, nw, lane, y, N, bias, T);
 }
 
 }  // namespace
@@ -230,9 +244,14 @@ int asvd_lowrank_forward_f16(const void* x, int64_t T, const void* Bp, const voi
     if (T < 1 || T > ASVD_LOWRANK_MAX_TOKENS || N < 1 || K < 64 || (K % 64) || rp < 64 || (rp % 64)) return ASVD_E_BADARG;
     if (work_bytes < asvd_lowrank_work_bytes(T, rp)) return ASVD_E_WORKSPACE;
     if ((((uintptr_t)x) | ((uintptr_t)Bp) | ((uintptr_t)Ap) | ((uintptr_t)work)) & 15) return ASVD_E_BADARG;
-    int dev = 0, cus = 0;
+    // per-call host cost matters at decode size: the CU count and the LDS opt-in are looked up once per device / kernel
+    static int s_cus[16] = {0};
+    static bool s_attr[16][3] = {{false}};
+    int dev = 0;
     ASVD_HIP_CHECK(hipGetDevice(&dev));
-    ASVD_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    if (dev < 0 || dev >= 16) return ASVD_E_BADARG;
+    if (!s_cus[dev]) ASVD_HIP_CHECK(hipDeviceGetAttribute(&s_cus[dev], hipDeviceAttributeMultiprocessorCount, dev));
+    const int cus = s_cus[dev];
     const int nT = (int)((T + 31) / 32);
     // half-masked tiles when full ones would leave more than half of the CUs without a unit (bandwidth-bound: more streams win)
     const int sl1 = (nT * (rp / 32) >= cus / 2) ? 32 : 16;
@@ -247,7 +266,11 @@ int asvd_lowrank_forward_f16(const void* x, int64_t T, const void* Bp, const voi
         const int ggrid = (int)(ceil_div64(rows, 8) < cus ? ceil_div64(rows, 8) : cus);
 #define ASVD_GV_LAUNCH(TT)                                                                                                                    \
     do {                                                                                                                                      \
-        ASVD_HIP_CHECK(hipFuncSetAttribute((const void*)lowrank_gemv_kernel<TT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gv_lds));     \
+        bool& attr_done = s_attr[dev][TT == 1 ? 0 : (TT == 2 ? 1 : 2)];                                                                         \
+        if (!attr_done) {                                                                                                                     \
+            ASVD_HIP_CHECK(hipFuncSetAttribute((const void*)lowrank_gemv_kernel<TT>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));   \
+            attr_done = true;                                                                                                                 \
+        }                                                                                                                                     \
         hipLaunchKernelGGL(lowrank_gemv_kernel<TT>, dim3(ggrid), dim3(512), gv_lds, (hipStream_t)stream, (const uint16_t*)x, (int)T,            \
                            (const uint16_t*)Bp, (const uint16_t*)Ap, (const uint16_t*)bias, (int)N, (int)K, (int)rp, (uint16_t*)y, z, bar);     \
     } while (0)

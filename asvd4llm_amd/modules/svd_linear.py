@@ -22,11 +22,11 @@ def _strict():
     return os.environ.get("ASVD_STRICT", "0") == "1"
 
 
-FUSED_FORWARD_MAX_TOKENS, FUSED_FORWARD_MAX_OUT = 16, 8192  # where the one-launch forward measured faster than two GEMM launches
+FUSED_FORWARD_MAX_TOKENS, FUSED_FORWARD_MAX_OUT = 16, 8192  # where the one-launch forward measured faster than two GEMM launches (tokens; in/out features)
 
 
-def _fused_forward_enabled():  # ASVD_FUSED_FORWARD=1 sends decode-sized forwards through the one-launch kernel (K10)
-    return os.environ.get("ASVD_FUSED_FORWARD", "0") == "1"
+def _fused_forward_enabled():  # ASVD_FUSED_FORWARD=0 keeps every forward on the two nn.Linear launches
+    return os.environ.get("ASVD_FUSED_FORWARD", "1") != "0"
 
 
 class SVDLinear(nn.Module):
@@ -238,13 +238,13 @@ class SVDLinear(nn.Module):
         return st[1:]
 
     def forward(self, inp):
-        # compute USV^Tx + b  (svd_linear.py:105-109): the reference's two GEMMs through nn.Linear (hipBLASLt).
-        # Opt-in (ASVD_FUSED_FORWARD=1) for decode-sized inputs (<= 16 fp16 tokens, out_features <= 8192, no autograd): ONE persistent launch
-        # that streams B and A once and keeps the r-wide intermediate on chip (K10, csrc/lowrank_forward.hip).  Parity-tested, but measured
-        # only at par with the two hipBLASLt launches at 4096 -> 1843 -> 4096 (38.5 vs 37.2 us at 1 token, 41.3 vs 37.6 at 16) and slower
-        # beyond, so it is not the default.
+        # compute USV^Tx + b  (svd_linear.py:105-109).  Decode-sized inputs (<= 16 fp16 tokens, in/out features <= 8192, no autograd): ONE
+        # persistent launch that streams B and A once and keeps the r-wide intermediate on chip (K10, csrc/lowrank_forward.hip) — measured
+        # 21 / 23 / 26 / 32 us at 1 / 2 / 4 / 16 tokens against 36 us for the two hipBLASLt launches at 4096 -> 1843 -> 4096.  Everywhere
+        # else the reference's two GEMMs through nn.Linear: at par from 64 tokens on and on the 11008-wide MLP projections (DESIGN.md
+        # section 4 has the table).  ASVD_FUSED_FORWARD=0 turns the fused path off.
         if (inp.is_cuda and inp.dtype == torch.float16 and self.BLinear.weight.dtype == torch.float16 and inp.shape[-1] % 64 == 0
-                and 0 < inp.numel() // inp.shape[-1] <= FUSED_FORWARD_MAX_TOKENS and self.ALinear.out_features <= FUSED_FORWARD_MAX_OUT
+                and 0 < inp.numel() // inp.shape[-1] <= FUSED_FORWARD_MAX_TOKENS and max(self.ALinear.out_features, inp.shape[-1]) <= FUSED_FORWARD_MAX_OUT
                 and self.BLinear.bias is None and _fused_forward_enabled()
                 and not (torch.is_grad_enabled() and (inp.requires_grad or self.ALinear.weight.requires_grad or self.BLinear.weight.requires_grad))):
             Ap, Bp, work = self._fused_state()

@@ -53,7 +53,7 @@ def test_fused_forward_vs_two_linears_and_fp64(gpu, T, K, r, N, with_bias):
 
 
 def test_svdlinear_forward_dispatch(gpu, monkeypatch):
-    """With ASVD_FUSED_FORWARD=1 SVDLinear.forward takes the fused launch for decode-sized fp16 inputs and the two nn.Linear GEMMs otherwise; repacks
+    """SVDLinear.forward takes the fused launch for decode-sized fp16 inputs and the two nn.Linear GEMMs otherwise; repacks
     when a weight changes."""
     from asvd4llm_amd.modules.svd_linear import SVDLinear
     torch.manual_seed(0)
@@ -61,10 +61,11 @@ def test_svdlinear_forward_dispatch(gpu, monkeypatch):
     m = SVDLinear.from_linear(lin, 0.6, act_aware=False)
     x = torch.randn(2, 7, 256, device="cuda").half()
     with torch.no_grad():
-        y_ref = m(x)  # default: the reference's two GEMMs
+        monkeypatch.setenv("ASVD_FUSED_FORWARD", "0")
+        y_ref = m(x)  # the reference's two GEMMs
         assert getattr(m, "_fused", None) is None
-        monkeypatch.setenv("ASVD_FUSED_FORWARD", "1")
-        y = m(x)
+        monkeypatch.delenv("ASVD_FUSED_FORWARD")
+        y = m(x)  # default: decode-sized fp16 input -> one launch
         assert getattr(m, "_fused", None) is not None and y.shape == (2, 7, 192)
         assert (y.float() - y_ref.float()).abs().max().item() <= 4e-3 * y_ref.float().abs().max().item()
         m.ALinear.weight.mul_(2.0)  # in-place edit bumps _version: the padded copy must follow
