@@ -203,7 +203,8 @@ int asvd_reconstruct_err(const void* W, int w_dtype, int64_t ldw, const void* A,
  * K10  fused SVDLinear forward for few tokens (modules/svd_linear.py:105-109 `y = self.BLinear(inp); y = self.ALinear(y)`):
  *        y[T, N] = fp16( fp16(x Bp^T) Ap^T + bias )
  *   ONE persistent launch (phase 1 z = x Bp^T, in-kernel grid barrier, phase 2 y = z Ap^T + bias); the r-wide intermediate z is
- *   rounded to fp16 exactly where BLinear's output is, lives in `work` and never leaves L2/MALL; B and A cross HBM once.
+ *   rounded to fp16 exactly where BLinear's output is, lives in `work` (agent-scope stores / loads, no cache-wide fence) and is
+ *   consumed inside the launch; B and A cross HBM once.  T <= 4: a pair of fused GEMVs (v_dot2_f32_f16); larger T: fp16 MFMA tiles.
  *   x [T, K] fp16 contiguous, 1 <= T <= ASVD_LOWRANK_MAX_TOKENS;  K % 64 == 0;
  *   Bp [rp, K] = BLinear.weight [r, K] with zero rows appended, Ap [N, rp] = ALinear.weight [N, r] with zero columns appended,
  *   rp = asvd_lowrank_padded_rank(r) (multiple of 64);  bias [N] fp16 or NULL;  y [T, N] fp16 contiguous.
