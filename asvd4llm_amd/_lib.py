@@ -71,6 +71,9 @@ def load(require_device=False):
         if not os.path.exists(LIB_PATH):
             raise AsvdHipError(f"{LIB_PATH} not built: run `python -m asvd4llm_amd.build` (hipcc --offload-arch=gfx950). "
                                "There is no CPU fallback for the ASVD hot path.")
+        # torch first: it bundles its own libamdhip64, and a process must not end up with two HIP runtimes — if this library pulled in
+        # /opt/rocm's copy before torch loaded, torch.cuda later reports "No HIP GPUs are available" (seen with build() + smoke() in one process)
+        import torch  # noqa: F401
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if a declared symbol is missing
