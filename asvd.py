@@ -16,7 +16,9 @@ def build_model(args):
     tokenizer = None
     if args.random_init:
         from asvd4llm_amd.model_zoo import random_init_model
-        model = random_init_model(args.model_id, dtype=torch.float16)
+        # synthetic weights are created on the GPU (seconds instead of ~2 minutes for a 7B-shaped model); ASVD_INIT_ON_CPU=1 keeps the host stream
+        init_dev = None if os.environ.get("ASVD_INIT_ON_CPU") == "1" or not torch.cuda.is_available() else "cuda"
+        model = random_init_model(args.model_id, dtype=torch.float16, device=init_dev)
     else:
         tokenizer = AutoTokenizer.from_pretrained(args.model_id, trust_remote_code=True)
         model = AutoModelForCausalLM.from_pretrained(args.model_id, torch_dtype=torch.float16, trust_remote_code=True)

@@ -34,14 +34,18 @@ def named_config(name, **overrides):
     return cfg
 
 
-def random_init_model(name, dtype=torch.float16, seed=233, **overrides):
+def random_init_model(name, dtype=torch.float16, seed=233, device=None, **overrides):
+    """device: where the parameters are created and initialised (None = CPU, the default the tests pin; "cuda" builds a 7B-shaped model
+    in seconds instead of ~2 minutes of fp16 normal_() on the host — a different, equally valid random stream)."""
+    import contextlib
     from transformers import AutoModelForCausalLM
     cfg = named_config(name, **overrides)
     torch.manual_seed(seed)
     prev = torch.get_default_dtype()
     torch.set_default_dtype(dtype)
     try:
-        model = AutoModelForCausalLM.from_config(cfg)
+        with (torch.device(device) if device is not None else contextlib.nullcontext()):
+            model = AutoModelForCausalLM.from_config(cfg)
     finally:
         torch.set_default_dtype(prev)
     model.config._name_or_path = name
