@@ -909,53 +909,59 @@ __global__ __launch_bounds__(256) void fullcheck_kernel(const float* __restrict_
 #pragma unroll
     for (int a = 0; a < 4; ++a) ok[a] = (ig * 4 + a <= J) && (J < nb);  // blocks below the diagonal are mirrors
     // slot q of the stage: q < 4 -> panel 4*ig + q (A side), q >= 4 -> panel 4*jg + q - 4 (B side); clamp padding panels
-    __shared__ __attribute__((aligned(16))) float stage[8][32 * PB];
     const float* __restrict__ Xb = X + (int64_t)b * batch_stride;
-    const float* src[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int pnl = (q < 4) ? ig * 4 + q : jg * 4 + q - 4;
-        src[q] = Xb + (int64_t)(pnl < nb ? pnl : nb - 1) * panel_stride + tid * 4;  // 256 threads x 16 B = one 32x32 chunk
-    }
-    f32x4 pre[8];
-    auto fetch = [&](int r0) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) pre[q] = *(const f32x4*)(src[q] + (int64_t)r0 * PB);
-    };
     f32x16 acc[4];
 #pragma unroll
     for (int a = 0; a < 4; ++a) acc[a] = (f32x16){0};
-    fetch(0);
-    for (int r0 = 0; r0 < m_pad; r0 += 32) {
-        __syncthreads();  // previous chunk fully consumed
+    if constexpr (SPLIT) {
+        // split-bf16 (twolevel.h): each fp32 operand = three bf16 exactly, six products per fp32 product on the bf16 matrix pipe (2.7x less
+        // pipe time; the dropped terms are at fp32 rounding level, which a coupling test against tol = 1e-6 needs).  The operand of k-step
+        // ks of a panel is: lane (column cc, group hh) holds rows 16 ks + 8 hh + e, e = 0..7.  Every operand of a 32-row chunk is built
+        // ONCE per workgroup: thread t owns the slots (panel (t >> 7) + 2 j, k-step (t >> 6) & 1, lane t & 63), j = 0..3, loads its eight
+        // values straight from global memory (a wave-load covers two 128-byte row segments), splits them and stores the three parts as
+        // ready operands; the waves then only read 16-byte operands.  (Before: every wave split the four A panels and its own B panel
+        // itself from an fp32 LDS image — 40 splits and 80 scalar LDS reads per wave and chunk against 48 MFMAs.)
+        __shared__ u32x4 oimg[8 * 2 * 3 * 64];
+        const int sks = (tid >> 6) & 1, sl = tid & 63;
+        const float* src[4];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) *(f32x4*)(&stage[q][tid * 4]) = pre[q];
-        __syncthreads();
-        if (r0 + 32 < m_pad) fetch(r0 + 32);
-        if constexpr (SPLIT) {
-            // split-bf16 (twolevel.h): each fp32 operand = three bf16 exactly, six products per fp32 product on the bf16 matrix pipe
-            // (2.7x less pipe time; the dropped terms are at fp32 rounding level, which a coupling test against tol = 1e-6 needs).
-            // Operand of k-step ks: lane (i = c, group h) holds rows 16 ks + 8 h + e, e = 0..7, of column c of its panel.
-            const int hh = lane >> 5, cc = lane & 31;
+        for (int j = 0; j < 4; ++j) {
+            const int q = (tid >> 7) + 2 * j;
+            const int pnl = (q < 4) ? ig * 4 + q : jg * 4 + q - 4;
+            src[j] = Xb + (int64_t)(pnl < nb ? pnl : nb - 1) * panel_stride + (int64_t)(16 * sks + 8 * (sl >> 5)) * PB + (sl & 31);
+        }
+        float pre[4][8];
+        auto fetch = [&](int r0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pre[j][e] = src[j][(int64_t)(r0 + e) * PB];
+        };
+        fetch(0);
+        for (int r0 = 0; r0 < m_pad; r0 += 32) {
+            __syncthreads();  // previous chunk's operands fully consumed
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                u32x4 p1, p2, p3;
+#pragma unroll
+                for (int e2 = 0; e2 < 4; ++e2) {
+                    unsigned x, y, z;
+                    split3(pre[j][2 * e2], pre[j][2 * e2 + 1], x, y, z);
+                    p1[e2] = x; p2[e2] = y; p3[e2] = z;
+                }
+                u32x4* o = oimg + ((((tid >> 7) + 2 * j) * 2 + sks) * 3) * 64 + sl;
+                o[0] = p1; o[64] = p2; o[128] = p3;
+            }
+            __syncthreads();
+            if (r0 + 32 < m_pad) fetch(r0 + 32);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                auto operand = [&](const float* pnl, bf16x8& o1, bf16x8& o2, bf16x8& o3) {
-                    const float* src = pnl + (16 * ks + 8 * hh) * PB + cc;
-                    u32x4 p1, p2, p3;
-#pragma unroll
-                    for (int e2 = 0; e2 < 4; ++e2) {
-                        unsigned x, y, z;
-                        split3(src[(2 * e2) * PB], src[(2 * e2 + 1) * PB], x, y, z);
-                        p1[e2] = x; p2[e2] = y; p3[e2] = z;
-                    }
-                    o1 = __builtin_bit_cast(bf16x8, p1); o2 = __builtin_bit_cast(bf16x8, p2); o3 = __builtin_bit_cast(bf16x8, p3);
-                };
-                bf16x8 B1, B2, B3;
-                operand(stage[4 + w], B1, B2, B3);
+                const u32x4* ob = oimg + (((4 + w) * 2 + ks) * 3) * 64 + lane;
+                const bf16x8 B1 = __builtin_bit_cast(bf16x8, ob[0]), B2 = __builtin_bit_cast(bf16x8, ob[64]), B3 = __builtin_bit_cast(bf16x8, ob[128]);
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
-                    bf16x8 A1, A2, A3;
-                    operand(stage[a], A1, A2, A3);
+                    const u32x4* oa = oimg + ((a * 2 + ks) * 3) * 64 + lane;
+                    const bf16x8 A1 = __builtin_bit_cast(bf16x8, oa[0]), A2 = __builtin_bit_cast(bf16x8, oa[64]), A3 = __builtin_bit_cast(bf16x8, oa[128]);
                     acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A3, B1, acc[a], 0, 0, 0);
                     acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B3, acc[a], 0, 0, 0);
                     acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, B2, acc[a], 0, 0, 0);
@@ -964,7 +970,27 @@ __global__ __launch_bounds__(256) void fullcheck_kernel(const float* __restrict_
                     acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B1, acc[a], 0, 0, 0);
                 }
             }
-        } else {
+        }
+    } else {
+        __shared__ __attribute__((aligned(16))) float stage[8][32 * PB];
+        const float* src[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int pnl = (q < 4) ? ig * 4 + q : jg * 4 + q - 4;
+            src[q] = Xb + (int64_t)(pnl < nb ? pnl : nb - 1) * panel_stride + tid * 4;  // 256 threads x 16 B = one 32x32 chunk
+        }
+        f32x4 pre[8];
+        auto fetch = [&](int r0) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) pre[q] = *(const f32x4*)(src[q] + (int64_t)r0 * PB);
+        };
+        fetch(0);
+        for (int r0 = 0; r0 < m_pad; r0 += 32) {
+            __syncthreads();  // previous chunk fully consumed
+#pragma unroll
+            for (int q = 0; q < 8; ++q) *(f32x4*)(&stage[q][tid * 4]) = pre[q];
+            __syncthreads();
+            if (r0 + 32 < m_pad) fetch(r0 + 32);
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
                 const float bf = stage[4 + w][u * 64 + lane];
