@@ -900,6 +900,8 @@ __global__ __launch_bounds__(256) void fullcheck_kernel(const float* __restrict_
                                                         int m_pad, int n_pad, const float* __restrict__ dn, float tol, int kb,
                                                         unsigned char* __restrict__ pflag, unsigned* __restrict__ maxoff_bits,
                                                         const int* __restrict__ done) {
+    // (An XCD-aware tile order — the workgroups of one XCD walking a contiguous run of tiles — was measured SLOWER: 66.8 vs 55.6 ms for
+    // the three snapshots of 32 problems; the plain order stays.)
     const int ig = blockIdx.x, jg = blockIdx.y, b = blockIdx.z;
     if (ig > jg || done[b]) return;
     ASVD_KERNEL_ACQUIRE();
