@@ -407,13 +407,19 @@ __device__ __forceinline__ void evd_body(const BlockCtx& ctx, float* __restrict_
             dB = v3.Gd32 + ((int64_t)b * v3.nbpan + J) * 1024;
             // cross block = summed tile [0,2] (tile 0) or [1,3] (tile 3)
             const int tile = sp ? 3 : 0;
+            // partials outermost: the four loads of a partial are independent and several partials are in flight (the sum of an element
+            // still runs over the partials in ascending order).  With the loop nest the other way round every element waited for its
+            // partials one L2 round trip at a time: 49 -> 69 ms of solves per batch-1 SVD between 2 and 16 partials.
+            float v4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 4
+            for (int s2 = 0; s2 < v3.nsplit6; ++s2)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v4[q] += gx[(int64_t)s2 * 6144 + tile * 1024 + tid + 256 * q];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int e = tid + 256 * q, i = e >> 5, j = e & 31;
-                float v = 0.0f;
-                for (int s2 = 0; s2 < v3.nsplit6; ++s2) v += gx[(int64_t)s2 * 6144 + tile * 1024 + e];
-                G[i * PW + pcol(32 + j)] = v;
-                G[(32 + j) * PW + pcol(i)] = v;
+                G[i * PW + pcol(32 + j)] = v4[q];
+                G[(32 + j) * PW + pcol(i)] = v4[q];
             }
         } else {
             dA = v3.D0 + (slot * 4 + ba) * 1024;
@@ -432,20 +438,30 @@ __device__ __forceinline__ void evd_body(const BlockCtx& ctx, float* __restrict_
                 QBh[e] = qb[k * PW + 32 + i];
             }
             // M blocks from the summed tiles: [0,1] = tile 4, [0,3] = tile 1, [2,1] = tile 2 ^T, [2,3] = tile 5
+            for (int qg = 0; qg < 4; ++qg) {  // four elements at a time (register budget of 4 workgroups per CU), partials outermost as above
+                int off4[4];
+                float v4[4];
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int e = tid + 256 * (4 * qg + q4), k = e >> 6, i = e & 63;  // MMt[k][i]
+                    // sp 0: MMt[k][i] = M[i][k] (i: rows = blocks 0,2; k: columns = blocks 1,3);  sp 1: MMt[k][i] = M[k][i]
+                    const int mr = sp ? k : i, mc = sp ? i : k;
+                    const int rb = mr >> 5, cb = mc >> 5, ri = mr & 31, ci = mc & 31;
+                    if (rb == 0 && cb == 0) off4[q4] = 4 * 1024 + ri * 32 + ci;
+                    else if (rb == 0) off4[q4] = 1 * 1024 + ri * 32 + ci;
+                    else if (cb == 0) off4[q4] = 2 * 1024 + ci * 32 + ri;  // [2,1] = [1,2]^T
+                    else off4[q4] = 5 * 1024 + ri * 32 + ci;
+                    v4[q4] = 0.0f;
+                }
 #pragma unroll 4
-            for (int q = 0; q < 16; ++q) {
-                const int e = tid + 256 * q, k = e >> 6, i = e & 63;  // MMt[k][i]
-                // sp 0: MMt[k][i] = M[i][k] (i: rows = blocks 0,2; k: columns = blocks 1,3);  sp 1: MMt[k][i] = M[k][i]
-                const int mr = sp ? k : i, mc = sp ? i : k;
-                const int rb = mr >> 5, cb = mc >> 5, ri = mr & 31, ci = mc & 31;
-                int off;
-                if (rb == 0 && cb == 0) off = 4 * 1024 + ri * 32 + ci;
-                else if (rb == 0) off = 1 * 1024 + ri * 32 + ci;
-                else if (cb == 0) off = 2 * 1024 + ci * 32 + ri;  // [2,1] = [1,2]^T
-                else off = 5 * 1024 + ri * 32 + ci;
-                float v = 0.0f;
-                for (int s2 = 0; s2 < v3.nsplit6; ++s2) v += gx[(int64_t)s2 * 6144 + off];
-                MMt[k * PW + i] = v;
+                for (int s2 = 0; s2 < v3.nsplit6; ++s2)
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) v4[q4] += gx[(int64_t)s2 * 6144 + off4[q4]];
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int e = tid + 256 * (4 * qg + q4);
+                    MMt[(e >> 6) * PW + (e & 63)] = v4[q4];
+                }
             }
             __syncthreads();
             const int hh = lane >> 5, cc = lane & 31;
@@ -1940,7 +1956,9 @@ int make_plan(int batch, int64_t m, int64_t n, int want_u, int want_vv, Plan& p)
         // measured (16 x 4096^2): 2 chunks (512 workgroups) beat 4 and 8 — longer streams per workgroup, fewer partial tiles for the solves to sum
         const int64_t quads = std::max<int64_t>(1, pw2 / 4) * batch;
         // (and 1 chunk = exactly one workgroup per CU beats 2 once the quads alone fill the chip: 170.7 vs 174.0 ms per step, solves 97 vs 100)
-        int64_t nq = std::max<int64_t>(1, std::min<int64_t>(quads >= 256 ? 1 : ceil_div64(512, quads), std::max<int64_t>(1, tiles / 8)));
+        // small batches: one round of 256 workgroups too (batch 4: 43.7 ms of supgram per step with 4 chunks, 47.3 with 8, 52.8 with 16);
+        // the solves sum the partial tiles with independent loads, so their cost no longer grows with the chunk count
+        int64_t nq = std::max<int64_t>(1, std::min<int64_t>(ceil_div64(256, quads), std::max<int64_t>(1, tiles / 8)));
         if (getenv("ASVD_SUPGRAM_CHUNKS")) nq = std::max<int64_t>(1, std::min<int64_t>(atoi(getenv("ASVD_SUPGRAM_CHUNKS")), tiles));
         p.rows_per_wg_q = (int)(ceil_div64(tiles, nq) * 32);
         p.nchunks_q = (int)ceil_div64(p.R_upd, p.rows_per_wg_q);
