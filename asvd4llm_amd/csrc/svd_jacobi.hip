@@ -58,12 +58,32 @@ __device__ __forceinline__ void rr_pair(int nb, int step, int k, int& I, int& J)
 // P-1 super-steps with many empty slots (13B: 80 super-panels -> 127 steps, 37 % empty), the tournament ns-1 full ones.  Pairs with
 // T >= ns (padding / the bye) are skipped by the callers.  `step` counts from 0.
 __constant__ int c_super_order = 1;
+// c_super_order = 2: GROUPED schedule for counts that are a multiple of 16 but not a power of two: XOR (d = 1..15) inside groups of 16
+// super-panels, then the group pairs of a round-robin tournament over the groups, each for the 16 offsets s (A_i <-> B_{i ^ s}): the
+// nearest-neighbour-first order of the XOR schedule inside a group and inside a group pair, and 15 + rounds * 16 super-steps with
+// (almost) every slot filled instead of a padded XOR schedule.  c_gpair[round][m] = {gA, gB} (gA < gB), c_gm = pairs per round.
+__constant__ int c_gpair[8][4][2];
+__constant__ int c_gm = 0;
 __device__ __forceinline__ void super_pair(int ns, int step, int k, int& S, int& T) {
-    if (c_super_order) {
+    if (c_super_order == 1) {
         const int d = step + 1;
         const int h = 31 - __clz(d);
         S = ((k >> h) << (h + 1)) | (k & ((1 << h) - 1));
         T = S ^ d;
+        return;
+    }
+    if (c_super_order == 2) {
+        if (step < 15) {
+            if (k >= ns / 2) { S = ns; T = ns; return; }
+            const int d = step + 1, h = 31 - __clz(d), g = k >> 3, kk = k & 7;
+            S = 16 * g + (((kk >> h) << (h + 1)) | (kk & ((1 << h) - 1)));
+            T = S ^ d;
+            return;
+        }
+        const int r = (step - 15) >> 4, sft = (step - 15) & 15, m = k >> 4, i = k & 15;
+        if (m >= c_gm) { S = ns; T = ns; return; }
+        S = 16 * c_gpair[r][m][0] + i;
+        T = 16 * c_gpair[r][m][1] + (i ^ sft);
         return;
     }
     const int n = ns + (ns & 1);  // even player count; player n-1 is the bye when ns is odd
@@ -1996,6 +2016,13 @@ static bool super_rr_for(const Plan& p) {
     const char* e = getenv("ASVD_SUPER_RR");
     return e && atoi(e) == 1;
 }
+// grouped schedule (super_pair, c_super_order = 2): ns a multiple of 16, not a power of two, at most 8 groups
+static bool super_grouped_for(const Plan& p) {
+    if (!p.two || (p.ns & (p.ns - 1)) == 0 || (p.ns % 16) || p.ns / 16 > 8 || super_rr_for(p)) return false;
+    const char* e = getenv("ASVD_SUPER_GROUPED");  // default on; =0 restores the padded XOR schedule
+    return !(e && atoi(e) == 0);
+}
+static int super_grouped_rounds(const Plan& p) { const int ng = p.ns / 16; return (ng & 1) ? ng : ng - 1; }
 
 // ---- optional per-class timing with HIP events on the call's stream ------------------------------
 // profiling state is per host thread: concurrent calls from different threads (on their own streams and workspaces) do not share it
@@ -2173,8 +2200,28 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
         ASVD_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_pair_order), &order, sizeof(int), 0, hipMemcpyHostToDevice));
         const int fence = stream_groups_for(batch) > 1 ? 1 : 0;
         ASVD_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_fence), &fence, sizeof(int), 0, hipMemcpyHostToDevice));
-        const int sup = super_rr_for(p) ? 0 : 1;
+        const int sup = super_grouped_for(p) ? 2 : (super_rr_for(p) ? 0 : 1);
         ASVD_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_super_order), &sup, sizeof(int), 0, hipMemcpyHostToDevice));
+        if (sup == 2) {  // group pairs of every round: circle method over the groups (+ a bye when their number is odd)
+            const int ng = p.ns / 16, n = ng + (ng & 1), gm = ng / 2;
+            int tab[8][4][2];
+            std::memset(tab, 0, sizeof(tab));
+            for (int r = 0; r < n - 1; ++r) {
+                int m = 0;
+                for (int k = 0; k < n / 2; ++k) {
+                    const int a = (k == 0) ? 0 : 1 + (k - 1 + r) % (n - 1);
+                    const int pb = n - 1 - k;
+                    const int bb = 1 + (pb - 1 + r) % (n - 1);
+                    if (a >= ng || bb >= ng) continue;  // the bye
+                    tab[r][m][0] = std::min(a, bb);
+                    tab[r][m][1] = std::max(a, bb);
+                    ++m;
+                }
+                for (; m < 4; ++m) { tab[r][m][0] = 0; tab[r][m][1] = 0; }
+            }
+            ASVD_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_gpair), tab, sizeof(tab), 0, hipMemcpyHostToDevice));
+            ASVD_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_gm), &gm, sizeof(int), 0, hipMemcpyHostToDevice));
+        }
         const int evp = getenv("ASVD_EVD_PAIRS") ? std::max(1, std::min(64, atoi(getenv("ASVD_EVD_PAIRS")))) : PW / 2;
         ASVD_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_evd_pairs), &evp, sizeof(int), 0, hipMemcpyHostToDevice));
     }
@@ -2436,7 +2483,7 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
             }
         }
         // pipelined two-level sweep (twolevel.h "dual launches"): two halves of the batch, two phases apart, on ONE stream
-        const bool piped = two_now && ngroups == 1 && batch >= 2 && split_piped && !super_rr_for(p);
+        const bool piped = two_now && ngroups == 1 && batch >= 2 && split_piped && !super_rr_for(p) && !super_grouped_for(p);
         if (piped) {
             const int nsuper = 2 * p.npairs_s - 1;
             const int dup2 = std::min(nsuper, getenv("ASVD_DUP2") ? atoi(getenv("ASVD_DUP2")) : 0);
@@ -2504,8 +2551,9 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
                 launch_u(0, D);
             }
         } else if (two_now) {
-            const bool super_rr = super_rr_for(p);
-            const int nsuper = super_rr ? (p.ns + (p.ns & 1)) - 1 : 2 * p.npairs_s - 1;
+            const bool super_grp = super_grouped_for(p);
+            const bool super_rr = super_rr_for(p) || super_grp;  // either way: no XOR structure at the super level (no fused update + Gram)
+            const int nsuper = super_grp ? 15 + 16 * super_grouped_rounds(p) : (super_rr ? (p.ns + (p.ns & 1)) - 1 : 2 * p.npairs_s - 1);
             const bool split_bf16 = split_on;
             const bool gram_split = split_on && getenv("ASVD_GRAM_SPLIT") && atoi(getenv("ASVD_GRAM_SPLIT")) == 1;
             // local super-levels D = 1..L run twice at the start of the sweep (the two-level form of ASVD_DUP; ASVD_DUP2=L)
