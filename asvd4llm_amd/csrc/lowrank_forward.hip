@@ -157,26 +157,33 @@ __global__ __launch_bounds__(256, 1) void lowrank_forward_kernel(const uint16_t*
 // interleaved over all waves of the grid.  No MFMA: at <= 4 tokens the tile would be >= 87 % padding and the op is a pure weight stream.
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
+constexpr int GV_MAXC = 22;  // chunks of 64 uint4 (512 halfs) per weight row: K, rp <= 11264
+
+// all 16-byte pieces of weight row `row` (klen8 of them) into registers: the whole row in flight at once
+__device__ __forceinline__ void gemv_load(uint4 (&wv)[GV_MAXC], const uint4* __restrict__ row, int klen8, int lane) {
+    const int nch = (klen8 + 63) / 64;
+#pragma unroll
+    for (int c = 0; c < GV_MAXC; ++c)
+        if (c < nch) {
+            const int k8 = c * 64 + lane;
+            wv[c] = k8 < klen8 ? row[k8] : make_uint4(0, 0, 0, 0);
+        }
+}
+
+// rows gw, gw + nw, ... of W against the TT activation rows in LDS.  The FIRST row of the wave arrives already loaded in wv: the caller
+// issues it before it waits for the activations (x -> LDS, or the grid barrier and z -> LDS), so that wait overlaps the weight stream.
 template <int TT, bool ZOUT>
-__device__ __forceinline__ void gemv_rows(const uint4* __restrict__ W4, int64_t ldw4 /* row stride in uint4 */, int rows, int klen8 /* k length in uint4 */,
-                                          const uint4* __restrict__ xs /* LDS: [TT][klen8] */, int gw, int nw, int lane,
-                                          uint16_t* __restrict__ out, int64_t ldo, const uint16_t* __restrict__ bias, int T) {
-    constexpr int MAXC = 22;  // chunks of 64 uint4 (512 halfs) per row: K <= 11264
+__device__ __forceinline__ void gemv_rows(uint4 (&wv)[GV_MAXC], const uint4* __restrict__ W4, int64_t ldw4 /* row stride in uint4 */, int rows,
+                                          int klen8 /* k length in uint4 */, const uint4* __restrict__ xs /* LDS: [TT][klen8] */, int gw, int nw,
+                                          int lane, uint16_t* __restrict__ out, int64_t ldo, const uint16_t* __restrict__ bias, int T) {
     const int nch = (klen8 + 63) / 64;
     for (int j = gw; j < rows; j += nw) {
-        const uint4* row = W4 + (int64_t)j * ldw4;
-        uint4 wv[MAXC];
-#pragma unroll
-        for (int c = 0; c < MAXC; ++c)
-            if (c < nch) {
-                const int k8 = c * 64 + lane;
-                wv[c] = k8 < klen8 ? row[k8] : make_uint4(0, 0, 0, 0);
-            }
+        if (j != gw) gemv_load(wv, W4 + (int64_t)j * ldw4, klen8, lane);
         float acc[TT];
 #pragma unroll
         for (int t = 0; t < TT; ++t) acc[t] = 0.f;
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c)
+        for (int c = 0; c < GV_MAXC; ++c)
             if (c < nch) {
                 const int k8 = min(c * 64 + lane, klen8 - 1);  // masked lanes hold zeros in wv: any valid x slot will do
 #pragma unroll
@@ -209,22 +216,25 @@ __global__ __launch_bounds__(512, 1) void lowrank_gemv_kernel(const uint16_t* __
     extern __shared__ __attribute__((aligned(16))) uint4 gv_smem[];  // [TT][max(K, rp) / 8]
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int G = gridDim.x, gw = blockIdx.x * 8 + wave, nw = G * 8;
+    uint4 wv[GV_MAXC];
     // ---- phase 1: z[t, j] = fp16( x[t, :] . B[j, :] ), j < rp (padded ranks have zero rows in Bp and give exact zeros) ----
-    const int k8 = K / 8;
+    const int k8 = K / 8, r8 = rp / 8;
+    if (gw < rp) gemv_load(wv, (const uint4*)Bp + (int64_t)gw * k8, k8, lane);  // weight row first, activations second
     for (int e = tid; e < TT * k8; e += 512) {
         const int t = e / k8, kk = e - t * k8;
         gv_smem[e] = t < T ? ((const uint4*)x)[(int64_t)t * k8 + kk] : make_uint4(0, 0, 0, 0);
     }
     __syncthreads();
-    gemv_rows<TT, true>((const uint4*)Bp, k8, rp, k8, gv_smem, gw, nw, lane, z, rp, nullptr, TT);
+    gemv_rows<TT, true>(wv, (const uint4*)Bp, k8, rp, k8, gv_smem, gw, nw, lane, z, rp, nullptr, TT);
 
+    // the first A row of this wave does not depend on phase 1: it streams in while the grid waits at the barrier
+    if (gw < N) gemv_load(wv, (const uint4*)Ap + (int64_t)gw * r8, r8, lane);
     grid_barrier(bar, (unsigned)G);
 
     // ---- phase 2: y[t, n] = fp16( z[t, :] . A[n, :] + bias[n] ) ----
-    const int r8 = rp / 8;
     for (int e = tid; e < TT * r8; e += 512) gv_smem[e] = z_load16((const uint4*)z + e);
     __syncthreads();
-    gemv_rows<TT, false>((const uint4*)Ap, r8, N, r8, gv_smem, gw, nw, lane, y, N, bias, T);
+    gemv_rows<TT, false>(wv, (const uint4*)Ap, r8, N, r8, gv_smem, gw, nw, lane, y, N, bias, T);
 }
 
 }  // namespace
