@@ -63,6 +63,9 @@ class AsvdHipError(RuntimeError):
     pass
 
 
+_device_seen = False
+
+
 def load(require_device=False):
     """dlopen the in-tree library and attach prototypes.  Raises AsvdHipError when it is absent (run
     `python -m asvd4llm_amd.build` / `__graft_entry__.build()`), or when require_device and no gfx950 GPU is visible."""
@@ -80,8 +83,11 @@ def load(require_device=False):
             fn.restype = res
             fn.argtypes = args
         _lib = lib
-    if require_device and _lib.asvd_device_count() <= 0:
-        raise AsvdHipError("libasvd_hip.so loaded but no gfx950 device is visible; the ASVD hot path has no CPU fallback")
+    global _device_seen
+    if require_device and not _device_seen:  # asked once per process: a device does not go away, and hot wrappers call this per launch
+        if _lib.asvd_device_count() <= 0:
+            raise AsvdHipError("libasvd_hip.so loaded but no gfx950 device is visible; the ASVD hot path has no CPU fallback")
+        _device_seen = True
     return _lib
 
 

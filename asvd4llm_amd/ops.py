@@ -27,6 +27,23 @@ def _stream(t):
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
+class _NoCtx:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+_NOCTX = _NoCtx()
+
+
+def _on(device):
+    """context that makes `device` current — nothing at all when it already is (torch.cuda.device costs several microseconds per call,
+    which is most of a decode-sized launch)"""
+    return _NOCTX if torch.cuda.current_device() == device.index else torch.cuda.device(device)
+
+
 def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
@@ -49,7 +66,7 @@ def absstat_accum(x2d, acc, method):
     nb = ctypes.c_size_t()
     L.check(lib.asvd_absstat_worksize(rows, cols, ctypes.byref(nb)), "asvd_absstat_worksize")
     work = _work(nb.value, x2d.device)
-    with torch.cuda.device(x2d.device):
+    with _on(x2d.device):
         L.check(lib.asvd_absstat_accum(_ptr(x2d), _dt(x2d), rows, cols, x2d.stride(0), _ptr(acc), _dt(acc), mode, _ptr(work),
                                        work.numel(), _stream(x2d)), "asvd_absstat_accum")
     return acc
@@ -69,7 +86,7 @@ def absstat_partial(x2d, method):
     nb = ctypes.c_size_t()
     L.check(lib.asvd_absstat_worksize(rows, cols, ctypes.byref(nb)), "asvd_absstat_worksize")
     work = _work(nb.value, x2d.device)
-    with torch.cuda.device(x2d.device):
+    with _on(x2d.device):
         L.check(lib.asvd_absstat_partial(_ptr(x2d), _dt(x2d), rows, cols, x2d.stride(0), _stat_mode(method), _ptr(work), work.numel(), _stream(x2d)),
                 "asvd_absstat_partial")
     return work
@@ -79,7 +96,7 @@ def absstat_finalize(work, rows, cols, acc, method):
     lib = L.load(True)
     _dev(acc, "acc")
     assert acc.is_contiguous() and acc.numel() == cols
-    with torch.cuda.device(acc.device):
+    with _on(acc.device):
         L.check(lib.asvd_absstat_finalize(_ptr(work), work.numel(), rows, cols, _ptr(acc), _dt(acc), _stat_mode(method), _stream(acc)),
                 "asvd_absstat_finalize")
     return acc
@@ -298,7 +315,7 @@ def lowrank_forward(x2d, Ap, Bp, bias, work):
     N, rp = Ap.shape
     assert x2d.dtype == torch.float16 and x2d.is_contiguous() and Bp.shape == (rp, K) and 1 <= T <= LOWRANK_MAX_TOKENS
     y = torch.empty((T, N), dtype=torch.float16, device=x2d.device)
-    with torch.cuda.device(x2d.device):
+    with _on(x2d.device):
         L.check(lib.asvd_lowrank_forward_f16(_ptr(x2d), T, _ptr(Bp), _ptr(Ap), _ptr(bias), N, K, rp, _ptr(y), _ptr(work), work.numel(),
                                              _stream(x2d)), "asvd_lowrank_forward_f16")
     return y
