@@ -2016,6 +2016,28 @@ static bool super_rr_for(const Plan& p) {
     const char* e = getenv("ASVD_SUPER_RR");
     return e && atoi(e) == 1;
 }
+// group pairs of every round of the grouped schedule: circle method over the ns / 16 groups (+ a bye when their number is odd)
+static hipError_t set_group_table(int ns) {
+    const int ng = ns / 16, n = ng + (ng & 1), gm = ng / 2;
+    int tab[8][4][2];
+    std::memset(tab, 0, sizeof(tab));
+    for (int r = 0; r < n - 1; ++r) {
+        int m = 0;
+        for (int k = 0; k < n / 2; ++k) {
+            const int a = (k == 0) ? 0 : 1 + (k - 1 + r) % (n - 1);
+            const int pb = n - 1 - k;
+            const int bb = 1 + (pb - 1 + r) % (n - 1);
+            if (a >= ng || bb >= ng) continue;  // the bye
+            tab[r][m][0] = std::min(a, bb);
+            tab[r][m][1] = std::max(a, bb);
+            ++m;
+        }
+    }
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_gpair), tab, sizeof(tab), 0, hipMemcpyHostToDevice);
+    if (e != hipSuccess) return e;
+    return hipMemcpyToSymbol(HIP_SYMBOL(c_gm), &gm, sizeof(int), 0, hipMemcpyHostToDevice);
+}
+
 // grouped schedule (super_pair, c_super_order = 2): ns a multiple of 16, not a power of two, at most 8 groups
 static bool super_grouped_for(const Plan& p) {
     if (!p.two || (p.ns & (p.ns - 1)) == 0 || (p.ns % 16) || p.ns / 16 > 8 || super_rr_for(p)) return false;
@@ -2202,26 +2224,7 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
         ASVD_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_fence), &fence, sizeof(int), 0, hipMemcpyHostToDevice));
         const int sup = super_grouped_for(p) ? 2 : (super_rr_for(p) ? 0 : 1);
         ASVD_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_super_order), &sup, sizeof(int), 0, hipMemcpyHostToDevice));
-        if (sup == 2) {  // group pairs of every round: circle method over the groups (+ a bye when their number is odd)
-            const int ng = p.ns / 16, n = ng + (ng & 1), gm = ng / 2;
-            int tab[8][4][2];
-            std::memset(tab, 0, sizeof(tab));
-            for (int r = 0; r < n - 1; ++r) {
-                int m = 0;
-                for (int k = 0; k < n / 2; ++k) {
-                    const int a = (k == 0) ? 0 : 1 + (k - 1 + r) % (n - 1);
-                    const int pb = n - 1 - k;
-                    const int bb = 1 + (pb - 1 + r) % (n - 1);
-                    if (a >= ng || bb >= ng) continue;  // the bye
-                    tab[r][m][0] = std::min(a, bb);
-                    tab[r][m][1] = std::max(a, bb);
-                    ++m;
-                }
-                for (; m < 4; ++m) { tab[r][m][0] = 0; tab[r][m][1] = 0; }
-            }
-            ASVD_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_gpair), tab, sizeof(tab), 0, hipMemcpyHostToDevice));
-            ASVD_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_gm), &gm, sizeof(int), 0, hipMemcpyHostToDevice));
-        }
+        if (sup == 2) ASVD_HIP_CHECK(set_group_table(p.ns));
         const int evp = getenv("ASVD_EVD_PAIRS") ? std::max(1, std::min(64, atoi(getenv("ASVD_EVD_PAIRS")))) : PW / 2;
         ASVD_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_evd_pairs), &evp, sizeof(int), 0, hipMemcpyHostToDevice));
     }
@@ -2957,6 +2960,42 @@ int asvd_test_supdate(int split, float* X, int64_t panel_stride, int64_t batch_s
     else
         supdate_kernel<<<dim3(nchunks, npairs, batch), 256, 0, st>>>(X, panel_stride, batch_stride, ns, D, R, rows_per_wg, Qfin, subact, done, nupd);
     ASVD_HIP_CHECK(hipGetLastError());
+    return ASVD_OK;
+}
+
+// Test hook: the super-panel pair schedule itself.  out[step * npairs + k] = (S << 16) | T of slot k of super-step `step`, or -1 for an empty
+// slot, for the order the library would pick for `ns` super-panels (1 XOR, 2 grouped; see super_pair).  Returns the number of super-steps
+// through *nsteps_out.  tests/test_gpu_twolevel.py checks that every pair appears exactly once and that the pairs of a step are disjoint.
+}  // extern "C"
+namespace {
+__global__ void super_schedule_kernel(int ns, int nsteps, int npairs, int* __restrict__ out) {
+    const int step = blockIdx.x, k = threadIdx.x;
+    if (k >= npairs) return;
+    int S, T;
+    super_pair(ns, step, k, S, T);
+    out[step * npairs + k] = (S < ns && T < ns) ? ((S << 16) | T) : -1;
+}
+}  // namespace
+extern "C" {
+int asvd_test_super_schedule(int ns, int grouped, int* out_dev, int out_capacity, int* nsteps_out, int* npairs_out) {
+    if (ns < 2 || ns > 1024 || !out_dev || !nsteps_out || !npairs_out) return ASVD_E_BADARG;
+    int pw2 = 2;
+    while (pw2 < ns) pw2 <<= 1;
+    const int npairs = pw2 / 2;
+    const bool grp = grouped && (ns % 16) == 0 && (ns & (ns - 1)) != 0 && ns / 16 <= 8;
+    const int ng = ns / 16;
+    const int nsteps = grp ? 15 + 16 * ((ng & 1) ? ng : ng - 1) : pw2 - 1;
+    *nsteps_out = nsteps;
+    *npairs_out = npairs;
+    if ((int64_t)nsteps * npairs > out_capacity || npairs > 1024) return ASVD_E_WORKSPACE;
+    const int sup = grp ? 2 : 1;
+    ASVD_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_super_order), &sup, sizeof(int), 0, hipMemcpyHostToDevice));
+    if (grp) ASVD_HIP_CHECK(set_group_table(ns));
+    super_schedule_kernel<<<nsteps, npairs>>>(ns, nsteps, npairs, out_dev);
+    ASVD_HIP_CHECK(hipGetLastError());
+    ASVD_HIP_CHECK(hipDeviceSynchronize());
+    const int one = 1;
+    ASVD_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_super_order), &one, sizeof(int), 0, hipMemcpyHostToDevice));
     return ASVD_OK;
 }
 

@@ -251,6 +251,10 @@ int asvd_test_supdate(int split, float* X, int64_t panel_stride, int64_t batch_s
 int asvd_test_supgram(float* X, int64_t panel_stride, int64_t batch_stride, int ns, int D, int E, int R, int m_pad, int rows_per_wg,
                       const float* Qfin, const int* subact, float* Gx, const int* done, int* nupd, int nchunks, int npairs, int batch,
                       void* stream);
+/* Test hook: the super-panel pair schedule of the two-level sweeps for `ns` super-panels (grouped != 0: the grouped order where it applies,
+ * else XOR).  out_dev: device int[out_capacity] >= nsteps * npairs; out[step * npairs + k] = (S << 16) | T or -1 (empty slot).
+ * tests/test_gpu_twolevel.py only. */
+int asvd_test_super_schedule(int ns, int grouped, int* out_dev, int out_capacity, int* nsteps_out, int* npairs_out);
 /* counts_host: long long[3] = {32-column panel-pair visits (one 64x64 eigen-solve each), pairs actually rotated, 128-column
  * super-pairs updated by the two-level sweeps (one 128-wide update pass over the rows each)} summed over the sweeps and problems of
  * the last profiled call: the algorithmic byte counts of the streaming kernels follow from these. */

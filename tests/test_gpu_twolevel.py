@@ -139,3 +139,31 @@ def test_supgram_gram_rows_stop_at_m_pad(gpu):
     """rows beyond m_pad (the accumulated right factor) are rotated but do not enter the Gram tiles"""
     err_x, err_g = _run_supgram(gpu, batch=1, D=2, E=3, ns=8, R=512, m_pad=256, rows_per_wg=128)
     assert err_x <= 2e-6 and err_g <= 2e-6, (err_x, err_g)
+
+
+@pytest.mark.parametrize("ns,grouped", [(64, 1), (80, 1), (80, 0), (48, 1), (96, 1), (112, 1), (12, 1), (20, 1)])
+def test_super_panel_schedule_meets_every_pair_once(gpu, ns, grouped):
+    """the pair schedule of the two-level sweeps (XOR, padded XOR, grouped): the pairs of a super-step are disjoint and every pair of
+    super-panels meets exactly once per sweep; the grouped order needs 15 + 16 * rounds steps (95 for the 13B shapes' 80 super-panels)"""
+    from asvd4llm_amd import _lib as L
+    lib = L.load(True)
+    out = torch.full((256 * 512,), -7, dtype=torch.int32, device=gpu)
+    nsteps, npairs = ctypes.c_int(), ctypes.c_int()
+    rc = lib.asvd_test_super_schedule(ns, grouped, ctypes.c_void_p(out.data_ptr()), out.numel(), ctypes.byref(nsteps), ctypes.byref(npairs))
+    assert rc == 0
+    tab = out[: nsteps.value * npairs.value].view(nsteps.value, npairs.value).cpu().tolist()
+    seen = {}
+    for row in tab:
+        used = set()
+        for code in row:
+            if code < 0:
+                continue
+            S, T = code >> 16, code & 0xFFFF
+            assert S < T < ns and S not in used and T not in used
+            used |= {S, T}
+            seen[(S, T)] = seen.get((S, T), 0) + 1
+    assert len(seen) == ns * (ns - 1) // 2 and set(seen.values()) == {1}
+    if grouped and ns == 80:
+        assert nsteps.value == 95
+    if not grouped and ns == 80:
+        assert nsteps.value == 127
