@@ -2039,8 +2039,15 @@ static hipError_t set_group_table(int ns) {
 }
 
 // grouped schedule (super_pair, c_super_order = 2): ns a multiple of 16, not a power of two, at most 8 groups
+static bool grouped_applies(int ns) {  // a multiple of 16, not a power of two, at most 8 groups, and fewer super-steps than the padded XOR schedule
+    if ((ns & (ns - 1)) == 0 || (ns % 16) || ns / 16 > 8) return false;
+    int pw2 = 2;
+    while (pw2 < ns) pw2 <<= 1;
+    const int ng = ns / 16;
+    return 15 + 16 * ((ng & 1) ? ng : ng - 1) < pw2 - 1;
+}
 static bool super_grouped_for(const Plan& p) {
-    if (!p.two || (p.ns & (p.ns - 1)) == 0 || (p.ns % 16) || p.ns / 16 > 8 || super_rr_for(p)) return false;
+    if (!p.two || !grouped_applies(p.ns) || super_rr_for(p)) return false;
     const char* e = getenv("ASVD_SUPER_GROUPED");  // default on; =0 restores the padded XOR schedule
     return !(e && atoi(e) == 0);
 }
@@ -2982,7 +2989,7 @@ int asvd_test_super_schedule(int ns, int grouped, int* out_dev, int out_capacity
     int pw2 = 2;
     while (pw2 < ns) pw2 <<= 1;
     const int npairs = pw2 / 2;
-    const bool grp = grouped && (ns % 16) == 0 && (ns & (ns - 1)) != 0 && ns / 16 <= 8;
+    const bool grp = grouped && grouped_applies(ns);
     const int ng = ns / 16;
     const int nsteps = grp ? 15 + 16 * ((ng & 1) ? ng : ng - 1) : pw2 - 1;
     *nsteps_out = nsteps;
