@@ -35,8 +35,8 @@ def main(args):
     if args.dist:
         import torch.distributed as dist
         local_rank = int(os.environ.get("LOCAL_RANK", 0))
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl")
+        torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))  # gloo: several ranks may share a GPU
+        dist.init_process_group(args.dist_backend)  # "nccl" = RCCL over xGMI; "gloo": CPU rendezvous (several ranks on one GPU, tests)
 
     from asvd4llm_amd.act_aware_utils import calib_fisher_info, calib_input_distribution
     from asvd4llm_amd.binary_search import binary_search_truncation_rank
@@ -55,7 +55,7 @@ def main(args):
         if "fisher" in args.scaling_method:
             calib_fisher_info(model, calib_loader, args.use_cache)
         if "abs" in args.scaling_method:
-            calib_input_distribution(model, calib_loader, args.scaling_method, args.use_cache)
+            calib_input_distribution(model, calib_loader, args.scaling_method, args.use_cache, shard_samples=args.shard_calib)
         if args.sensitivity_metric == "ppl":
             sensitivity = calib_sensitivity_ppl(model, calib_loader, args, args.use_cache)
         elif args.sensitivity_metric == "stable_rank":
@@ -132,6 +132,11 @@ def build_parser():
                         help="--dist: after the sharded decomposition send every layer's A/B factors to rank 0 (point-to-point), to all ranks "
                              "(broadcast), or nowhere")
     parser.add_argument("--dist", action="store_true", help="torchrun launch: one rank per GPU, layers sharded, RCCL all-gather of sensitivities")
+    parser.add_argument("--dist_backend", type=str, default="nccl", choices=["nccl", "gloo"],
+                        help="--dist: process-group backend; nccl is RCCL over xGMI (one rank per GPU), gloo lets several ranks share one GPU")
+    parser.add_argument("--shard_calib", action="store_true",
+                        help="--dist: every rank runs the calibration hook pass over its own samples and the [C] accumulators are all-reduced "
+                             "(default: replicated pass, identical statistics without a collective)")
     return parser
 
 

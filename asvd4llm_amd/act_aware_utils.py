@@ -48,8 +48,30 @@ def _hook_factory(method):
     return hook
 
 
+def _allreduce_statistics(model, method):
+    """--shard_calib: combine the per-rank accumulators (SURVEY.md 8e "optional"): sum for abs_mean, max for abs_max — ONE collective
+    over a flat buffer of all [C] vectors.  The sum runs in fp32 and is rounded once to the activation dtype (the replicated pass adds
+    batch by batch in that dtype: equal up to that rounding, which is why this is opt-in)."""
+    import torch.distributed as dist
+    from . import parallel
+    mods = [m for _, m in model.named_modules() if isinstance(m, nn.Linear) and torch.is_tensor(m.scaling_diag_matrix)]
+    if not mods:
+        return
+    dev = parallel._comm_device()
+    flat = torch.cat([m.scaling_diag_matrix.float().reshape(-1) for m in mods]).to(dev)
+    dist.all_reduce(flat, op=dist.ReduceOp.MAX if "abs_max" in method else dist.ReduceOp.SUM)
+    off = 0
+    for m in mods:
+        n = m.scaling_diag_matrix.numel()
+        m.scaling_diag_matrix = flat[off:off + n].to(m.scaling_diag_matrix.device).to(m.scaling_diag_matrix.dtype)
+        off += n
+
+
 @torch.no_grad()
-def calib_input_distribution(model, calib_loader, method, use_cache=True):
+def calib_input_distribution(model, calib_loader, method, use_cache=True, shard_samples=False):
+    """shard_samples (additive; asvd.py --shard_calib): with torch.distributed initialised, rank r runs the hook pass over the calibration
+    samples i = r (mod world size) only and the accumulators are all-reduced — the default is the replicated pass (bit-identical
+    statistics on every rank, no collective)."""
     model_id = model.config._name_or_path
     cache_file = f"cache/{model_id.replace('/','_')}_calib_input_distribution_{method}.pt"
     if os.path.exists(cache_file) and use_cache:
@@ -67,10 +89,17 @@ def calib_input_distribution(model, calib_loader, method, use_cache=True):
             module.scaling_diag_matrix = 0
             module.register_forward_hook(hook)
 
-    for batch in tqdm(calib_loader):
+    from . import parallel
+    rank, ws = parallel.world()
+    shard = bool(shard_samples) and ws > 1
+    for i, batch in enumerate(tqdm(calib_loader, disable=(rank != 0))):
+        if shard and i % ws != rank:
+            continue
         batch = {k: v.to(model.device) for k, v in batch.items()}
         model(**batch)
         hook.release()
+    if shard:
+        _allreduce_statistics(model, method)
 
     all_scaling_diag_matrix = {}
     for name, module in model.named_modules():

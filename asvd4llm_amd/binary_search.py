@@ -1,14 +1,26 @@
-"""Rank allocation + final decomposition — MI355X implementation of binary_search.py:10-131 behind the same signature.
+"""Rank allocation + final decomposition behind the reference's entry point (binary_search.py:10-131):
 
-`binary_search_truncation_rank(model, sensitivity_dict, calib_loader, args)` mutates the model in place.  The search is
-the reference's (stable sort by -ppl, bisection on the cut index, the last-`mid` slice quirk, identical trace lines); the
-decomposition stage slices the cached exact SVD of each layer (computed once by the sweep, or here on first use) instead
-of re-factorising, and — with torch.distributed initialised and args.shard_decompose (default) — each rank decomposes only
-the layers it owns under the same LPT map as the sweep."""
+    binary_search_truncation_rank(model, sensitivity_dict, calib_loader, args)      # mutates the model in place
+
+What the reference computes — kept, because the fixtures generated from it pin the trace lines and the final ranks:
+  * candidates (layer, ratio, ppl), ratio < 1 unless compressing the kv cache, stably sorted by descending ppl;
+  * a bisection on the cut index `c` of that list: the plan of a cut gives every layer the smallest ratio among its candidates
+    at positions >= c (or the default 1 / 2 when it has none there); the plan's parameter ratio (or, with --ppl_target, the
+    perplexity of the model compressed to the plan) decides the half;
+  * the decomposition uses the plan of the LAST PROBED cut, not of the converged bound (binary_search.py:106).
+
+How it is done here (own design):
+  * `_CutPlans` indexes the sorted list once: per layer the positions of its candidates with the running minimum of their ratios
+    from the back, so the plan of any cut is one bisect per layer — O(#layers log #ratios) per probe instead of a scan of the
+    whole list per probe (1350 entries x 11 probes for Llama-2-7B);
+  * the bisection is a generic `_bisect_cut(n, probe)`; the two targets are two probe closures that also print the trace line;
+  * the decomposition stage slices the cached exact SVD of each layer (computed once by the sweep, or here on first use) instead
+    of re-factorising, and — with torch.distributed initialised and args.shard_decompose (default) — each rank decomposes only
+    the layers it owns under the same LPT map as the sweep, then the factors are exchanged (parallel.exchange_factors)."""
+import bisect
 import time
 
 import torch
-import torch.nn as nn
 from tqdm import tqdm
 
 from . import parallel
@@ -17,139 +29,153 @@ from .modules.svd_linear import SVDLinear
 from .sensitivity import collect_linear_info
 
 
+class _CutPlans:
+    """The sorted candidate list, indexed by layer for suffix minima."""
+
+    def __init__(self, sensitivity, keep_ratio, default_ratio):
+        self.layers = list(sensitivity.keys())  # plan order = insertion order of the sensitivity dict (the parameter sums run in it)
+        self.default = default_ratio
+        cand = [(name, ratio, ppl) for name, per_ratio in sensitivity.items() for ratio, ppl in per_ratio.items() if keep_ratio(ratio)]
+        order = sorted(range(len(cand)), key=lambda i: -cand[i][2])  # stable: ties keep the traversal order
+        self.size = len(order)
+        pos = {name: [] for name in self.layers}
+        for p, i in enumerate(order):
+            pos[cand[i][0]].append((p, cand[i][1]))
+        self._pos, self._sufmin = {}, {}
+        for name, pr in pos.items():  # pr is ascending in position
+            self._pos[name] = [p for p, _ in pr]
+            mins, cur = [], None
+            for _, ratio in reversed(pr):
+                cur = ratio if cur is None else min(cur, ratio)
+                mins.append(cur)
+            self._sufmin[name] = mins[::-1]
+
+    def plan(self, cut):
+        """{layer: smallest candidate ratio at sorted positions >= cut, else the default} in plan order"""
+        out = {}
+        for name in self.layers:
+            j = bisect.bisect_left(self._pos[name], cut)
+            out[name] = min(self.default, self._sufmin[name][j]) if j < len(self._pos[name]) else self.default
+        return out
+
+
+def _bisect_cut(n, probe):
+    """The reference's bisection over cut indices 0 .. n-1: probe(low, mid, high) -> True keeps the lower half.
+    Returns the last probed index (None when n < 2: nothing was probed)."""
+    low, high, last = 0, n - 1, None
+    while low < high:
+        last = (low + high) // 2
+        if probe(low, last, high):
+            high = last
+        else:
+            low = last + 1
+    return last
+
+
+def _plan_params(plan, weights):
+    """(compressed, total) parameter counts of a plan, accumulated layer by layer in plan order (floats: the trace prints them)"""
+    total, compressed = 0, 0
+    for name, ratio in plan.items():
+        n = weights[name]
+        total += n
+        compressed += n * ratio
+    return compressed, total
+
+
 def binary_search_truncation_rank(model, sensitivity_dict, calib_loader, args):
-    module_dict = {name: module for name, module in model.named_modules()}
+    modules = dict(model.named_modules())
     linear_info = collect_linear_info(model)
 
-    if args.compress_kv_cache:
-        ratio_target = args.kv_cache_ratio_target
-        sensitivity_dict = {k: v for k, v in sensitivity_dict.items() if "k_proj" in k or "v_proj" in k}
+    kv = bool(args.compress_kv_cache)
+    if kv:
         assert args.ppl_target < 0, "ppl_target is not supported when compressing kv_cache"
-        default_param_ratio = 2
-    else:
-        ratio_target = args.param_ratio_target
-        default_param_ratio = 1
-
-    print(
-        f"=== {'compress kv_cache' if args.compress_kv_cache else 'compress weight'} target: ppl={args.ppl_target}, ratio_target={ratio_target} ==="
-    )
-
-    sensitivity_list = []
-    for layername, v in sensitivity_dict.items():
-        for param_ratio, ppl in v.items():
-            if not args.compress_kv_cache and param_ratio >= 1:
-                continue  # weights are to be compressed: ratio must be < 1
-            sensitivity_list.append((layername, param_ratio, ppl))
-    sorted_sensitive_list = sorted(sensitivity_list, key=lambda x: -x[2])
-
-    high = len(sorted_sensitive_list) - 1
-    low = 0
+        sensitivity_dict = {k: v for k, v in sensitivity_dict.items() if "k_proj" in k or "v_proj" in k}
+    ratio_target = args.kv_cache_ratio_target if kv else args.param_ratio_target
+    default_ratio = 2 if kv else 1
+    print(f"=== {'compress kv_cache' if kv else 'compress weight'} target: ppl={args.ppl_target}, ratio_target={ratio_target} ===")
     assert args.ppl_target > 0 or ratio_target > 0
 
+    # weights are to be compressed: only ratios < 1 are candidates; the kv-cache sweep keeps all of its 0.1 .. 1.9
+    plans = _CutPlans(sensitivity_dict, (lambda r: True) if kv else (lambda r: r < 1), default_ratio)
+    weights = {name: modules[name].weight.numel() for name in plans.layers}
     rank, ws = parallel.world()
-    input_ids = torch.cat([_["input_ids"] for _ in calib_loader], 0)
-    while low < high:
-        mid = (low + high) // 2
-        layers_min_ratio = {layername: default_param_ratio for layername in sensitivity_dict.keys()}
-        for layername, param_ratio, ppl in sorted_sensitive_list[mid:]:
-            layers_min_ratio[layername] = min(layers_min_ratio[layername], param_ratio)
-        tot_params = 0
-        compress_params = 0
-        if args.ppl_target > 0:
-            assert not args.compress_kv_cache, "ppl_target is not supported when compressing kv_cache now"
-            assert ws == 1, "ppl-target search evaluates the whole model per round: replicas only (SURVEY.md §8e)"
-            for layername, param_ratio in layers_min_ratio.items():
-                raw_linear = module_dict[layername]
-                info = linear_info[raw_linear]
-                svd_linear = SVDLinear.from_linear(
-                    raw_linear,
-                    param_ratio=param_ratio,
-                    alpha=args.alpha,
-                    act_aware=args.act_aware,
-                    sigma_fuse=args.sigma_fuse,
-                    rank_align=args.rank_align,
-                )
-                setattr(info["father"], info["name"], svd_linear)
-                tot_params += raw_linear.weight.numel()
-                compress_params += raw_linear.weight.numel() * param_ratio
+    from_linear_kw = dict(alpha=args.alpha, act_aware=args.act_aware, sigma_fuse=args.sigma_fuse, rank_align=args.rank_align)
+
+    if args.ppl_target > 0:
+        assert ws == 1, "ppl-target search evaluates the whole model per round: replicas only (SURVEY.md §8e)"
+        input_ids = torch.cat([_["input_ids"] for _ in calib_loader], 0)
+
+        def probe(low, mid, high):
+            plan = plans.plan(mid)
+            for name, ratio in plan.items():  # the whole model compressed to this plan (every layer, ratio 1 included)
+                raw = modules[name]
+                info = linear_info[raw]
+                setattr(info["father"], info["name"], SVDLinear.from_linear(raw, param_ratio=ratio, **from_linear_kw))
             ppl = evaluate_perplexity(model, input_ids, args.n_calib_samples)
-            param_ratio = compress_params / tot_params
-            msg = f"low={low} mid={mid}, high={high}, ppl={ppl}, param_ratio={param_ratio}"
-            print(msg)
-            if ppl < args.ppl_target:
-                high = mid
-            else:
-                low = mid + 1
-        else:
-            for layername, param_ratio in layers_min_ratio.items():
-                raw_linear = module_dict[layername]
-                tot_params += raw_linear.weight.numel()
-                compress_params += raw_linear.weight.numel() * param_ratio
-            now_ratio = compress_params / tot_params
-            if args.compress_kv_cache:
-                now_ratio /= 2  # param ratio counts ALinear+BLinear, the rank ratio is half of it
-            msg = f"low={low} mid={mid}, high={high}, now_ratio={now_ratio}, params=({compress_params}/{tot_params})"
-            print(msg)
-            if now_ratio > ratio_target:
-                high = mid
-            else:
-                low = mid + 1
+            compressed, total = _plan_params(plan, weights)
+            print(f"low={low} mid={mid}, high={high}, ppl={ppl}, param_ratio={compressed / total}")
+            return ppl < args.ppl_target
+    else:
+        def probe(low, mid, high):
+            compressed, total = _plan_params(plans.plan(mid), weights)
+            now_ratio = compressed / total
+            if kv:
+                now_ratio /= 2  # the ratio counts ALinear + BLinear; the kv-cache (rank) ratio is half of it
+            print(f"low={low} mid={mid}, high={high}, now_ratio={now_ratio}, params=({compressed}/{total})")
+            return now_ratio > ratio_target
 
-    print(f"=== Searching done, decomposing layers... ===")
-    layers_min_ratio = {layername: default_param_ratio for layername in sensitivity_dict.keys()}
-    for layername, param_ratio, ppl in sorted_sensitive_list[mid:]:  # the LAST mid, not low (reference quirk, :106)
-        layers_min_ratio[layername] = min(layers_min_ratio[layername], param_ratio)
+    last_cut = _bisect_cut(plans.size, probe)
+    print("=== Searching done, decomposing layers... ===")
+    if last_cut is None:  # fewer than two candidates: the reference dies on its unbound `mid` here (binary_search.py:106)
+        raise UnboundLocalError("binary search needs at least two (layer, ratio) candidates: no cut was probed")
+    layers_min_ratio = plans.plan(last_cut)  # the LAST PROBED cut, not the converged one (reference quirk)
 
+    _decompose(model, modules, linear_info, layers_min_ratio, default_ratio, from_linear_kw, args, rank, ws)
+    model._asvd_layers_min_ratio = layers_min_ratio
+
+
+def _decompose(model, modules, linear_info, layers_min_ratio, default_ratio, from_linear_kw, args, rank, ws):
+    """Swap in the factorised layers of the chosen plan (reference: binary_search.py:111-131, which also times this stage)."""
     # ownership under the same LPT map as the sweep (all Linears in traversal order)
     shard = ws > 1 and getattr(args, "shard_decompose", True)
     linears = list(linear_info.items())
     owner_list = parallel.lpt_assign([parallel.svd_flops(l.out_features, l.in_features) for l, _ in linears], ws)
     owner = {info["full_name"]: o for (_, info), o in zip(linears, owner_list)}
-
     # tied weights (OPT: lm_head.weight IS embed_tokens.weight): the reference's `raw_linear.to("cpu")` would drag the embedding to the
-    # CPU with it and break the next forward; only offload weights no other module shares
+    # CPU with it and break the next forward; only weights no other module shares are offloaded
     uses = {}
     for _, prm in model.named_parameters(remove_duplicate=False):
         uses[id(prm)] = uses.get(id(prm), 0) + 1
+    offload = getattr(args, "offload_raw_to_cpu", True)
 
-    st = time.time()
-    exchange_items = []
-    for layername, param_ratio in tqdm(layers_min_ratio.items(), disable=(rank != 0)):
-        raw_linear = module_dict[layername]
-        info = linear_info[raw_linear]
-        if param_ratio == default_param_ratio:
-            svd_linear = raw_linear
-        elif shard and owner[layername] != rank:
-            svd_linear = raw_linear  # another rank owns this layer's factors: they arrive in exchange_factors below
-            exchange_items.append((layername, info["father"], info["name"], raw_linear))
-        else:
-            exchange_items.append((layername, info["father"], info["name"], raw_linear))
-            svd_linear = SVDLinear.from_linear(
-                raw_linear,
-                param_ratio=param_ratio,
-                alpha=args.alpha,
-                act_aware=args.act_aware,
-                sigma_fuse=args.sigma_fuse,
-                rank_align=args.rank_align,
-            )
-            SVDLinear.drop_factor_cache(raw_linear)
-            if getattr(args, "offload_raw_to_cpu", True) and uses.get(id(raw_linear.weight), 1) <= 1:
-                raw_linear.to("cpu")  # binary_search.py:127
-        setattr(info["father"], info["name"], svd_linear)
+    t_start = time.time()
+    selected = []  # (full_name, father, child name, raw Linear) of every layer the plan factorises: what exchange_factors walks
+    for name, ratio in tqdm(layers_min_ratio.items(), disable=(rank != 0)):
+        raw = modules[name]
+        info = linear_info[raw]
+        if ratio == default_ratio:
+            setattr(info["father"], info["name"], raw)  # not selected: the raw Linear (a ppl-target probe may have left a module in its place)
+            continue
+        selected.append((name, info["father"], info["name"], raw))
+        if shard and owner[name] != rank:
+            continue  # another rank owns this layer's factors: they arrive in exchange_factors below
+        setattr(info["father"], info["name"], SVDLinear.from_linear(raw, param_ratio=ratio, **from_linear_kw))
+        SVDLinear.drop_factor_cache(raw)
+        if offload and uses.get(id(raw.weight), 1) <= 1:
+            raw.to("cpu")  # binary_search.py:127
     if torch.cuda.is_available():
         torch.cuda.synchronize()
-    ed = time.time()
-    print(f"decompose time: {ed-st}")
+    t_end = time.time()
+    print(f"decompose time: {t_end-t_start}")
+    model._asvd_decompose_time = t_end - t_start
     if shard:
         # complete the model: every owner hands its factors to rank 0 (default) or to everybody — without this only ~1/ws of the
         # layers of any one replica would be factorised and an export / evaluation would silently miss the target
         mode = getattr(args, "gather_factors", "rank0")
         t0 = time.time()
-        got = parallel.exchange_factors(exchange_items, owner, mode)
+        got = parallel.exchange_factors(selected, owner, mode)
         if torch.cuda.is_available():
             torch.cuda.synchronize()
         model._asvd_factor_exchange = {"mode": mode, "received": got, "seconds": time.time() - t0}
         if rank == 0:
             print(f"factor exchange ({mode}): received {got} layers in {time.time() - t0:.2f} s")
-    model._asvd_layers_min_ratio = layers_min_ratio
-    model._asvd_decompose_time = ed - st

@@ -71,9 +71,10 @@ static inline bool dtype_ok(int dt) { return dt == ASVD_F32 || dt == ASVD_F16 ||
 // agent-scope acquire (invalidate this CU's L1) and ends with an agent-scope release (write back the XCD L2's dirty lines); either
 // fence alone was not enough.  The release costs a full L2 write-back per workgroup (the streaming kernels run 2x slower with
 // it), which is more than the 5-9 % the overlap of stream groups buys: one stream group, no fences, is the default.
-static __constant__ int c_fence = 0;
-#define ASVD_KERNEL_ACQUIRE() do { if (c_fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); } while (0)
-#define ASVD_KERNEL_RELEASE() do { if (c_fence) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); } while (0)
+// The flag travels with every launch (Sched::fence, a kernel ARGUMENT): nothing the kernels read is process-global state, so concurrent
+// calls with different settings cannot disturb each other.
+#define ASVD_KERNEL_ACQUIRE(sc) do { if ((sc).fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); } while (0)
+#define ASVD_KERNEL_RELEASE(sc) do { if ((sc).fence) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); } while (0)
 
 // ---- wave / block reductions ---------------------------------------------------------------
 __device__ __forceinline__ float wave_reduce_max(float v) {

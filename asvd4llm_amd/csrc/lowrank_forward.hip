@@ -38,18 +38,31 @@ __device__ __forceinline__ uint4 z_load16(const uint4* p) {
 }
 
 __device__ __forceinline__ void grid_barrier(unsigned* bar, unsigned nwg) {
-    // sense-reversing barrier on two words: bar[0] arrivals, bar[1] generation.  Zero-initialised once by the caller; reusable.
+    // sense-reversing barrier on three words: bar[0] arrivals, bar[1] generation, bar[2] give-up flag.  Zero-initialised once by the caller;
+    // reusable.  The generation is read BEFORE this workgroup arrives: both words sit in one 128-byte line (one L2 channel serves its
+    // requests in issue order) and the compiler barrier keeps the program order.  The spin is BOUNDED: the launch is not cooperative, so
+    // co-residency of the <= #CUs workgroups is an assumption (another stream's persistent kernel could hold CUs); after ~2^22 polls a
+    // waiter sets bar[2] and leaves instead of hanging the GPU — the output of that launch is then incomplete and the flag says so
+    // (asvd_lowrank_forward_f16's `work`, word 2; the Python module checks it when ASVD_DEBUG is set).
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's z stores have been acknowledged (s_waitcnt vmcnt(0)); no L2 write-back
     __syncthreads();
     if (threadIdx.x == 0) {
-        unsigned gen = __hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned prev = __hip_atomic_fetch_add(&bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned gen = __hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        const unsigned prev = __hip_atomic_fetch_add(&bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (prev == nwg - 1) {
             __hip_atomic_store(&bar[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __builtin_amdgcn_s_waitcnt(0);  // the reset is out before the generation moves
             __hip_atomic_fetch_add(&bar[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
-            while (__hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) __builtin_amdgcn_s_sleep(1);
+            unsigned spins = 0;
+            while (__hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1u << 22)) {  // seconds: not a slow barrier, a workgroup that never became resident
+                    __hip_atomic_store(&bar[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
         }
     }
     __syncthreads();

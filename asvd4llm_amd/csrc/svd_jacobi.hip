@@ -34,12 +34,28 @@ constexpr int PW = 2 * PB;   // pair width
 //    which on the norm-sorted, Cholesky-preconditioned matrices is where the coupling is: measured 10 -> 8 sweeps at 4096^2
 //    and 14 -> 9 on the row-scaled wide layers against the round-robin tournament (CPU prototype at n = 1024: 8 -> 6).
 //  * c_pair_order = 0 (ASVD_ORDER=rr, for A/B measurements): round-robin tournament (circle method), nb-1 steps of nb/2 pairs.
-__constant__ int c_pair_order = 1;
-// phase pairs per inner sweep of the 64x64 eigen-solve: 32 = one full odd-even cycle (every column pair meets once).  ASVD_EVD_PAIRS (experiments).
-__constant__ int c_evd_pairs = 32;
+// Everything a kernel needs to know about the call's pair schedules travels BY VALUE in its argument list (84 bytes of kernarg): round 2
+// kept these in __constant__ symbols rewritten by every call, so two concurrent calls with different shapes (a grouped 13B schedule next
+// to an XOR one) overwrote each other's tables mid-flight.
+//   pair_order  1 XOR (default), 0 round-robin (ASVD_ORDER=rr)
+//   super_order 1 XOR, 0 round-robin tournament, 2 grouped (below);  gm / gpair: group pairs per round / {gA, gB} of the grouped schedule
+//   evd_pairs   phase pairs per inner sweep of the 64x64 eigen-solve: 32 = one full odd-even cycle (ASVD_EVD_PAIRS, experiments)
+//   fence       agent-scope acquire / release at kernel boundaries (stream groups, common.h)
+struct Sched {
+    int pair_order, super_order, evd_pairs, fence, gm;
+    signed char gpair[8][4][2];
+};
+static Sched default_sched() {
+    Sched sc;
+    std::memset(&sc, 0, sizeof(sc));
+    sc.pair_order = 1;
+    sc.super_order = 1;
+    sc.evd_pairs = 32;
+    return sc;
+}
 
-__device__ __forceinline__ void rr_pair(int nb, int step, int k, int& I, int& J) {
-    if (c_pair_order) {  // pair space padded to the next power of two: callers skip pairs with J >= nb
+__device__ __forceinline__ void rr_pair(const Sched& sc, int nb, int step, int k, int& I, int& J) {
+    if (sc.pair_order) {  // pair space padded to the next power of two: callers skip pairs with J >= nb
         const int d = step + 1;
         const int h = 31 - __clz(d);  // highest set bit of d: i < i^d  <=>  bit h of i is clear
         I = ((k >> h) << (h + 1)) | (k & ((1 << h) - 1));
@@ -57,22 +73,19 @@ __device__ __forceinline__ void rr_pair(int nb, int step, int k, int& I, int& J)
 // power of two; otherwise (c_super_order = 0) the round-robin tournament over ns (+1 if odd) super-panels — a padded XOR schedule runs
 // P-1 super-steps with many empty slots (13B: 80 super-panels -> 127 steps, 37 % empty), the tournament ns-1 full ones.  Pairs with
 // T >= ns (padding / the bye) are skipped by the callers.  `step` counts from 0.
-__constant__ int c_super_order = 1;
 // c_super_order = 2: GROUPED schedule for counts that are a multiple of 16 but not a power of two: XOR (d = 1..15) inside groups of 16
 // super-panels, then the group pairs of a round-robin tournament over the groups, each for the 16 offsets s (A_i <-> B_{i ^ s}): the
 // nearest-neighbour-first order of the XOR schedule inside a group and inside a group pair, and 15 + rounds * 16 super-steps with
-// (almost) every slot filled instead of a padded XOR schedule.  c_gpair[round][m] = {gA, gB} (gA < gB), c_gm = pairs per round.
-__constant__ int c_gpair[8][4][2];
-__constant__ int c_gm = 0;
-__device__ __forceinline__ void super_pair(int ns, int step, int k, int& S, int& T) {
-    if (c_super_order == 1) {
+// (almost) every slot filled instead of a padded XOR schedule.  sc.gpair[round][m] = {gA, gB} (gA < gB), sc.gm = pairs per round.
+__device__ __forceinline__ void super_pair(const Sched& sc, int ns, int step, int k, int& S, int& T) {
+    if (sc.super_order == 1) {
         const int d = step + 1;
         const int h = 31 - __clz(d);
         S = ((k >> h) << (h + 1)) | (k & ((1 << h) - 1));
         T = S ^ d;
         return;
     }
-    if (c_super_order == 2) {
+    if (sc.super_order == 2) {
         if (step < 15) {
             if (k >= ns / 2) { S = ns; T = ns; return; }
             const int d = step + 1, h = 31 - __clz(d), g = k >> 3, kk = k & 7;
@@ -81,9 +94,9 @@ __device__ __forceinline__ void super_pair(int ns, int step, int k, int& S, int&
             return;
         }
         const int r = (step - 15) >> 4, sft = (step - 15) & 15, m = k >> 4, i = k & 15;
-        if (m >= c_gm) { S = ns; T = ns; return; }
-        S = 16 * c_gpair[r][m][0] + i;
-        T = 16 * c_gpair[r][m][1] + (i ^ sft);
+        if (m >= sc.gm) { S = ns; T = ns; return; }
+        S = 16 * sc.gpair[r][m][0] + i;
+        T = 16 * sc.gpair[r][m][1] + (i ^ sft);
         return;
     }
     const int n = ns + (ns & 1);  // even player count; player n-1 is the bye when ns is odd
@@ -97,7 +110,7 @@ __device__ __forceinline__ void super_pair(int ns, int step, int k, int& S, int&
 
 // Pair handled by a workgroup: from the schedule (plist == nullptr) or, in sparse sweeps, from an explicit per-problem list of
 // marked pairs (code = I << 16 | J, -1 = empty slot).  Returns false when there is nothing to do for this slot.
-__device__ __forceinline__ bool get_pair(const int* __restrict__ plist, int list_stride, int b, int nb, int step, int pair, int& I, int& J) {
+__device__ __forceinline__ bool get_pair(const Sched& sc, const int* __restrict__ plist, int list_stride, int b, int nb, int step, int pair, int& I, int& J) {
     if (plist) {
         const int code = plist[b * list_stride + pair];
         if (code < 0) return false;
@@ -105,7 +118,7 @@ __device__ __forceinline__ bool get_pair(const int* __restrict__ plist, int list
         J = code & 0xffff;
         return true;
     }
-    rr_pair(nb, step, pair, I, J);
+    rr_pair(sc, nb, step, pair, I, J);
     return J < nb;  // padding pair of the XOR ordering
 }
 
@@ -174,16 +187,16 @@ __global__ void vinit_kernel(float* __restrict__ X, int cols, int R, int m_pad) 
 constexpr int GCH = 32;  // rows per staged chunk
 
 
-__global__ __launch_bounds__(256) void gram_kernel(const float* __restrict__ X, int64_t panel_stride, int64_t batch_stride,
+__global__ __launch_bounds__(256) void gram_kernel(Sched sc, const float* __restrict__ X, int64_t panel_stride, int64_t batch_stride,
                                                    int nb, int step, int m_pad, int rows_per_split,
                                                    float* __restrict__ Gpart, const int* __restrict__ done,
                                                    const int* __restrict__ plist, int list_stride) {
     const int split = blockIdx.x, pair = blockIdx.y, b = blockIdx.z;
     const int nsplit = gridDim.x, npairs = gridDim.y;
-    ASVD_KERNEL_ACQUIRE();
+    ASVD_KERNEL_ACQUIRE(sc);
     if (done[b]) return;
     int I, J;
-    if (!get_pair(plist, list_stride, b, nb, step, pair, I, J)) return;
+    if (!get_pair(sc, plist, list_stride, b, nb, step, pair, I, J)) return;
     const float* __restrict__ XI = X + (int64_t)b * batch_stride + (int64_t)I * panel_stride;
     const float* __restrict__ XJ = X + (int64_t)b * batch_stride + (int64_t)J * panel_stride;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -269,7 +282,7 @@ __global__ __launch_bounds__(256) void gram_kernel(const float* __restrict__ X, 
             out[2 * 1024 + i * 32 + c] = ajj[reg] + red[(32 + reg) * 64 + lane];
         }
     }
-    ASVD_KERNEL_RELEASE();
+    ASVD_KERNEL_RELEASE(sc);
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -352,7 +365,7 @@ struct BlockCtx { int bx, by, bz, gx, gy, gz; };
 constexpr int EVD_SMEM_FLOATS(int keepg) { return (keepg ? 2 : 1) * PW * PW + 2 * PW + 64 + 8 + PW + PW; }
 
 template <int MODE, int KEEPG>
-__device__ __forceinline__ void evd_body(const BlockCtx& ctx, float* __restrict__ smem, const float* __restrict__ Gpart, int nsplit,
+__device__ __forceinline__ void evd_body(const Sched& sc, const BlockCtx& ctx, float* __restrict__ smem, const float* __restrict__ Gpart, int nsplit,
                                          float* __restrict__ Qbuf, int* __restrict__ active, unsigned* __restrict__ maxoff_bits,
                                          int* __restrict__ nrot, const int* __restrict__ done, float tol, int inner_sweeps, int nb, int step,
                                          int kb, int* __restrict__ hist, const int* __restrict__ plist, int list_stride, const EvdV3& v3) {
@@ -370,7 +383,7 @@ __device__ __forceinline__ void evd_body(const BlockCtx& ctx, float* __restrict_
     int* rnk = (int*)(cscale + PW);
 
     const int pair = MODE ? (ctx.bx >> 1) : ctx.bx, b = ctx.by, npairs = MODE ? (ctx.gx >> 1) : ctx.gx;
-    ASVD_KERNEL_ACQUIRE();
+    ASVD_KERNEL_ACQUIRE(sc);
     if (done[b]) return;
     // the eigen-solve is a dependent chain of short VALU/LDS phases on every group's critical path: let its waves win the issue
     // arbitration against the matrix-pipe-bound gram/update waves of the other stream groups that share the SIMD
@@ -385,7 +398,7 @@ __device__ __forceinline__ void evd_body(const BlockCtx& ctx, float* __restrict_
     if constexpr (MODE == 0) {
         act_flag = active + b * npairs + pair;
         qo = Qbuf + slot * (PW * PW);
-        if (!get_pair(plist, list_stride, b, nb, step, pair, I, J)) {  // padding pair / empty slot: nothing to rotate
+        if (!get_pair(sc, plist, list_stride, b, nb, step, pair, I, J)) {  // padding pair / empty slot: nothing to rotate
             if (tid == 0) *act_flag = 0;
             return;
         }
@@ -411,7 +424,7 @@ __device__ __forceinline__ void evd_body(const BlockCtx& ctx, float* __restrict_
     } else {
         act_flag = v3.subact + slot * 4 + (MODE - 1) * 2 + sp;
         qo = v3.Q0 + (slot * 2 + sp) * (PW * PW);
-        super_pair(v3.ns, step, pair, S, T);
+        super_pair(sc, v3.ns, step, pair, S, T);
         if (T >= v3.ns) {  // padding super-pair
             if (tid == 0) *act_flag = 0;
             return;
@@ -602,7 +615,7 @@ __device__ __forceinline__ void evd_body(const BlockCtx& ctx, float* __restrict_
                     d1[e] = G[(32 + i) * PW + pcol(32 + j)];
                 }
             }
-            ASVD_KERNEL_RELEASE();
+            ASVD_KERNEL_RELEASE(sc);
             return;
         }
     }
@@ -708,7 +721,7 @@ __device__ __forceinline__ void evd_body(const BlockCtx& ctx, float* __restrict_
         __syncthreads();
         cur = nxt;
     };
-    for (int ph2 = 0; ph2 < (rotate ? nsw * c_evd_pairs : 0); ++ph2) {
+    for (int ph2 = 0; ph2 < (rotate ? nsw * sc.evd_pairs : 0); ++ph2) {
         phase(std::integral_constant<int, 0>{});
         phase(std::integral_constant<int, 1>{});
     }
@@ -805,18 +818,18 @@ __device__ __forceinline__ void evd_body(const BlockCtx& ctx, float* __restrict_
             qf[(32 * rblk + i) * 128 + 32 * bb + cc] = c1[reg];
         }
     }
-    ASVD_KERNEL_RELEASE();
+    ASVD_KERNEL_RELEASE(sc);
 }
 
 template <int MODE, int KEEPG>
-__global__ __launch_bounds__(256, 4) void evd_kernel(const float* __restrict__ Gpart, int nsplit, float* __restrict__ Qbuf,
+__global__ __launch_bounds__(256, 4) void evd_kernel(Sched sc, const float* __restrict__ Gpart, int nsplit, float* __restrict__ Qbuf,
                                                    int* __restrict__ active, unsigned* __restrict__ maxoff_bits,
                                                    int* __restrict__ nrot, const int* __restrict__ done, float tol,
                                                    int inner_sweeps, int nb, int step, int kb, int* __restrict__ hist,
                                                    const int* __restrict__ plist, int list_stride, EvdV3 v3) {
     __shared__ __attribute__((aligned(16))) float smem[EVD_SMEM_FLOATS(KEEPG)];
     const BlockCtx ctx{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, (int)gridDim.y, (int)gridDim.z};
-    evd_body<MODE, KEEPG>(ctx, smem, Gpart, nsplit, Qbuf, active, maxoff_bits, nrot, done, tol, inner_sweeps, nb, step, kb, hist, plist,
+    evd_body<MODE, KEEPG>(sc, ctx, smem, Gpart, nsplit, Qbuf, active, maxoff_bits, nrot, done, tol, inner_sweeps, nb, step, kb, hist, plist,
                           list_stride, v3);
 }
 
@@ -826,15 +839,15 @@ __global__ __launch_bounds__(256, 4) void evd_kernel(const float* __restrict__ G
 // row-per-lane out), multiplied by Q held in 64 VGPRs, and stored as full 128-B row segments.
 constexpr int TLD = PW + 4;  // LDS row stride in floats (272 B, multiple of 16 B; bank-conflict-free b128 reads)
 
-__global__ __launch_bounds__(256) void update_kernel(float* __restrict__ X, int64_t panel_stride, int64_t batch_stride,
+__global__ __launch_bounds__(256) void update_kernel(Sched sc, float* __restrict__ X, int64_t panel_stride, int64_t batch_stride,
                                                      int nb, int step, int R, int rows_per_wg,
                                                      const float* __restrict__ Qbuf, const int* __restrict__ active,
                                                      const int* __restrict__ done, const int* __restrict__ plist, int list_stride) {
     const int chunk = blockIdx.x, pair = blockIdx.y, b = blockIdx.z, npairs = gridDim.y;
-    ASVD_KERNEL_ACQUIRE();
+    ASVD_KERNEL_ACQUIRE(sc);
     if (done[b] || !active[b * npairs + pair]) return;
     int I, J;
-    if (!get_pair(plist, list_stride, b, nb, step, pair, I, J)) return;
+    if (!get_pair(sc, plist, list_stride, b, nb, step, pair, I, J)) return;
     float* __restrict__ XI = X + (int64_t)b * batch_stride + (int64_t)I * panel_stride;
     float* __restrict__ XJ = X + (int64_t)b * batch_stride + (int64_t)J * panel_stride;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -889,7 +902,7 @@ __global__ __launch_bounds__(256) void update_kernel(float* __restrict__ X, int6
             }
         }
     }
-    ASVD_KERNEL_RELEASE();
+    ASVD_KERNEL_RELEASE(sc);
 }
 
 // bit surgery for the XOR schedule: pair slot <-> lower member, quad index -> representative
@@ -906,10 +919,10 @@ __device__ __forceinline__ int remove_bit(int v, int pos) { return ((v >> (pos +
 // are disjoint) and launches gram / evd / update for marked pairs only, skipping empty steps.  Couplings of unmarked pairs move
 // only by (rotation angle) x (other couplings) during the sweep, second order in what is left; the next snapshot sees them.
 // The termination measure is the snapshot's (same definition as in evd_kernel), so the stopping rule is unchanged.
-__global__ __launch_bounds__(256) void panel_sumsq_kernel(const float* __restrict__ X, int64_t panel_stride, int64_t batch_stride,
+__global__ __launch_bounds__(256) void panel_sumsq_kernel(Sched sc, const float* __restrict__ X, int64_t panel_stride, int64_t batch_stride,
                                                           int m_pad, int n_pad, float* __restrict__ dn, const int* __restrict__ done) {
     const int I = blockIdx.x, b = blockIdx.y, c = threadIdx.x & 31, g = threadIdx.x >> 5;
-    ASVD_KERNEL_ACQUIRE();
+    ASVD_KERNEL_ACQUIRE(sc);
     if (done[b]) return;
     const float* __restrict__ P = X + (int64_t)b * batch_stride + (int64_t)I * panel_stride;
     float s = 0.0f;
@@ -923,7 +936,7 @@ __global__ __launch_bounds__(256) void panel_sumsq_kernel(const float* __restric
         for (int i = 0; i < 8; ++i) t += red[i][c];
         dn[(int64_t)b * n_pad + I * PB + c] = t;
     }
-    ASVD_KERNEL_RELEASE();
+    ASVD_KERNEL_RELEASE(sc);
 }
 
 __device__ __forceinline__ float nanmax(float a, float b) { return (b != b) ? b : ((a != a) ? a : fmaxf(a, b)); }
@@ -932,7 +945,7 @@ __device__ __forceinline__ float nanmax(float a, float b) { return (b != b) ? b 
 // 32-row chunks of the eight panels are staged in LDS (coalesced 16-B loads, next chunk prefetched into registers while the
 // current one is in the matrix pipe); every wave reads its operands from LDS as conflict-free 256-B rows.
 template <int SPLIT>
-__global__ __launch_bounds__(256) void fullcheck_kernel(const float* __restrict__ X, int64_t panel_stride, int64_t batch_stride, int nb,
+__global__ __launch_bounds__(256) void fullcheck_kernel(Sched sc, const float* __restrict__ X, int64_t panel_stride, int64_t batch_stride, int nb,
                                                         int m_pad, int n_pad, const float* __restrict__ dn, float tol, int kb,
                                                         unsigned char* __restrict__ pflag, unsigned* __restrict__ maxoff_bits,
                                                         const int* __restrict__ done) {
@@ -940,7 +953,7 @@ __global__ __launch_bounds__(256) void fullcheck_kernel(const float* __restrict_
     // the three snapshots of 32 problems; the plain order stays.)
     const int ig = blockIdx.x, jg = blockIdx.y, b = blockIdx.z;
     if (ig > jg || done[b]) return;
-    ASVD_KERNEL_ACQUIRE();
+    ASVD_KERNEL_ACQUIRE(sc);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int J = jg * 4 + w;
     bool ok[4];
@@ -1037,7 +1050,7 @@ __global__ __launch_bounds__(256) void fullcheck_kernel(const float* __restrict_
             }
         }
     }
-    if (J >= nb) { ASVD_KERNEL_RELEASE(); return; }
+    if (J >= nb) { ASVD_KERNEL_RELEASE(sc); return; }
     const int h = lane >> 5, c = lane & 31;
     const float* __restrict__ dnb = dn + (int64_t)b * n_pad;
     const float dj = dnb[J * PB + c];
@@ -1078,7 +1091,7 @@ __global__ __launch_bounds__(256) void fullcheck_kernel(const float* __restrict_
             }
         }
     }
-    ASVD_KERNEL_RELEASE();
+    ASVD_KERNEL_RELEASE(sc);
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -2017,10 +2030,10 @@ static bool super_rr_for(const Plan& p) {
     return e && atoi(e) == 1;
 }
 // group pairs of every round of the grouped schedule: circle method over the ns / 16 groups (+ a bye when their number is odd)
-static hipError_t set_group_table(int ns) {
+static void set_group_table(Sched& sc, int ns) {
     const int ng = ns / 16, n = ng + (ng & 1), gm = ng / 2;
-    int tab[8][4][2];
-    std::memset(tab, 0, sizeof(tab));
+    signed char (*tab)[4][2] = sc.gpair;
+    std::memset(sc.gpair, 0, sizeof(sc.gpair));
     for (int r = 0; r < n - 1; ++r) {
         int m = 0;
         for (int k = 0; k < n / 2; ++k) {
@@ -2028,14 +2041,12 @@ static hipError_t set_group_table(int ns) {
             const int pb = n - 1 - k;
             const int bb = 1 + (pb - 1 + r) % (n - 1);
             if (a >= ng || bb >= ng) continue;  // the bye
-            tab[r][m][0] = std::min(a, bb);
-            tab[r][m][1] = std::max(a, bb);
+            tab[r][m][0] = (signed char)std::min(a, bb);
+            tab[r][m][1] = (signed char)std::max(a, bb);
             ++m;
         }
     }
-    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_gpair), tab, sizeof(tab), 0, hipMemcpyHostToDevice);
-    if (e != hipSuccess) return e;
-    return hipMemcpyToSymbol(HIP_SYMBOL(c_gm), &gm, sizeof(int), 0, hipMemcpyHostToDevice);
+    sc.gm = gm;
 }
 
 // grouped schedule (super_pair, c_super_order = 2): ns a multiple of 16, not a power of two, at most 8 groups
@@ -2224,16 +2235,16 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
     std::vector<int> host_done(batch, 0);
     std::vector<float> last_off(batch, 0.0f), prev_off(batch, 1e30f);
     const bool debug = getenv("ASVD_DEBUG") != nullptr;
+    // the call's schedule description: a kernel argument of every launch below (no process-global device state)
+    Sched sc = default_sched();
     {
-        const int order = pair_order_xor() ? 1 : 0;
-        ASVD_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_pair_order), &order, sizeof(int), 0, hipMemcpyHostToDevice));
-        const int fence = stream_groups_for(batch) > 1 ? 1 : 0;
-        ASVD_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_fence), &fence, sizeof(int), 0, hipMemcpyHostToDevice));
-        const int sup = super_grouped_for(p) ? 2 : (super_rr_for(p) ? 0 : 1);
-        ASVD_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_super_order), &sup, sizeof(int), 0, hipMemcpyHostToDevice));
-        if (sup == 2) ASVD_HIP_CHECK(set_group_table(p.ns));
-        const int evp = getenv("ASVD_EVD_PAIRS") ? std::max(1, std::min(64, atoi(getenv("ASVD_EVD_PAIRS")))) : PW / 2;
-        ASVD_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_evd_pairs), &evp, sizeof(int), 0, hipMemcpyHostToDevice));
+        sc.pair_order = pair_order_xor() ? 1 : 0;
+        // agent-scope fences at kernel boundaries: on with several stream groups (common.h); ASVD_FENCE=0/1 overrides (experiments)
+        sc.fence = stream_groups_for(batch) > 1 ? 1 : 0;
+        if (getenv("ASVD_FENCE")) sc.fence = atoi(getenv("ASVD_FENCE")) ? 1 : 0;
+        sc.super_order = super_grouped_for(p) ? 2 : (super_rr_for(p) ? 0 : 1);
+        if (sc.super_order == 2) set_group_table(sc, p.ns);
+        sc.evd_pairs = getenv("ASVD_EVD_PAIRS") ? std::max(1, std::min(64, atoi(getenv("ASVD_EVD_PAIRS")))) : PW / 2;
     }
     const int nsteps = pair_order_xor() ? 2 * p.npairs - 1 : p.nb - 1;
     // panels whose convergence is enforced: those holding the k leading columns, plus one panel of margin
@@ -2322,15 +2333,15 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
                 const int b0 = gb0[g], nbg = gnb[g];
                 const float* Xg = X + (int64_t)b0 * p.batch_stride;
                 ASVD_HIP_CHECK(hipMemsetAsync(pflag + (size_t)b0 * p.nb * p.nb, 0, (size_t)nbg * p.nb * p.nb, gst[g]));
-                panel_sumsq_kernel<<<dim3(p.nb, nbg), 256, 0, gst[g]>>>(Xg, p.panel_stride, p.batch_stride, p.m_pad, p.n_pad,
+                panel_sumsq_kernel<<<dim3(p.nb, nbg), 256, 0, gst[g]>>>(sc, Xg, p.panel_stride, p.batch_stride, p.m_pad, p.n_pad,
                                                                         dnorm + (size_t)b0 * p.n_pad, done + b0);
                 const unsigned nt = (unsigned)ceil_div64(p.nb, 4);
                 if (split_check)
-                    fullcheck_kernel<1><<<dim3(nt, nt, nbg), 256, 0, gst[g]>>>(Xg, p.panel_stride, p.batch_stride, p.nb, p.m_pad, p.n_pad,
+                    fullcheck_kernel<1><<<dim3(nt, nt, nbg), 256, 0, gst[g]>>>(sc, Xg, p.panel_stride, p.batch_stride, p.nb, p.m_pad, p.n_pad,
                                                                                dnorm + (size_t)b0 * p.n_pad, tol, kb,
                                                                                pflag + (size_t)b0 * p.nb * p.nb, maxoff + b0, done + b0);
                 else
-                    fullcheck_kernel<0><<<dim3(nt, nt, nbg), 256, 0, gst[g]>>>(Xg, p.panel_stride, p.batch_stride, p.nb, p.m_pad, p.n_pad,
+                    fullcheck_kernel<0><<<dim3(nt, nt, nbg), 256, 0, gst[g]>>>(sc, Xg, p.panel_stride, p.batch_stride, p.nb, p.m_pad, p.n_pad,
                                                                                dnorm + (size_t)b0 * p.n_pad, tol, kb,
                                                                                pflag + (size_t)b0 * p.nb * p.nb, maxoff + b0, done + b0);
             }
@@ -2442,17 +2453,17 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
                     const int nch = (int)ceil_div64(p.R_upd, rpw);
                     {
                         ProfScope ps(6, s2);
-                        gram_kernel<<<dim3(nsp, slots, nbg), 256, 0, s2>>>(Xg, p.panel_stride, p.batch_stride, p.nb, step, p.m_pad, rps, Gg,
+                        gram_kernel<<<dim3(nsp, slots, nbg), 256, 0, s2>>>(sc, Xg, p.panel_stride, p.batch_stride, p.nb, step, p.m_pad, rps, Gg,
                                                                            done + b0, pl, slots);
                     }
                     {
                         ProfScope ps(2, s2);
-                        evd_kernel<0, 0><<<dim3(slots, nbg), 256, 0, s2>>>(Gg, nsp, Qg, ag, maxoff + b0, nrot + b0, done + b0, tol, inner_sweeps,
+                        evd_kernel<0, 0><<<dim3(slots, nbg), 256, 0, s2>>>(sc, Gg, nsp, Qg, ag, maxoff + b0, nrot + b0, done + b0, tol, inner_sweeps,
                                                                            p.nb, step, kb, hist_dev, pl, slots, EvdV3{});
                     }
                     {
                         ProfScope ps(7, s2);
-                        update_kernel<<<dim3(nch, slots, nbg), 256, 0, s2>>>(Xg, p.panel_stride, p.batch_stride, p.nb, step, p.R_upd, rpw, Qg,
+                        update_kernel<<<dim3(nch, slots, nbg), 256, 0, s2>>>(sc, Xg, p.panel_stride, p.batch_stride, p.nb, step, p.R_upd, rpw, Qg,
                                                                              ag, done + b0, pl, slots);
                     }
                     continue;
@@ -2461,7 +2472,7 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
                 const int ns_here = gram_here ? p.nsplit : p.nchunks_f;
                 if (gram_here) {
                     ProfScope ps(6, s2);
-                    gram_kernel<<<dim3(p.nsplit, p.npairs, nbg), 256, 0, s2>>>(Xg, p.panel_stride, p.batch_stride, p.nb, step, p.m_pad,
+                    gram_kernel<<<dim3(p.nsplit, p.npairs, nbg), 256, 0, s2>>>(sc, Xg, p.panel_stride, p.batch_stride, p.nb, step, p.m_pad,
                                                                                p.rows_per_split, Gg, done + b0, nullptr, 0);
                 }
                 {
@@ -2471,10 +2482,10 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
                         v3.ns = p.ns;
                         v3.nbpan = p.nb;
                         v3.Gd32 = Gd32g;
-                        evd_kernel<0, 1><<<dim3(p.npairs, nbg), 256, 0, s2>>>(Gg, ns_here, Qg, ag, maxoff + b0, nrot + b0, done + b0, tol,
+                        evd_kernel<0, 1><<<dim3(p.npairs, nbg), 256, 0, s2>>>(sc, Gg, ns_here, Qg, ag, maxoff + b0, nrot + b0, done + b0, tol,
                                                                                inner_sweeps, p.nb, step, kb, hist_dev, nullptr, 0, v3);
                     } else {
-                        evd_kernel<0, 0><<<dim3(p.npairs, nbg), 256, 0, s2>>>(Gg, ns_here, Qg, ag, maxoff + b0, nrot + b0, done + b0, tol,
+                        evd_kernel<0, 0><<<dim3(p.npairs, nbg), 256, 0, s2>>>(sc, Gg, ns_here, Qg, ag, maxoff + b0, nrot + b0, done + b0, tol,
                                                                                inner_sweeps, p.nb, step, kb, hist_dev, nullptr, 0, EvdV3{});
                     }
                 }
@@ -2486,7 +2497,7 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
                                                                                         p.R_upd, p.m_pad, p.rows_per_wg_f, Qg, ag, Gg,
                                                                                         done + b0);
                     } else {
-                        update_kernel<<<dim3(p.nchunks, p.npairs, nbg), 256, 0, s2>>>(Xg, p.panel_stride, p.batch_stride, p.nb, step,
+                        update_kernel<<<dim3(p.nchunks, p.npairs, nbg), 256, 0, s2>>>(sc, Xg, p.panel_stride, p.batch_stride, p.nb, step,
                                                                                       p.R_upd, p.rows_per_wg, Qg, ag, done + b0, nullptr, 0);
                     }
                 }
@@ -2532,13 +2543,13 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
                 const int nblk = sa.gx * sa.gy + ga.gx * ga.gy * ga.gz;
                 if (nblk == 0) return;
                 ProfScope ps(emode ? 2 : 1, st);
-                if (emode == 1) dual_gram_kernel<1><<<nblk, 256, 0, st>>>(sa, ga);
-                else dual_gram_kernel<2><<<nblk, 256, 0, st>>>(sa, ga);
+                if (emode == 1) dual_gram_kernel<1><<<nblk, 256, 0, st>>>(sc, sa, ga);
+                else dual_gram_kernel<2><<<nblk, 256, 0, st>>>(sc, sa, ga);
             };
             auto launch_u = [&](int h, int D) {
                 const int b0 = hb0[h];
                 ProfScope ps(3, st);
-                supdate_split_kernel<<<dim3(p.nchunks_s, p.npairs_s, hnb[h]), 256, 0, st>>>(
+                supdate_split_kernel<<<dim3(p.nchunks_s, p.npairs_s, hnb[h]), 256, 0, st>>>(sc, 
                     X + (int64_t)b0 * p.batch_stride, p.panel_stride, p.batch_stride, p.ns, D, p.R_upd, p.rows_per_wg_s,
                     (float*)(wb + p.off_qfin) + (int64_t)b0 * p.npairs_s * SP * SP, (int*)(wb + p.off_subact) + (int64_t)b0 * p.npairs_s * 4,
                     done + b0, nupd + b0);
@@ -2612,30 +2623,30 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
                     if (gram_in) {
                         ProfScope ps(1, s2);
                         if (gram_split)
-                            sgram6_kernel<1><<<dim3(p.nsplit_s, p.npairs_s, nbg), 256, 0, s2>>>(Xg, p.panel_stride, p.batch_stride, p.ns, D, p.m_pad,
+                            sgram6_kernel<1><<<dim3(p.nsplit_s, p.npairs_s, nbg), 256, 0, s2>>>(sc, Xg, p.panel_stride, p.batch_stride, p.ns, D, p.m_pad,
                                                                                                p.rows_per_split_s, Gx6g, done + b0);
                         else
-                            sgram6_kernel<0><<<dim3(p.nsplit_s, p.npairs_s, nbg), 256, 0, s2>>>(Xg, p.panel_stride, p.batch_stride, p.ns, D, p.m_pad,
+                            sgram6_kernel<0><<<dim3(p.nsplit_s, p.npairs_s, nbg), 256, 0, s2>>>(sc, Xg, p.panel_stride, p.batch_stride, p.ns, D, p.m_pad,
                                                                                                p.rows_per_split_s, Gx6g, done + b0);
                     }
                     {
                         ProfScope ps(2, s2);
-                        evd_kernel<1, 1><<<dim3(2 * p.npairs_s, nbg), 256, 0, s2>>>(nullptr, 0, nullptr, nullptr, maxoff + b0, nrot + b0, done + b0, tol,
+                        evd_kernel<1, 1><<<dim3(2 * p.npairs_s, nbg), 256, 0, s2>>>(sc, nullptr, 0, nullptr, nullptr, maxoff + b0, nrot + b0, done + b0, tol,
                                                                                    inner_sweeps, p.nb, D - 1, kb, hist_dev, nullptr, 0, v3);
-                        evd_kernel<2, 1><<<dim3(2 * p.npairs_s, nbg), 256, 0, s2>>>(nullptr, 0, nullptr, nullptr, maxoff + b0, nrot + b0, done + b0, tol,
+                        evd_kernel<2, 1><<<dim3(2 * p.npairs_s, nbg), 256, 0, s2>>>(sc, nullptr, 0, nullptr, nullptr, maxoff + b0, nrot + b0, done + b0, tol,
                                                                                    inner_sweeps, p.nb, D - 1, kb, hist_dev, nullptr, 0, v3);
                     }
                     {
                         ProfScope ps(gram_out ? 8 : 3, s2);
                         if (gram_out)
-                            supgram_kernel<<<dim3(p.nchunks_q, (2 * p.npairs_s) / 4, nbg), 512, SUPGRAM_SMEM_FLOATS * sizeof(float), s2>>>(
+                            supgram_kernel<<<dim3(p.nchunks_q, (2 * p.npairs_s) / 4, nbg), 512, SUPGRAM_SMEM_FLOATS * sizeof(float), s2>>>(sc, 
                                 Xg, p.panel_stride, p.batch_stride, p.ns, D, E, p.R_upd, p.m_pad, p.rows_per_wg_q, v3.Qfin, v3.subact, Gx6g, done + b0,
                                 nupd + b0, p.npairs_s);
                         else if (split_bf16)
-                            supdate_split_kernel<<<dim3(p.nchunks_s, p.npairs_s, nbg), 256, 0, s2>>>(Xg, p.panel_stride, p.batch_stride, p.ns, D,
+                            supdate_split_kernel<<<dim3(p.nchunks_s, p.npairs_s, nbg), 256, 0, s2>>>(sc, Xg, p.panel_stride, p.batch_stride, p.ns, D,
                                                                                                     p.R_upd, p.rows_per_wg_s, v3.Qfin, v3.subact, done + b0, nupd + b0);
                         else
-                            supdate_kernel<<<dim3(p.nchunks_s, p.npairs_s, nbg), 256, 0, s2>>>(Xg, p.panel_stride, p.batch_stride, p.ns, D, p.R_upd,
+                            supdate_kernel<<<dim3(p.nchunks_s, p.npairs_s, nbg), 256, 0, s2>>>(sc, Xg, p.panel_stride, p.batch_stride, p.ns, D, p.R_upd,
                                                                                               p.rows_per_wg_s, v3.Qfin, v3.subact, done + b0, nupd + b0);
                     }
                 }
@@ -2957,15 +2968,11 @@ int asvd_test_supdate(int split, float* X, int64_t panel_stride, int64_t batch_s
                       const int* subact, const int* done, int* nupd, int nchunks, int npairs, int batch, void* stream) {
     if (!X || !Qfin || !subact || !done || !nupd || ns < 2 || D < 1 || R < 32 || (R % 32) || rows_per_wg < 32 || (rows_per_wg % 32)) return ASVD_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
-    {
-        const int order = 1;
-        ASVD_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_pair_order), &order, sizeof(int), 0, hipMemcpyHostToDevice));
-        ASVD_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_super_order), &order, sizeof(int), 0, hipMemcpyHostToDevice));
-    }
+    const Sched sc = default_sched();
     if (split)
-        supdate_split_kernel<<<dim3(nchunks, npairs, batch), 256, 0, st>>>(X, panel_stride, batch_stride, ns, D, R, rows_per_wg, Qfin, subact, done, nupd);
+        supdate_split_kernel<<<dim3(nchunks, npairs, batch), 256, 0, st>>>(sc, X, panel_stride, batch_stride, ns, D, R, rows_per_wg, Qfin, subact, done, nupd);
     else
-        supdate_kernel<<<dim3(nchunks, npairs, batch), 256, 0, st>>>(X, panel_stride, batch_stride, ns, D, R, rows_per_wg, Qfin, subact, done, nupd);
+        supdate_kernel<<<dim3(nchunks, npairs, batch), 256, 0, st>>>(sc, X, panel_stride, batch_stride, ns, D, R, rows_per_wg, Qfin, subact, done, nupd);
     ASVD_HIP_CHECK(hipGetLastError());
     return ASVD_OK;
 }
@@ -2975,11 +2982,11 @@ int asvd_test_supdate(int split, float* X, int64_t panel_stride, int64_t batch_s
 // through *nsteps_out.  tests/test_gpu_twolevel.py checks that every pair appears exactly once and that the pairs of a step are disjoint.
 }  // extern "C"
 namespace {
-__global__ void super_schedule_kernel(int ns, int nsteps, int npairs, int* __restrict__ out) {
+__global__ void super_schedule_kernel(Sched sc, int ns, int nsteps, int npairs, int* __restrict__ out) {
     const int step = blockIdx.x, k = threadIdx.x;
     if (k >= npairs) return;
     int S, T;
-    super_pair(ns, step, k, S, T);
+    super_pair(sc, ns, step, k, S, T);
     out[step * npairs + k] = (S < ns && T < ns) ? ((S << 16) | T) : -1;
 }
 }  // namespace
@@ -2995,14 +3002,12 @@ int asvd_test_super_schedule(int ns, int grouped, int* out_dev, int out_capacity
     *nsteps_out = nsteps;
     *npairs_out = npairs;
     if ((int64_t)nsteps * npairs > out_capacity || npairs > 1024) return ASVD_E_WORKSPACE;
-    const int sup = grp ? 2 : 1;
-    ASVD_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_super_order), &sup, sizeof(int), 0, hipMemcpyHostToDevice));
-    if (grp) ASVD_HIP_CHECK(set_group_table(ns));
-    super_schedule_kernel<<<nsteps, npairs>>>(ns, nsteps, npairs, out_dev);
+    Sched sc = default_sched();
+    sc.super_order = grp ? 2 : 1;
+    if (grp) set_group_table(sc, ns);
+    super_schedule_kernel<<<nsteps, npairs>>>(sc, ns, nsteps, npairs, out_dev);
     ASVD_HIP_CHECK(hipGetLastError());
     ASVD_HIP_CHECK(hipDeviceSynchronize());
-    const int one = 1;
-    ASVD_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_super_order), &one, sizeof(int), 0, hipMemcpyHostToDevice));
     return ASVD_OK;
 }
 
@@ -3014,13 +3019,9 @@ int asvd_test_supgram(float* X, int64_t panel_stride, int64_t batch_stride, int 
         R < 32 || (R % 32) || (m_pad % 32) || rows_per_wg < 32 || (rows_per_wg % 32))
         return ASVD_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
-    {
-        const int order = 1;
-        ASVD_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_pair_order), &order, sizeof(int), 0, hipMemcpyHostToDevice));
-        ASVD_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_super_order), &order, sizeof(int), 0, hipMemcpyHostToDevice));
-    }
+    const Sched sc = default_sched();
     ASVD_HIP_CHECK(hipFuncSetAttribute((const void*)supgram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SUPGRAM_SMEM_FLOATS * sizeof(float))));
-    supgram_kernel<<<dim3(nchunks, (2 * npairs) / 4, batch), 512, SUPGRAM_SMEM_FLOATS * sizeof(float), st>>>(X, panel_stride, batch_stride, ns, D, E, R, m_pad,
+    supgram_kernel<<<dim3(nchunks, (2 * npairs) / 4, batch), 512, SUPGRAM_SMEM_FLOATS * sizeof(float), st>>>(sc, X, panel_stride, batch_stride, ns, D, E, R, m_pad,
                                                                                                            rows_per_wg, Qfin, subact, Gx, done, nupd, npairs);
     ASVD_HIP_CHECK(hipGetLastError());
     return ASVD_OK;

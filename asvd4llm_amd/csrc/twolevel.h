@@ -47,15 +47,15 @@ __device__ __forceinline__ void split3(float x0, float x1, unsigned& p1, unsigne
 // chunk, wave-private LDS image, one ds_read_b32 per MFMA operand); four panels and six accumulators per wave.
 constexpr int SGRAM6_SMEM_FLOATS = 4 * 4 * 16 * PB;  // 32 KiB
 template <int GSPLIT>  // 1: split-bf16 arithmetic (six bf16 products per fp32 product), 0: fp32 MFMA
-__device__ __forceinline__ void sgram6_body(const BlockCtx& ctx, float* __restrict__ smem, const float* __restrict__ X, int64_t panel_stride,
+__device__ __forceinline__ void sgram6_body(const Sched& sc, const BlockCtx& ctx, float* __restrict__ smem, const float* __restrict__ X, int64_t panel_stride,
                                             int64_t batch_stride, int ns, int D, int m_pad, int rows_per_split, float* __restrict__ Gx,
                                             const int* __restrict__ done) {
     const int split = ctx.bx, pair = ctx.by, b = ctx.bz;
     const int nsplit = ctx.gx, npairs = ctx.gy;
-    ASVD_KERNEL_ACQUIRE();
+    ASVD_KERNEL_ACQUIRE(sc);
     if (done[b]) return;
     int S, T;
-    super_pair(ns, D - 1, pair, S, T);
+    super_pair(sc, ns, D - 1, pair, S, T);
     if (T >= ns) return;
     const float* __restrict__ Xb = X + (int64_t)b * batch_stride;
     const float* __restrict__ P0 = Xb + (int64_t)(2 * S) * panel_stride;
@@ -159,15 +159,15 @@ __device__ __forceinline__ void sgram6_body(const BlockCtx& ctx, float* __restri
             out[tile * 1024 + i * 32 + j] = v;
         }
     }
-    ASVD_KERNEL_RELEASE();
+    ASVD_KERNEL_RELEASE(sc);
 }
 
 template <int GSPLIT>
-__global__ __launch_bounds__(256, 2) void sgram6_kernel(const float* __restrict__ X, int64_t panel_stride, int64_t batch_stride, int ns, int D,
+__global__ __launch_bounds__(256, 2) void sgram6_kernel(Sched sc, const float* __restrict__ X, int64_t panel_stride, int64_t batch_stride, int ns, int D,
                                                         int m_pad, int rows_per_split, float* __restrict__ Gx, const int* __restrict__ done) {
     __shared__ __attribute__((aligned(16))) float smem[SGRAM6_SMEM_FLOATS];
     const BlockCtx ctx{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, (int)gridDim.y, (int)gridDim.z};
-    sgram6_body<GSPLIT>(ctx, smem, X, panel_stride, batch_stride, ns, D, m_pad, rows_per_split, Gx, done);
+    sgram6_body<GSPLIT>(sc, ctx, smem, X, panel_stride, batch_stride, ns, D, m_pad, rows_per_split, Gx, done);
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -175,14 +175,14 @@ __global__ __launch_bounds__(256, 2) void sgram6_kernel(const float* __restrict_
 // double-buffered padded LDS image (next tile prefetched into registers while the current one is in the matrix pipe, one barrier
 // per tile); wave w owns output panel w: its 128 x 32 slice of Qfin sits in 64 VGPRs, 64 MFMAs per tile.
 constexpr int ULD = SP + 4;  // LDS row stride in floats (528 B: conflict-free b128 row-per-lane reads)
-__global__ __launch_bounds__(256, 2) void supdate_kernel(float* __restrict__ X, int64_t panel_stride, int64_t batch_stride, int ns, int D,
+__global__ __launch_bounds__(256, 2) void supdate_kernel(Sched sc, float* __restrict__ X, int64_t panel_stride, int64_t batch_stride, int ns, int D,
                                                          int R, int rows_per_wg, const float* __restrict__ Qfin,
                                                          const int* __restrict__ subact, const int* __restrict__ done, int* __restrict__ nupd) {
     const int chunk = blockIdx.x, pair = blockIdx.y, b = blockIdx.z, npairs = gridDim.y;
-    ASVD_KERNEL_ACQUIRE();
+    ASVD_KERNEL_ACQUIRE(sc);
     if (done[b] || !pair_active(subact, (int64_t)b * npairs + pair)) return;
     int S, T;
-    super_pair(ns, D - 1, pair, S, T);
+    super_pair(sc, ns, D - 1, pair, S, T);
     if (T >= ns) return;
     if (chunk == 0 && threadIdx.x == 0) atomicAdd(&nupd[b], 1);  // instrumentation: super-pairs updated in this sweep
     float* __restrict__ Xb = X + (int64_t)b * batch_stride;
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256, 2) void supdate_kernel(float* __restrict__ X, 
         __syncthreads();
         cur ^= 1;
     }
-    ASVD_KERNEL_RELEASE();
+    ASVD_KERNEL_RELEASE(sc);
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -253,14 +253,14 @@ __global__ __launch_bounds__(256, 2) void supdate_kernel(float* __restrict__ X, 
 // v_mfma_f32_32x32x2_f32 (64 cycles each): 2.7x less matrix-pipe time for the kernel that holds 4/5 of the sweep's flops.
 // Bitwise it is not the fp32 MFMA result (different summation tree), numerically it is equivalent (tests compare both with fp64).
 constexpr int SUPDATE_SMEM_FLOATS = 2 * 32 * ULD;  // 33 KiB
-__device__ __forceinline__ void supdate_split_body(const BlockCtx& ctx, float* __restrict__ smem, float* __restrict__ X, int64_t panel_stride,
+__device__ __forceinline__ void supdate_split_body(const Sched& sc, const BlockCtx& ctx, float* __restrict__ smem, float* __restrict__ X, int64_t panel_stride,
                                                    int64_t batch_stride, int ns, int D, int R, int rows_per_wg, const float* __restrict__ Qfin,
                                                    const int* __restrict__ subact, const int* __restrict__ done, int* __restrict__ nupd) {
     const int chunk = ctx.bx, pair = ctx.by, b = ctx.bz, npairs = ctx.gy;
-    ASVD_KERNEL_ACQUIRE();
+    ASVD_KERNEL_ACQUIRE(sc);
     if (done[b] || !pair_active(subact, (int64_t)b * npairs + pair)) return;
     int S, T;
-    super_pair(ns, D - 1, pair, S, T);
+    super_pair(sc, ns, D - 1, pair, S, T);
     if (T >= ns) return;
     if (chunk == 0 && threadIdx.x == 0) atomicAdd(&nupd[b], 1);  // instrumentation: super-pairs updated in this sweep
     float* __restrict__ Xb = X + (int64_t)b * batch_stride;
@@ -344,15 +344,15 @@ __device__ __forceinline__ void supdate_split_body(const BlockCtx& ctx, float* _
         __syncthreads();
         cur ^= 1;
     }
-    ASVD_KERNEL_RELEASE();
+    ASVD_KERNEL_RELEASE(sc);
 }
 
-__global__ __launch_bounds__(256, 2) void supdate_split_kernel(float* __restrict__ X, int64_t panel_stride, int64_t batch_stride, int ns,
+__global__ __launch_bounds__(256, 2) void supdate_split_kernel(Sched sc, float* __restrict__ X, int64_t panel_stride, int64_t batch_stride, int ns,
                                                                int D, int R, int rows_per_wg, const float* __restrict__ Qfin,
                                                                const int* __restrict__ subact, const int* __restrict__ done, int* __restrict__ nupd) {
     __shared__ __attribute__((aligned(16))) float smem[SUPDATE_SMEM_FLOATS];
     const BlockCtx ctx{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, (int)gridDim.y, (int)gridDim.z};
-    supdate_split_body(ctx, smem, X, panel_stride, batch_stride, ns, D, R, rows_per_wg, Qfin, subact, done, nupd);
+    supdate_split_body(sc, ctx, smem, X, panel_stride, batch_stride, ns, D, R, rows_per_wg, Qfin, subact, done, nupd);
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -378,13 +378,13 @@ constexpr int SUPGRAM_OPND_WORDS = 8 * 2 * 3 * 64 * 4;             // updated pa
 constexpr int SUPGRAM_SMEM_FLOATS = 2 * SUPGRAM_AIMG_WORDS + SUPGRAM_OPND_WORDS;  // 159,744 B of the CU's 160 KiB
 static_assert(SUPGRAM_SMEM_FLOATS >= 24 * 1024, "the final reduction reuses the whole buffer");
 
-__global__ __launch_bounds__(512, 1) void supgram_kernel(float* __restrict__ X, int64_t panel_stride, int64_t batch_stride, int ns, int D,
+__global__ __launch_bounds__(512, 1) void supgram_kernel(Sched sc, float* __restrict__ X, int64_t panel_stride, int64_t batch_stride, int ns, int D,
                                                          int E, int R, int m_pad, int rows_per_wg, const float* __restrict__ Qfin,
                                                          const int* __restrict__ subact, float* __restrict__ Gx, const int* __restrict__ done,
                                                          int* __restrict__ nupd, int npairs) {
     extern __shared__ __attribute__((aligned(16))) float sg_smem[];
     const int chunk = blockIdx.x, quad = blockIdx.y, b = blockIdx.z, nsplit = gridDim.x;
-    ASVD_KERNEL_ACQUIRE();
+    ASVD_KERNEL_ACQUIRE(sc);
     if (done[b]) return;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5, c = lane & 31;
     // ---- quad geometry (uniform) ----
@@ -596,7 +596,7 @@ __global__ __launch_bounds__(512, 1) void supgram_kernel(float* __restrict__ X, 
         const int i = (reg & 3) + 8 * (reg >> 2) + 4 * (ln >> 5), j = ln & 31;
         Gx[((((int64_t)b * npairs + (np ? knxt1 : knxt0)) * nsplit + chunk) * 6 + (tt - 6 * np)) * 1024 + i * 32 + j] = v;
     }
-    ASVD_KERNEL_RELEASE();
+    ASVD_KERNEL_RELEASE(sc);
 }
 
 // ==================================================================================================
@@ -636,17 +636,17 @@ constexpr int DUAL_SMEM_FLOATS = EVD_SMEM_FLOATS(1) > SUPDATE_SMEM_FLOATS ? EVD_
 static_assert(DUAL_SMEM_FLOATS >= SGRAM6_SMEM_FLOATS, "LDS of the dual kernels");
 
 template <int EMODE>
-__global__ __launch_bounds__(256, 3) void dual_gram_kernel(SolveArgs sa, GramArgs ga) {
+__global__ __launch_bounds__(256, 3) void dual_gram_kernel(Sched sc, SolveArgs sa, GramArgs ga) {
     __shared__ __attribute__((aligned(16))) float smem[DUAL_SMEM_FLOATS];
     int id = blockIdx.x;
     const int nsolve = sa.gx * sa.gy;
     if (id < nsolve) {
         const BlockCtx ctx{id % sa.gx, id / sa.gx, 0, sa.gx, sa.gy, 1};
-        evd_body<EMODE, 1>(ctx, smem, nullptr, 0, nullptr, nullptr, sa.maxoff, sa.nrot, sa.done, sa.tol, sa.inner_sweeps, sa.nb, sa.step, sa.kb,
+        evd_body<EMODE, 1>(sc, ctx, smem, nullptr, 0, nullptr, nullptr, sa.maxoff, sa.nrot, sa.done, sa.tol, sa.inner_sweeps, sa.nb, sa.step, sa.kb,
                            sa.hist, nullptr, 0, sa.v3);
     } else {
         id -= nsolve;
         const BlockCtx ctx{id % ga.gx, ga.pair0 + (id / ga.gx) % ga.gy, id / (ga.gx * ga.gy), ga.gx, ga.npairs, ga.gz};
-        sgram6_body<0>(ctx, smem, ga.X, ga.panel_stride, ga.batch_stride, ga.ns, ga.D, ga.m_pad, ga.rows_per_split, ga.Gx, ga.done);
+        sgram6_body<0>(sc, ctx, smem, ga.X, ga.panel_stride, ga.batch_stride, ga.ns, ga.D, ga.m_pad, ga.rows_per_split, ga.Gx, ga.done);
     }
 }

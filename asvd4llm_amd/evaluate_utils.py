@@ -1,29 +1,29 @@
-"""evaluate_perplexity — the calibration perplexity used inside the sweep and the ppl-target search (evaluate_utils.py:90-115).
-Reproduced verbatim including the mean-over-(T-1)-times-T quirk.  Model forwards are ordinary
-PyTorch-ROCm execution; only linalg is hand-written in this build."""
+"""Calibration perplexity used inside the sweep and the ppl-target search (reference: evaluate_utils.py:90-115).
+
+Own implementation of the same quantity, including the reference's normalisation quirk: each sample
+contributes  mean-over-(T-1)-predicted-tokens x T  and the total is divided by  n x T  — not by the number of predicted tokens.
+The arithmetic keeps the reference's rounding points (mean cross entropy in the logits' dtype, up-cast, times T; one fp32
+vector sum over the samples; one exp), so the value is the reference's to the last bit on the same logits
+(tests/test_host_logic.py::test_perplexity_quirk_matches_reference).  Model forwards are ordinary PyTorch-ROCm execution."""
 import torch
-import torch.nn as nn
+import torch.nn.functional as F
+
+
+def _sample_nll(model, row, seqlen):
+    """T x (mean next-token cross entropy of one calibration row), fp32 scalar on the model's device"""
+    dev = model.device
+    logits = model(input_ids=row[:, :-1].to(dev))[0]
+    targets = row[:, 1:].to(dev).reshape(-1)
+    return F.cross_entropy(logits.reshape(-1, logits.size(-1)), targets).float() * seqlen
 
 
 @torch.no_grad()
 def evaluate_perplexity(model, dataset, limit):
-    """dataset: input ids tensor of shape [batch, sequence length]"""
-    nsamples, seqlen = dataset.size()
-    nlls = []
-    for i in range(nsamples):
-        if i == limit:
-            break
-        input_ids = dataset[i:i + 1, :-1].to(model.device)
-        labels = dataset[i:i + 1, 1:].contiguous()
-        logits = model(input_ids=input_ids)[0]
-        shift_logits = logits[:, :, :]
-        shift_labels = labels.to(model.device)
-        loss_fct = nn.CrossEntropyLoss()
-        loss = loss_fct(shift_logits.view(-1, shift_logits.size(-1)), shift_labels.view(-1))
-        neg_log_likelihood = loss.float() * seqlen
-        nlls.append(neg_log_likelihood)
-    ppl = torch.exp(torch.stack(nlls).sum() / (len(nlls) * seqlen))
-    return ppl.item()
+    """dataset: [n, T] token ids; the first `limit` rows are used (all of them when limit is negative or larger than n)."""
+    n_rows, seqlen = dataset.size()
+    n_used = n_rows if (limit < 0 or limit > n_rows) else limit
+    per_sample = torch.stack([_sample_nll(model, dataset[i:i + 1], seqlen) for i in range(n_used)])  # empty -> RuntimeError, as the reference
+    return torch.exp(per_sample.sum() / (n_used * seqlen)).item()
 
 
 @torch.no_grad()

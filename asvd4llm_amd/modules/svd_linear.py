@@ -25,8 +25,19 @@ def _strict():
 FUSED_FORWARD_MAX_TOKENS, FUSED_FORWARD_MAX_OUT = 16, 8192  # where the one-launch forward measured faster than two GEMM launches (tokens; in/out features)
 
 
-def _fused_forward_enabled():  # ASVD_FUSED_FORWARD=0 keeps every forward on the two nn.Linear launches
-    return os.environ.get("ASVD_FUSED_FORWARD", "1") != "0"
+def _fused_forward_enabled():
+    """The one-launch forward is OPT-IN (ASVD_FUSED_FORWARD=1, or `module.fused_forward = True` on one SVDLinear): it runs from padded
+    COPIES of the two factors, so it must only be used on weights that are no longer edited through `.data` (such edits do not bump
+    Parameter._version and cannot be seen without reading the weights; call `refresh_fused()` after one)."""
+    return os.environ.get("ASVD_FUSED_FORWARD", "0") == "1"
+
+
+def _plain_linear_without_hooks(mod):
+    """the fused launch replaces ALinear.forward / BLinear.forward: only legitimate when those are exactly nn.Linear.forward with nothing
+    hooked on (calibration hooks of a re-calibrated compressed model, wrappers, subclasses, global hooks must keep running)"""
+    import torch.nn.modules.module as _m
+    return (type(mod) is nn.Linear and not mod._forward_hooks and not mod._forward_pre_hooks and not mod._backward_hooks
+            and not _m._global_forward_hooks and not _m._global_forward_pre_hooks)
 
 
 class SVDLinear(nn.Module):
@@ -227,27 +238,36 @@ class SVDLinear(nn.Module):
         new_linear.to(dtype)
         return new_linear
 
-    def _fused_state(self):
-        """Padded copies of the two factors for the one-launch forward (ops.lowrank_pack), rebuilt when either weight changes."""
+    def refresh_fused(self):
+        """drop the padded factor copies of the one-launch forward (rebuilt on the next decode-sized call)"""
+        self._fused = None
+
+    def _fused_state(self, stream_id):
+        """Padded copies of the two factors for the one-launch forward (ops.lowrank_pack), rebuilt when either Parameter is replaced or
+        bumps its version, and ONE barrier/intermediate workspace PER STREAM (two launches in flight must not share barrier words)."""
         A, B = self.ALinear.weight, self.BLinear.weight
         key = (A.data_ptr(), A._version, B.data_ptr(), B._version, A.device)
         st = getattr(self, "_fused", None)
         if st is None or st[0] != key:
-            st = (key,) + ops.lowrank_pack(A.detach(), B.detach())
+            Ap, Bp, work = ops.lowrank_pack(A.detach(), B.detach())
+            st = (key, Ap, Bp, {stream_id: work})
             self._fused = st
-        return st[1:]
+        works = st[3]
+        if stream_id not in works:
+            works[stream_id] = torch.zeros_like(next(iter(works.values())))
+        return st[1], st[2], works[stream_id]
 
     def forward(self, inp):
         # compute USV^Tx + b  (svd_linear.py:105-109).  Decode-sized inputs (<= 16 fp16 tokens, in/out features <= 8192, no autograd): ONE
         # persistent launch that streams B and A once and keeps the r-wide intermediate on chip (K10, csrc/lowrank_forward.hip) — measured
         # 21 / 23 / 26 / 32 us at 1 / 2 / 4 / 16 tokens against 36 us for the two hipBLASLt launches at 4096 -> 1843 -> 4096.  Everywhere
         # else the reference's two GEMMs through nn.Linear: at par from 64 tokens on and on the 11008-wide MLP projections (DESIGN.md
-        # section 4 has the table).  ASVD_FUSED_FORWARD=0 turns the fused path off.
-        if (inp.is_cuda and inp.dtype == torch.float16 and self.BLinear.weight.dtype == torch.float16 and inp.shape[-1] % 64 == 0
+        # section 4 has the table).  Opt-in (ASVD_FUSED_FORWARD=1 / self.fused_forward): see _fused_forward_enabled.
+        if ((getattr(self, "fused_forward", False) or _fused_forward_enabled()) and inp.is_cuda and inp.dtype == torch.float16 and self.BLinear.weight.dtype == torch.float16 and inp.shape[-1] % 64 == 0
                 and 0 < inp.numel() // inp.shape[-1] <= FUSED_FORWARD_MAX_TOKENS and max(self.ALinear.out_features, inp.shape[-1]) <= FUSED_FORWARD_MAX_OUT
-                and self.BLinear.bias is None and _fused_forward_enabled()
+                and _plain_linear_without_hooks(self.ALinear) and _plain_linear_without_hooks(self.BLinear) and self.BLinear.bias is None
                 and not (torch.is_grad_enabled() and (inp.requires_grad or self.ALinear.weight.requires_grad or self.BLinear.weight.requires_grad))):
-            Ap, Bp, work = self._fused_state()
+            Ap, Bp, work = self._fused_state(torch.cuda.current_stream(inp.device).cuda_stream)
             x2d = inp.reshape(-1, inp.shape[-1])
             y = ops.lowrank_forward(x2d if x2d.is_contiguous() else x2d.contiguous(), Ap, Bp, self.ALinear.bias, work)
             return y.view(*inp.shape[:-1], y.shape[-1])

@@ -108,7 +108,15 @@ def calib_sensitivity_ppl(model, calib_loader, args, use_cache=True):
             multi = _multi_rank_module(raw_linear, param_ratio_candidates, args)
             if multi is not None:
                 setattr(info["father"], info["name"], multi)
-                ppls = evaluator.perplexities(info["full_name"], multi)
+                try:
+                    ppls = evaluator.perplexities(info["full_name"], multi)
+                except (RuntimeError, AssertionError, ValueError, TypeError) as e:
+                    # a model that rejects the R-fold batch (attention-mask batch checks of older architectures, out of memory on the
+                    # R x T x V logits of the 19-ratio kv sweep): the evaluator has restored its hooks and blocks; use the per-ratio path
+                    print(f"batched-ratio pass failed for {info['full_name']} ({type(e).__name__}: {e}); evaluating its ratios one by one")
+                    if torch.cuda.is_available():
+                        torch.cuda.empty_cache()
+                    ppls = None
                 if ppls is not None:
                     for param_ratio, ppl in zip(param_ratio_candidates, ppls):
                         local[info["full_name"]][param_ratio] = ppl

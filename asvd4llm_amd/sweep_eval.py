@@ -61,7 +61,7 @@ class MultiRankSVDLinear(nn.Module):
         self.ranks = list(ranks)
         rmax = B.shape[0]
         idx = torch.arange(rmax, device=B.device)
-        self.mask = torch.stack([(idx < r) for r in self.ranks]).to(B.dtype)  # [R, r_max]
+        self.mask = torch.stack([(idx < r) for r in self.ranks])  # [R, r_max] bool
 
     def forward(self, x):
         R = len(self.ranks)
@@ -70,7 +70,7 @@ class MultiRankSVDLinear(nn.Module):
             x = x.view(R, -1, x.shape[-1])
         assert x.shape[0] == R, f"MultiRankSVDLinear expects batch {R}, got {tuple(x.shape)}"
         z = nn.functional.linear(x, self.B)                       # [R, T, r_max]
-        y = nn.functional.linear(z * self.mask[:, None, :], self.A, self.bias)
+        y = nn.functional.linear(torch.where(self.mask[:, None, :], z, torch.zeros((), dtype=z.dtype, device=z.device)), self.A, self.bias)  # select, not multiply: an inf in a masked component must not become NaN
         return y.view(-1, y.shape[-1]) if flat else y
 
 

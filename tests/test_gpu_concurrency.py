@@ -1,0 +1,119 @@
+"""Concurrency contract of asvd_svd_batched (include/asvd_hip.h): calls from different host threads on different streams and
+workspaces give exactly the results — bit for bit, sweep for sweep — of the same calls made one after the other, also while a third
+stream keeps the GPU busy with foreign kernels (torch GEMMs) and while a call with a DIFFERENT pair schedule runs next to them.
+
+Round 2 kept the pair schedules in __constant__ symbols that every call rewrote; two concurrent calls with different shapes could
+overwrite each other's tables.  They are kernel arguments now (csrc/svd_jacobi.hip `Sched`); `test_mixed_schedules_concurrently`
+is the regression test for that."""
+import threading
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _problems(gpu, n_prob, m, n, seed):
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for _ in range(n_prob):
+        W = torch.randn(m, n, generator=g) * 0.02
+        W[:, torch.randperm(n, generator=g)[: max(1, n // 200)]] *= 20
+        out.append(W.to(gpu))
+    return out
+
+
+def _same(a, b):
+    """(U, S, V, infos) bit-identical, identical sweep counts"""
+    for x, y in zip(a[:3], b[:3]):
+        for t, u in zip(x, y):
+            if not torch.equal(t, u):
+                return False
+    return [(i.status, i.sweeps) for i in a[3]] == [(i.status, i.sweeps) for i in b[3]]
+
+
+def _run_concurrently(gpu, jobs, rounds, with_gemm_stream=True):
+    """jobs: list of problem lists.  Every job runs `rounds` times in its own host thread on its own stream while (optionally) another
+    thread streams torch GEMMs.  Returns per job the list of results of every round."""
+    from asvd4llm_amd import ops
+    results = [[] for _ in jobs]
+    errors = []
+    stop = threading.Event()
+    barrier = threading.Barrier(len(jobs) + (1 if with_gemm_stream else 0))
+
+    def svd_worker(i):
+        try:
+            st = torch.cuda.Stream(device=gpu)
+            with torch.cuda.stream(st):
+                barrier.wait()
+                for _ in range(rounds):
+                    results[i].append(ops.svd_batched(jobs[i]))
+            st.synchronize()
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+            try:
+                barrier.abort()
+            except Exception:  # noqa: BLE001
+                pass
+
+    def gemm_worker():
+        try:
+            st = torch.cuda.Stream(device=gpu)
+            with torch.cuda.stream(st):
+                a = torch.randn(4096, 4096, device=gpu, dtype=torch.float16)
+                b = torch.randn(4096, 4096, device=gpu, dtype=torch.float16)
+                barrier.wait()
+                while not stop.is_set():
+                    for _ in range(8):
+                        c = a @ b
+                        a = (c * 1e-2).clamp_(-1, 1)
+                    st.synchronize()
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    ts = [threading.Thread(target=svd_worker, args=(i,)) for i in range(len(jobs))]
+    tg = threading.Thread(target=gemm_worker) if with_gemm_stream else None
+    if tg:
+        tg.start()
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    stop.set()
+    if tg:
+        tg.join()
+    torch.cuda.synchronize()
+    assert not errors, errors
+    return results
+
+
+@pytest.mark.timeout(900)
+def test_two_threads_two_streams_8x4096_plus_gemm_stream(gpu):
+    """2 host threads x 2 streams x 8 x 4096^2 each + a third stream running torch GEMMs: bit-identical results AND identical sweep
+    counts against the serial runs."""
+    from asvd4llm_amd import ops
+    jobs = [_problems(gpu, 8, 4096, 4096, seed=101), _problems(gpu, 8, 4096, 4096, seed=202)]
+    ref = [ops.svd_batched(j) for j in jobs]
+    torch.cuda.synchronize()
+    assert all(i.status == 0 for r in ref for i in r[3])
+    res = _run_concurrently(gpu, jobs, rounds=3)
+    for i in range(2):
+        assert len(res[i]) == 3
+        for k, r in enumerate(res[i]):
+            assert _same(r, ref[i]), f"thread {i} round {k}: differs from the serial run (sweeps {[x.sweeps for x in r[3]]} vs {[x.sweeps for x in ref[i][3]]})"
+
+
+@pytest.mark.timeout(900)
+def test_mixed_schedules_concurrently(gpu):
+    """a grouped-schedule shape (5120 columns: 80 super-panels), an XOR shape (2048 columns), a padded-XOR shape (768 columns) and a
+    single-level one (192 columns) in flight together: each call carries its own schedule in its kernel arguments"""
+    from asvd4llm_amd import ops
+    jobs = [_problems(gpu, 2, 5120, 5120, seed=1), _problems(gpu, 4, 2048, 2048, seed=2), _problems(gpu, 6, 768, 768, seed=3),
+            _problems(gpu, 6, 300, 192, seed=4)]
+    ref = [ops.svd_batched(j) for j in jobs]
+    torch.cuda.synchronize()
+    assert all(i.status == 0 for r in ref for i in r[3])
+    res = _run_concurrently(gpu, jobs, rounds=4, with_gemm_stream=False)
+    for i in range(len(jobs)):
+        for k, r in enumerate(res[i]):
+            assert _same(r, ref[i]), f"job {i} round {k} differs from its serial run"

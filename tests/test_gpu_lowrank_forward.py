@@ -53,25 +53,47 @@ def test_fused_forward_vs_two_linears_and_fp64(gpu, T, K, r, N, with_bias):
 
 
 def test_svdlinear_forward_dispatch(gpu, monkeypatch):
-    """SVDLinear.forward takes the fused launch for decode-sized fp16 inputs and the two nn.Linear GEMMs otherwise; repacks
-    when a weight changes."""
+    """SVDLinear.forward takes the fused launch only when asked to (ASVD_FUSED_FORWARD=1 or module.fused_forward), for decode-sized
+    fp16 inputs, when ALinear/BLinear are plain hook-free nn.Linear; repacks when a weight changes; one workspace per stream."""
     from asvd4llm_amd.modules.svd_linear import SVDLinear
     torch.manual_seed(0)
     lin = nn.Linear(256, 192, bias=True).half().cuda()
     m = SVDLinear.from_linear(lin, 0.6, act_aware=False)
     x = torch.randn(2, 7, 256, device="cuda").half()
     with torch.no_grad():
-        monkeypatch.setenv("ASVD_FUSED_FORWARD", "0")
-        y_ref = m(x)  # the reference's two GEMMs
+        monkeypatch.delenv("ASVD_FUSED_FORWARD", raising=False)
+        y_ref = m(x)  # default: the reference's two GEMMs (ADVICE r2: the fused path is opt-in)
         assert getattr(m, "_fused", None) is None
-        monkeypatch.delenv("ASVD_FUSED_FORWARD")
-        y = m(x)  # default: decode-sized fp16 input -> one launch
+        monkeypatch.setenv("ASVD_FUSED_FORWARD", "1")
+        y = m(x)  # decode-sized fp16 input -> one launch
         assert getattr(m, "_fused", None) is not None and y.shape == (2, 7, 192)
         assert (y.float() - y_ref.float()).abs().max().item() <= 4e-3 * y_ref.float().abs().max().item()
         m.ALinear.weight.mul_(2.0)  # in-place edit bumps _version: the padded copy must follow
         y2 = m(x)
         b = m.ALinear.bias.float()
         assert torch.allclose(y2.float() - b, 2 * (y.float() - b), rtol=0, atol=8e-3 * y_ref.float().abs().max().item())
+        # a `.data` edit does not bump the version: documented, refresh_fused() is the remedy
+        m.ALinear.weight.data.mul_(0.5)
+        m.refresh_fused()
+        y3 = m(x)
+        assert torch.allclose(y3.float(), y.float(), rtol=0, atol=8e-3 * y_ref.float().abs().max().item())
+        # a second stream gets its own barrier / intermediate workspace
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            y4 = m(x)
+        st.synchronize()
+        assert len(m._fused[3]) == 2 and torch.equal(y4, y3)
+        # a forward hook on BLinear (e.g. a calibration hook of a re-calibrated compressed model) must keep firing: nn.Linear path
+        seen = []
+        h = m.BLinear.register_forward_hook(lambda mod, i, o: seen.append(1))
+        m(x)
+        assert seen == [1]
+        h.remove()
+        monkeypatch.delenv("ASVD_FUSED_FORWARD")
+        m.refresh_fused()
+        m.fused_forward = True  # per-module opt-in
+        m(x)
+        assert m._fused is not None
         big = torch.randn(300, 256, device="cuda").half()  # more tokens than the dispatch takes: nn.Linear path
         assert m(big).shape == (300, 192)
         m._fused = None

@@ -68,3 +68,43 @@ def default_args(**kw):
                 act_aware=True, sigma_fuse="UV", ppl_target=-1, param_ratio_target=0.8, kv_cache_ratio_target=-1)
     base.update(kw)
     return types.SimpleNamespace(**base)
+
+
+class WideBlock(nn.Module):
+    """one residual block around a 4096-wide square Linear (the BASELINE unit shape) between a tall and a wide projection"""
+
+    def __init__(self, d, w):
+        super().__init__()
+        self.up_proj, self.mid_proj, self.down_proj = nn.Linear(d, w, bias=False), nn.Linear(w, w, bias=False), nn.Linear(w, d, bias=True)
+
+    def forward(self, h):
+        return h + self.down_proj(torch.tanh(self.mid_proj(torch.nn.functional.silu(self.up_proj(h)))))
+
+
+class WideLM(nn.Module):
+    """TinyLM-shaped module tree whose block holds ONE width x width Linear (width 4096 in the sharded GPU test: the two-level sweeps,
+    the fused update + Gram kernel and the Cholesky-QR reduction all run) next to the small Linears of a TinyLM layer."""
+
+    def __init__(self, d=64, width=4096, f=176, vocab=50, seed=0):
+        super().__init__()
+        torch.manual_seed(seed)
+        self.config = types.SimpleNamespace(_name_or_path="golden/wide_lm", vocab_size=vocab)
+        self.model = nn.Module()
+        self.model.embed_tokens = nn.Embedding(vocab, d)
+        self.model.layers = nn.ModuleList([Layer(d, f), WideBlock(d, width)])
+        self.lm_head = nn.Linear(d, vocab, bias=False)
+        with torch.no_grad():
+            self.model.layers[1].mid_proj.weight.mul_(0.5)
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    def forward(self, input_ids=None, labels=None, **kw):
+        h = self.model.embed_tokens(input_ids)
+        for l in self.model.layers:
+            h = l(h)
+        logits = self.lm_head(h)
+        if labels is not None:
+            return (nn.functional.cross_entropy(logits.view(-1, logits.size(-1)), labels.reshape(-1)), logits)
+        return (logits,)
