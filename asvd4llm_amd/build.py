@@ -6,7 +6,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["svd_jacobi.hip", "aux_kernels.hip", "sigma_max.hip", "comm.hip", "lowrank_forward.hip"]
+SOURCES = ["svd_jacobi.hip", "evd_wave.hip", "aux_kernels.hip", "sigma_max.hip", "comm.hip", "lowrank_forward.hip"]
 LIB = os.path.join(HERE, "libasvd_hip.so")
 
 
@@ -15,15 +15,33 @@ def _newest_source_mtime():
     return max(os.path.getmtime(p) for p in paths)
 
 
+# per-source extra flags.  evd_wave.hip: the SLP vectoriser would pack the per-register FMAs of the wave-local eigen-solver into
+# v_pk_fma_f32, which cannot take the DPP operand its column rotations live on (csrc/jacobi_shared.h)
+EXTRA_FLAGS = {"evd_wave.hip": ["-fno-slp-vectorize"]}
+
+
 def build(force=False, verbose=True):
     if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _newest_source_mtime():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
-           "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES] + ["-ldl"]
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    common = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+    procs, objs = [], []
+    for src in SOURCES:  # one hipcc per translation unit, all at once
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        objs.append(obj)
+        cmd = common + EXTRA_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((src, subprocess.Popen(cmd)))
+    failed = [src for src, p in procs if p.wait() != 0]
+    if failed:
+        raise subprocess.CalledProcessError(1, f"hipcc -c {failed}")
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
     if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+        print(" ".join(link), flush=True)
+    subprocess.check_call(link)
     return LIB
 
 

@@ -73,8 +73,15 @@ static inline bool dtype_ok(int dt) { return dt == ASVD_F32 || dt == ASVD_F16 ||
 // it), which is more than the 5-9 % the overlap of stream groups buys: one stream group, no fences, is the default.
 // The flag travels with every launch (Sched::fence, a kernel ARGUMENT): nothing the kernels read is process-global state, so concurrent
 // calls with different settings cannot disturb each other.
-#define ASVD_KERNEL_ACQUIRE(sc) do { if ((sc).fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); } while (0)
-#define ASVD_KERNEL_RELEASE(sc) do { if ((sc).fence) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); } while (0)
+// fence bits: 1 = acquire at kernel start, 2 = release at kernel end (ASVD_FENCE=1 means both; 2 / 3 = acquire / release only, experiments)
+#define ASVD_KERNEL_ACQUIRE(sc) do { if ((sc).fence & 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); } while (0)
+#define ASVD_KERNEL_RELEASE(sc) do { if ((sc).fence & 2) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); } while (0)
+
+// ---- small control words rewritten between launches (activity flags, done flags, pair lists) ----------------------------------
+// Read through the VECTOR path with an agent-scope load (global_load ... sc1: served by L2, never by the scalar data cache or this
+// CU's L1).  A plain `flags[i]` with a wave-uniform index is compiled to s_load_dword, i.e. it goes through the scalar cache that
+// several CUs share; these words are rewritten at the same address every step of the sweep.
+__device__ __forceinline__ int ld_flag(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // ---- wave / block reductions ---------------------------------------------------------------
 __device__ __forceinline__ float wave_reduce_max(float v) {

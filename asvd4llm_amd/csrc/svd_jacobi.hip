@@ -14,6 +14,7 @@
 //   evd_kernel     two-sided Jacobi on G in LDS (fp32), eigenvalues sorted descending -> Q (64x64)
 //   update_kernel  [X_I X_J] <- [X_I X_J] * Q  over all R rows — v_mfma_f32_32x32x2_f32, K = 64
 #include "common.h"
+#include "jacobi_shared.h"
 #include <vector>
 #include <cmath>
 #include <cstring>
@@ -24,103 +25,8 @@
 #include <type_traits>
 
 namespace {
+using namespace asvdk;
 
-constexpr int PB = 32;       // panel width
-constexpr int PW = 2 * PB;   // pair width
-
-// Pair ordering of one Jacobi sweep: nb (even) panels, nb-1 steps, pair k in [0, nb/2) of step `step`.
-//  * default: XOR ordering over the panel count padded to a power of two P — step d = step+1 (d = 1..P-1) pairs every panel i
-//    with i^d; pairs that touch a padding panel (J >= nb) are skipped.  Steps 1, 2, 3, ... meet the nearest neighbours first,
-//    which on the norm-sorted, Cholesky-preconditioned matrices is where the coupling is: measured 10 -> 8 sweeps at 4096^2
-//    and 14 -> 9 on the row-scaled wide layers against the round-robin tournament (CPU prototype at n = 1024: 8 -> 6).
-//  * c_pair_order = 0 (ASVD_ORDER=rr, for A/B measurements): round-robin tournament (circle method), nb-1 steps of nb/2 pairs.
-// Everything a kernel needs to know about the call's pair schedules travels BY VALUE in its argument list (84 bytes of kernarg): round 2
-// kept these in __constant__ symbols rewritten by every call, so two concurrent calls with different shapes (a grouped 13B schedule next
-// to an XOR one) overwrote each other's tables mid-flight.
-//   pair_order  1 XOR (default), 0 round-robin (ASVD_ORDER=rr)
-//   super_order 1 XOR, 0 round-robin tournament, 2 grouped (below);  gm / gpair: group pairs per round / {gA, gB} of the grouped schedule
-//   evd_pairs   phase pairs per inner sweep of the 64x64 eigen-solve: 32 = one full odd-even cycle (ASVD_EVD_PAIRS, experiments)
-//   fence       agent-scope acquire / release at kernel boundaries (stream groups, common.h)
-struct Sched {
-    int pair_order, super_order, evd_pairs, fence, gm;
-    signed char gpair[8][4][2];
-};
-static Sched default_sched() {
-    Sched sc;
-    std::memset(&sc, 0, sizeof(sc));
-    sc.pair_order = 1;
-    sc.super_order = 1;
-    sc.evd_pairs = 32;
-    return sc;
-}
-
-__device__ __forceinline__ void rr_pair(const Sched& sc, int nb, int step, int k, int& I, int& J) {
-    if (sc.pair_order) {  // pair space padded to the next power of two: callers skip pairs with J >= nb
-        const int d = step + 1;
-        const int h = 31 - __clz(d);  // highest set bit of d: i < i^d  <=>  bit h of i is clear
-        I = ((k >> h) << (h + 1)) | (k & ((1 << h) - 1));
-        J = I ^ d;
-        return;
-    }
-    const int a = (k == 0) ? 0 : 1 + (k - 1 + step) % (nb - 1);
-    const int pb = nb - 1 - k;
-    const int b = 1 + (pb - 1 + step) % (nb - 1);
-    I = a < b ? a : b;
-    J = a < b ? b : a;
-}
-
-// Pair ordering at the SUPER-PANEL level of the two-level sweeps (twolevel.h): XOR like the panel level when the super-panel count is a
-// power of two; otherwise (c_super_order = 0) the round-robin tournament over ns (+1 if odd) super-panels — a padded XOR schedule runs
-// P-1 super-steps with many empty slots (13B: 80 super-panels -> 127 steps, 37 % empty), the tournament ns-1 full ones.  Pairs with
-// T >= ns (padding / the bye) are skipped by the callers.  `step` counts from 0.
-// c_super_order = 2: GROUPED schedule for counts that are a multiple of 16 but not a power of two: XOR (d = 1..15) inside groups of 16
-// super-panels, then the group pairs of a round-robin tournament over the groups, each for the 16 offsets s (A_i <-> B_{i ^ s}): the
-// nearest-neighbour-first order of the XOR schedule inside a group and inside a group pair, and 15 + rounds * 16 super-steps with
-// (almost) every slot filled instead of a padded XOR schedule.  sc.gpair[round][m] = {gA, gB} (gA < gB), sc.gm = pairs per round.
-__device__ __forceinline__ void super_pair(const Sched& sc, int ns, int step, int k, int& S, int& T) {
-    if (sc.super_order == 1) {
-        const int d = step + 1;
-        const int h = 31 - __clz(d);
-        S = ((k >> h) << (h + 1)) | (k & ((1 << h) - 1));
-        T = S ^ d;
-        return;
-    }
-    if (sc.super_order == 2) {
-        if (step < 15) {
-            if (k >= ns / 2) { S = ns; T = ns; return; }
-            const int d = step + 1, h = 31 - __clz(d), g = k >> 3, kk = k & 7;
-            S = 16 * g + (((kk >> h) << (h + 1)) | (kk & ((1 << h) - 1)));
-            T = S ^ d;
-            return;
-        }
-        const int r = (step - 15) >> 4, sft = (step - 15) & 15, m = k >> 4, i = k & 15;
-        if (m >= sc.gm) { S = ns; T = ns; return; }
-        S = 16 * sc.gpair[r][m][0] + i;
-        T = 16 * sc.gpair[r][m][1] + (i ^ sft);
-        return;
-    }
-    const int n = ns + (ns & 1);  // even player count; player n-1 is the bye when ns is odd
-    if (k >= n / 2) { S = ns; T = ns; return; }
-    const int a = (k == 0) ? 0 : 1 + (k - 1 + step) % (n - 1);
-    const int pb = n - 1 - k;
-    const int b = 1 + (pb - 1 + step) % (n - 1);
-    S = a < b ? a : b;
-    T = a < b ? b : a;
-}
-
-// Pair handled by a workgroup: from the schedule (plist == nullptr) or, in sparse sweeps, from an explicit per-problem list of
-// marked pairs (code = I << 16 | J, -1 = empty slot).  Returns false when there is nothing to do for this slot.
-__device__ __forceinline__ bool get_pair(const Sched& sc, const int* __restrict__ plist, int list_stride, int b, int nb, int step, int pair, int& I, int& J) {
-    if (plist) {
-        const int code = plist[b * list_stride + pair];
-        if (code < 0) return false;
-        I = code >> 16;
-        J = code & 0xffff;
-        return true;
-    }
-    rr_pair(sc, nb, step, pair, I, J);
-    return J < nb;  // padding pair of the XOR ordering
-}
 
 // --------------------------------------------------------------------------------------------------
 // pack: oriented, scaled, fp32 copy of the input into panel layout.  X must be zero-filled before.
@@ -194,7 +100,7 @@ __global__ __launch_bounds__(256) void gram_kernel(Sched sc, const float* __rest
     const int split = blockIdx.x, pair = blockIdx.y, b = blockIdx.z;
     const int nsplit = gridDim.x, npairs = gridDim.y;
     ASVD_KERNEL_ACQUIRE(sc);
-    if (done[b]) return;
+    if (ld_flag(done + b)) return;
     int I, J;
     if (!get_pair(sc, plist, list_stride, b, nb, step, pair, I, J)) return;
     const float* __restrict__ XI = X + (int64_t)b * batch_stride + (int64_t)I * panel_stride;
@@ -291,24 +197,6 @@ __global__ __launch_bounds__(256) void gram_kernel(Sched sc, const float* __rest
 // 2x2 blocks {row pairs 2ty, 2ty+1} x {column pairs 2tx, 2tx+1} and rows 4ty..4ty+3 of those column pairs of Q.
 // Every thread recomputes the four rotations it needs from the OLD matrix (G is ping-ponged between two LDS images), so
 // a step costs ONE barrier and no serialized "compute rotations" phase.  Pair tables are precomputed in LDS.
-__device__ __forceinline__ void jacobi_rot(float a, float d, float b, float& c, float& s, float& t) {
-    // branch-free: b == 0 gives zeta = +-inf -> t = 0, c = 1, s = 0 by itself; a or d <= 0 (empty column) is masked at the end
-    const float cosv = b * __builtin_amdgcn_rsqf(a) * __builtin_amdgcn_rsqf(d);  // |cos| of the two columns
-    const float zeta = (d - a) * __builtin_amdgcn_rcpf(2.0f * b);
-    float tt = copysignf(1.0f, zeta) * __builtin_amdgcn_rcpf(fabsf(zeta) + __builtin_amdgcn_sqrtf(fmaf(zeta, zeta, 1.0f)));
-    float cc = __builtin_amdgcn_rsqf(fmaf(tt, tt, 1.0f));
-    float ss = tt * cc;
-    // unit-norm correction: delta = c^2 + s^2 - 1 via FMAs is accurate far below one ulp, so after scaling by (1 - delta/2)
-    // only the unbiased rounding of c and s themselves remains (no systematic norm drift; the hardware rcp/rsq
-    // approximations above only perturb the ANGLE, which the next visit corrects).
-    const float hd = 0.5f * fmaf(ss, ss, fmaf(cc, cc, -1.0f));
-    cc = fmaf(-cc, hd, cc);
-    ss = fmaf(-ss, hd, ss);
-    const bool rot = fabsf(cosv) > 1e-8f;  // false for NaN (zero / negative diagonal) as well
-    c = rot ? cc : 1.0f;
-    s = rot ? ss : 0.0f;
-    t = rot ? tt : 0.0f;
-}
 
 // LDS image: element (row r, position c) lives at r*64 + pcol(c), pcol(c) = (c&1)*32 + (c>>1)  ("plane-major" columns:
 // even positions in banks 0..31 of a row, odd positions in the next 32).  With ONE column pair per lane (32 lanes of a
@@ -334,17 +222,6 @@ __device__ __forceinline__ int pcol(int c) { return ((c & 1) << 5) | (c >> 1); }
 //   MODE 0 is the single-level solve (Gram partials of gram_kernel); with v3.Gd32 set (internal step d = 1 of a two-level sweep) it
 //           also stores the two transformed diagonal blocks as the fresh carried blocks of its panels.
 // A solve that does not rotate (all couplings below tol) leaves everything in place: identity Q, no sort.
-struct EvdV3 {
-    int ns;               // super-panels per problem
-    int nbpan;            // 32-column panels per problem (stride of Gd32)
-    const float* Gx6;     // sgram6 partials [slot][nsplit][6][32*32]
-    int nsplit6;
-    float* Gd32;          // carried diagonal blocks [problem][panel][32*32]
-    float* Q0;            // [slot][2][64*64]
-    float* D0;            // [slot][4][32*32]
-    float* Qfin;          // [slot][128*128]
-    int* subact;          // [slot][4]: step 0 sub-pairs 0,1; step 1 sub-pairs 0,1
-};
 
 // transformed diagonal 32x32 blocks of the (sorted, rescaled) matrix left in LDS: block h = sorted positions 32h..32h+31
 __device__ __forceinline__ void store_diag_blocks(const float* G, const int* rnk, const float* cscale, float* d0, float* d1, int tid) {
@@ -384,7 +261,7 @@ __device__ __forceinline__ void evd_body(const Sched& sc, const BlockCtx& ctx, f
 
     const int pair = MODE ? (ctx.bx >> 1) : ctx.bx, b = ctx.by, npairs = MODE ? (ctx.gx >> 1) : ctx.gx;
     ASVD_KERNEL_ACQUIRE(sc);
-    if (done[b]) return;
+    if (ld_flag(done + b)) return;
     // the eigen-solve is a dependent chain of short VALU/LDS phases on every group's critical path: let its waves win the issue
     // arbitration against the matrix-pipe-bound gram/update waves of the other stream groups that share the SIMD
     __builtin_amdgcn_s_setprio(3);
@@ -845,7 +722,7 @@ __global__ __launch_bounds__(256) void update_kernel(Sched sc, float* __restrict
                                                      const int* __restrict__ done, const int* __restrict__ plist, int list_stride) {
     const int chunk = blockIdx.x, pair = blockIdx.y, b = blockIdx.z, npairs = gridDim.y;
     ASVD_KERNEL_ACQUIRE(sc);
-    if (done[b] || !active[b * npairs + pair]) return;
+    if (ld_flag(done + b) || !ld_flag(active + b * npairs + pair)) return;
     int I, J;
     if (!get_pair(sc, plist, list_stride, b, nb, step, pair, I, J)) return;
     float* __restrict__ XI = X + (int64_t)b * batch_stride + (int64_t)I * panel_stride;
@@ -923,7 +800,7 @@ __global__ __launch_bounds__(256) void panel_sumsq_kernel(Sched sc, const float*
                                                           int m_pad, int n_pad, float* __restrict__ dn, const int* __restrict__ done) {
     const int I = blockIdx.x, b = blockIdx.y, c = threadIdx.x & 31, g = threadIdx.x >> 5;
     ASVD_KERNEL_ACQUIRE(sc);
-    if (done[b]) return;
+    if (ld_flag(done + b)) return;
     const float* __restrict__ P = X + (int64_t)b * batch_stride + (int64_t)I * panel_stride;
     float s = 0.0f;
     for (int r = g; r < m_pad; r += 8) { const float x = P[(int64_t)r * PB + c]; s = fmaf(x, x, s); }
@@ -952,7 +829,7 @@ __global__ __launch_bounds__(256) void fullcheck_kernel(Sched sc, const float* _
     // (An XCD-aware tile order — the workgroups of one XCD walking a contiguous run of tiles — was measured SLOWER: 66.8 vs 55.6 ms for
     // the three snapshots of 32 problems; the plain order stays.)
     const int ig = blockIdx.x, jg = blockIdx.y, b = blockIdx.z;
-    if (ig > jg || done[b]) return;
+    if (ig > jg || ld_flag(done + b)) return;
     ASVD_KERNEL_ACQUIRE(sc);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int J = jg * 4 + w;
@@ -1110,7 +987,7 @@ __global__ __launch_bounds__(256, 1) void upgram_kernel(float* __restrict__ X, i
                                                         const float* __restrict__ Qbuf, const int* __restrict__ active,
                                                         float* __restrict__ Gpart, const int* __restrict__ done) {
     const int chunk = blockIdx.x, quad = blockIdx.y, b = blockIdx.z, nsplit = gridDim.x, npairs = nb >> 1;
-    if (done[b]) return;
+    if (ld_flag(done + b)) return;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int h = lane >> 5, c = lane & 31;
     // ---- quad geometry (uniform per workgroup) ----
@@ -1123,7 +1000,7 @@ __global__ __launch_bounds__(256, 1) void upgram_kernel(float* __restrict__ X, i
     // current pairs (step d): A = slots (0,1), B = slots (2,3); the lower-index member has bit h1 clear
     const bool swapB = (P2 >> h1) & 1;
     const int kA = remove_bit(P0, h1), kB = remove_bit(swapB ? P3 : P2, h1);
-    const bool actA = active[b * npairs + kA] != 0, actB = active[b * npairs + kB] != 0;
+    const bool actA = ld_flag(active + b * npairs + kA) != 0, actB = ld_flag(active + b * npairs + kB) != 0;
     // next pairs (step e): C = slots (0,2), D = slots (1,3)
     const int he = 31 - __clz(e);
     const bool swapD = (P1 >> he) & 1;
@@ -2240,8 +2117,8 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
     {
         sc.pair_order = pair_order_xor() ? 1 : 0;
         // agent-scope fences at kernel boundaries: on with several stream groups (common.h); ASVD_FENCE=0/1 overrides (experiments)
-        sc.fence = stream_groups_for(batch) > 1 ? 1 : 0;
-        if (getenv("ASVD_FENCE")) sc.fence = atoi(getenv("ASVD_FENCE")) ? 1 : 0;
+        sc.fence = stream_groups_for(batch) > 1 ? 3 : 0;
+        if (getenv("ASVD_FENCE")) { const int f = atoi(getenv("ASVD_FENCE")); sc.fence = f == 1 ? 3 : (f == 2 ? 1 : (f == 3 ? 2 : 0)); }
         sc.super_order = super_grouped_for(p) ? 2 : (super_rr_for(p) ? 0 : 1);
         if (sc.super_order == 2) set_group_table(sc, p.ns);
         sc.evd_pairs = getenv("ASVD_EVD_PAIRS") ? std::max(1, std::min(64, atoi(getenv("ASVD_EVD_PAIRS")))) : PW / 2;
@@ -2317,6 +2194,8 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
     std::vector<int> sl_off((size_t)MAXG * (nsteps > 0 ? nsteps : 1), 0), sl_cnt((size_t)MAXG * (nsteps > 0 ? nsteps : 1), 0);
     int* hist_dev = nullptr;
     if (getenv("ASVD_DEBUG_HIST")) { ASVD_HIP_CHECK(hipMalloc(&hist_dev, 10 * sizeof(int))); }
+    // 64x64 eigen-solves: the wave-local solver (evd_wave.hip) unless ASVD_EVDW=0 (the LDS solver of rounds 1-2, also used for the histogram)
+    const bool evd_wave = !hist_dev && !(getenv("ASVD_EVDW") && atoi(getenv("ASVD_EVDW")) == 0);
     for (; sweep < max_sweeps; ++sweep) {
         const auto sweep_t0 = std::chrono::steady_clock::now();
         if (hist_dev) ASVD_HIP_CHECK(hipMemsetAsync(hist_dev, 0, 10 * sizeof(int), st));
@@ -2458,8 +2337,12 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
                     }
                     {
                         ProfScope ps(2, s2);
-                        evd_kernel<0, 0><<<dim3(slots, nbg), 256, 0, s2>>>(sc, Gg, nsp, Qg, ag, maxoff + b0, nrot + b0, done + b0, tol, inner_sweeps,
-                                                                           p.nb, step, kb, hist_dev, pl, slots, EvdV3{});
+                        if (evd_wave)
+                            launch_evdw0(false, slots, nbg, s2, sc, Gg, nsp, Qg, ag, maxoff + b0, nrot + b0, done + b0, tol, inner_sweeps, p.nb, step, kb,
+                                         pl, slots, EvdV3{});
+                        else
+                            evd_kernel<0, 0><<<dim3(slots, nbg), 256, 0, s2>>>(sc, Gg, nsp, Qg, ag, maxoff + b0, nrot + b0, done + b0, tol, inner_sweeps,
+                                                                               p.nb, step, kb, hist_dev, pl, slots, EvdV3{});
                     }
                     {
                         ProfScope ps(7, s2);
@@ -2482,8 +2365,15 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
                         v3.ns = p.ns;
                         v3.nbpan = p.nb;
                         v3.Gd32 = Gd32g;
-                        evd_kernel<0, 1><<<dim3(p.npairs, nbg), 256, 0, s2>>>(sc, Gg, ns_here, Qg, ag, maxoff + b0, nrot + b0, done + b0, tol,
-                                                                               inner_sweeps, p.nb, step, kb, hist_dev, nullptr, 0, v3);
+                        if (evd_wave)
+                            launch_evdw0(true, p.npairs, nbg, s2, sc, Gg, ns_here, Qg, ag, maxoff + b0, nrot + b0, done + b0, tol, inner_sweeps, p.nb, step,
+                                         kb, nullptr, 0, v3);
+                        else
+                            evd_kernel<0, 1><<<dim3(p.npairs, nbg), 256, 0, s2>>>(sc, Gg, ns_here, Qg, ag, maxoff + b0, nrot + b0, done + b0, tol,
+                                                                                   inner_sweeps, p.nb, step, kb, hist_dev, nullptr, 0, v3);
+                    } else if (evd_wave) {
+                        launch_evdw0(false, p.npairs, nbg, s2, sc, Gg, ns_here, Qg, ag, maxoff + b0, nrot + b0, done + b0, tol, inner_sweeps, p.nb, step, kb,
+                                     nullptr, 0, EvdV3{});
                     } else {
                         evd_kernel<0, 0><<<dim3(p.npairs, nbg), 256, 0, s2>>>(sc, Gg, ns_here, Qg, ag, maxoff + b0, nrot + b0, done + b0, tol,
                                                                                inner_sweeps, p.nb, step, kb, hist_dev, nullptr, 0, EvdV3{});
@@ -2631,10 +2521,14 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
                     }
                     {
                         ProfScope ps(2, s2);
-                        evd_kernel<1, 1><<<dim3(2 * p.npairs_s, nbg), 256, 0, s2>>>(sc, nullptr, 0, nullptr, nullptr, maxoff + b0, nrot + b0, done + b0, tol,
-                                                                                   inner_sweeps, p.nb, D - 1, kb, hist_dev, nullptr, 0, v3);
-                        evd_kernel<2, 1><<<dim3(2 * p.npairs_s, nbg), 256, 0, s2>>>(sc, nullptr, 0, nullptr, nullptr, maxoff + b0, nrot + b0, done + b0, tol,
-                                                                                   inner_sweeps, p.nb, D - 1, kb, hist_dev, nullptr, 0, v3);
+                        if (evd_wave) {  // both inner steps of every super-pair in one launch, one wave per 64x64 solve (evd_wave.hip)
+                            launch_evdw12(p.npairs_s, nbg, s2, sc, maxoff + b0, nrot + b0, done + b0, tol, inner_sweeps, p.nb, D - 1, kb, v3);
+                        } else {
+                            evd_kernel<1, 1><<<dim3(2 * p.npairs_s, nbg), 256, 0, s2>>>(sc, nullptr, 0, nullptr, nullptr, maxoff + b0, nrot + b0, done + b0,
+                                                                                       tol, inner_sweeps, p.nb, D - 1, kb, hist_dev, nullptr, 0, v3);
+                            evd_kernel<2, 1><<<dim3(2 * p.npairs_s, nbg), 256, 0, s2>>>(sc, nullptr, 0, nullptr, nullptr, maxoff + b0, nrot + b0, done + b0,
+                                                                                       tol, inner_sweeps, p.nb, D - 1, kb, hist_dev, nullptr, 0, v3);
+                        }
                     }
                     {
                         ProfScope ps(gram_out ? 8 : 3, s2);
@@ -3023,6 +2917,15 @@ int asvd_test_supgram(float* X, int64_t panel_stride, int64_t batch_stride, int 
     ASVD_HIP_CHECK(hipFuncSetAttribute((const void*)supgram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SUPGRAM_SMEM_FLOATS * sizeof(float))));
     supgram_kernel<<<dim3(nchunks, (2 * npairs) / 4, batch), 512, SUPGRAM_SMEM_FLOATS * sizeof(float), st>>>(sc, X, panel_stride, batch_stride, ns, D, E, R, m_pad,
                                                                                                            rows_per_wg, Qfin, subact, Gx, done, nupd, npairs);
+    ASVD_HIP_CHECK(hipGetLastError());
+    return ASVD_OK;
+}
+
+// Test hook (tests/test_gpu_evd_wave.py): the wave-local 64x64 eigen-solver alone.  G: [batch][64][64] symmetric (device); outputs
+// Q [batch][64][64] (unsorted, unscaled), diag / rnk / cs [batch][64], Gout [batch][64][64] (the image the sweeps leave), meas [batch][2].
+int asvd_test_evd_wave(const float* G, int batch, int sweeps, float* Q, float* diag, int* rnk, float* cs, float* Gout, float* meas, void* stream) {
+    if (!G || !Q || !diag || !rnk || !cs || !Gout || !meas || batch < 1 || sweeps < 0) return ASVD_E_BADARG;
+    launch_evdw_test(batch, (hipStream_t)stream, G, sweeps, Q, diag, rnk, cs, Gout, meas);
     ASVD_HIP_CHECK(hipGetLastError());
     return ASVD_OK;
 }

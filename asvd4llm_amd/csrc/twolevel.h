@@ -24,7 +24,7 @@ constexpr int SP = 2 * SW;   // super-pair width
 // a super-pair is updated when any of its four eigen-solves rotated
 __device__ __forceinline__ bool pair_active(const int* __restrict__ subact, int64_t slot) {
     const int* sa = subact + slot * 4;
-    return (sa[0] | sa[1] | sa[2] | sa[3]) != 0;
+    return (ld_flag(sa) | ld_flag(sa + 1) | ld_flag(sa + 2) | ld_flag(sa + 3)) != 0;
 }
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -53,7 +53,7 @@ __device__ __forceinline__ void sgram6_body(const Sched& sc, const BlockCtx& ctx
     const int split = ctx.bx, pair = ctx.by, b = ctx.bz;
     const int nsplit = ctx.gx, npairs = ctx.gy;
     ASVD_KERNEL_ACQUIRE(sc);
-    if (done[b]) return;
+    if (ld_flag(done + b)) return;
     int S, T;
     super_pair(sc, ns, D - 1, pair, S, T);
     if (T >= ns) return;
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void supdate_kernel(Sched sc, float* __rest
                                                          const int* __restrict__ subact, const int* __restrict__ done, int* __restrict__ nupd) {
     const int chunk = blockIdx.x, pair = blockIdx.y, b = blockIdx.z, npairs = gridDim.y;
     ASVD_KERNEL_ACQUIRE(sc);
-    if (done[b] || !pair_active(subact, (int64_t)b * npairs + pair)) return;
+    if (ld_flag(done + b) || !pair_active(subact, (int64_t)b * npairs + pair)) return;
     int S, T;
     super_pair(sc, ns, D - 1, pair, S, T);
     if (T >= ns) return;
@@ -258,7 +258,7 @@ __device__ __forceinline__ void supdate_split_body(const Sched& sc, const BlockC
                                                    const int* __restrict__ subact, const int* __restrict__ done, int* __restrict__ nupd) {
     const int chunk = ctx.bx, pair = ctx.by, b = ctx.bz, npairs = ctx.gy;
     ASVD_KERNEL_ACQUIRE(sc);
-    if (done[b] || !pair_active(subact, (int64_t)b * npairs + pair)) return;
+    if (ld_flag(done + b) || !pair_active(subact, (int64_t)b * npairs + pair)) return;
     int S, T;
     super_pair(sc, ns, D - 1, pair, S, T);
     if (T >= ns) return;
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(512, 1) void supgram_kernel(Sched sc, float* __rest
     extern __shared__ __attribute__((aligned(16))) float sg_smem[];
     const int chunk = blockIdx.x, quad = blockIdx.y, b = blockIdx.z, nsplit = gridDim.x;
     ASVD_KERNEL_ACQUIRE(sc);
-    if (done[b]) return;
+    if (ld_flag(done + b)) return;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5, c = lane & 31;
     // ---- quad geometry (uniform) ----
     const int h1 = 31 - __clz(D);

@@ -255,6 +255,11 @@ int asvd_test_supgram(float* X, int64_t panel_stride, int64_t batch_stride, int 
  * else XOR).  out_dev: device int[out_capacity] >= nsteps * npairs; out[step * npairs + k] = (S << 16) | T or -1 (empty slot).
  * tests/test_gpu_twolevel.py only. */
 int asvd_test_super_schedule(int ns, int grouped, int* out_dev, int out_capacity, int* nsteps_out, int* npairs_out);
+/* Test hook: the wave-local 64x64 symmetric eigen-solver of the sweeps (csrc/evd_wave.h) alone, one wave per matrix, `sweeps` full
+ * inner sweeps.  G [batch][64][64] symmetric; Q [batch][64][64] accumulated rotations (column = position, unsorted, unscaled);
+ * diag / rnk / cs [batch][64]: eigenvalue estimate, descending-order rank and 1/|q_c| of every position; Gout: the image after the
+ * sweeps; meas [batch][2]: the two off-diagonal measures of the input.  tests/test_gpu_evd_wave.py only. */
+int asvd_test_evd_wave(const float* G, int batch, int sweeps, float* Q, float* diag, int* rnk, float* cs, float* Gout, float* meas, void* stream);
 /* counts_host: long long[3] = {32-column panel-pair visits (one 64x64 eigen-solve each), pairs actually rotated, 128-column
  * super-pairs updated by the two-level sweeps (one 128-wide update pass over the rows each)} summed over the sweeps and problems of
  * the last profiled call: the algorithmic byte counts of the streaming kernels follow from these. */

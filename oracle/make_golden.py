@@ -368,10 +368,73 @@ def gen_fisher():
     np.savez_compressed(os.path.join(OUT, "fisher.npz"), **out)
 
 
+def gen_hf_export():
+    """F-export: what the reference's exported-repo loaders expect.  The reference's OWN model classes
+    (huggingface_repos/modeling_asvd_{llama,opt}.py) are instantiated on tiny configs with a truncation_ranks dict; the state-dict keys /
+    shapes they create, the config attribute they read, and the auto_map / architectures entries build_asvd_repo.py:66-88 writes are the
+    fixture.  Under the installed transformers (5.x; the reference pins 4.41) ASVDLlamaConfig lacks three attributes newer LlamaModel
+    code reads: the error is recorded, then the attributes are taken from a stock LlamaConfig of the same shape (data on the config
+    INSTANCE; no reference file is touched) so that the class can still be instantiated."""
+    import ast
+    import importlib
+    import transformers
+    out = {"transformers_version": transformers.__version__, "families": {}}
+    # auto_map / architectures literals, read out of the reference's exporter with ast (not retyped)
+    src = open(os.path.join(REF, "huggingface_repos", "build_asvd_repo.py")).read()
+    tree = ast.parse(src)
+    assigns = {}
+    for node in ast.walk(tree):
+        if isinstance(node, ast.If) and isinstance(node.test, ast.Compare) and isinstance(node.test.left, ast.Constant) and node.test.left.value in ("opt", "llama"):
+            fam = node.test.left.value
+            for st in node.body:
+                if isinstance(st, ast.Assign) and isinstance(st.targets[0], ast.Subscript):
+                    key = st.targets[0].slice.value if isinstance(st.targets[0].slice, ast.Constant) else None
+                    if key in ("auto_map", "architectures"):
+                        assigns.setdefault(fam, {})[key] = ast.literal_eval(st.value)
+    assert set(assigns) == {"opt", "llama"} and all(set(v) == {"auto_map", "architectures"} for v in assigns.values()), assigns
+    cases = {
+        "llama": ("configuration_asvd_llama", "ASVDLlamaConfig", "modeling_asvd_llama", "ASVDLlamaForCausalLM", "LlamaConfig",
+                  dict(hidden_size=32, intermediate_size=64, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=2, vocab_size=64,
+                       max_position_embeddings=64),
+                  {"model.layers.0.self_attn.q_proj": 8, "model.layers.1.mlp.down_proj": 12, "lm_head": 10}),
+        "opt": ("configuration_asvd_opt", "ASVDOPTConfig", "modeling_asvd_opt", "ASVDOPTForCausalLM", "OPTConfig",
+                dict(hidden_size=32, ffn_dim=64, num_hidden_layers=2, num_attention_heads=2, vocab_size=64, word_embed_proj_dim=32,
+                     max_position_embeddings=64),
+                {"model.decoder.layers.0.self_attn.k_proj": 8, "model.decoder.layers.1.fc1": 12}),
+    }
+    for fam, (cfg_mod, cfg_cls, mdl_mod, mdl_cls, stock_cls, kw, ranks) in cases.items():
+        cm = importlib.import_module("huggingface_repos." + cfg_mod)
+        mm = importlib.import_module("huggingface_repos." + mdl_mod)
+        rec = {"config_kwargs": kw, "truncation_ranks": ranks, "plain_instantiation_error": None, "config_attributes_added": []}
+        cfg = getattr(cm, cfg_cls)(truncation_ranks=ranks, **kw)
+        try:
+            model = getattr(mm, mdl_cls)(cfg)
+        except Exception as e:  # noqa: BLE001 — transformers-version drift of the pinned reference
+            rec["plain_instantiation_error"] = f"{type(e).__name__}: {e}"
+            stock = getattr(transformers, stock_cls)(**kw)
+            for k, v in stock.to_dict().items():
+                if not hasattr(cfg, k):
+                    setattr(cfg, k, v)
+                    rec["config_attributes_added"].append(k)
+            model = getattr(mm, mdl_cls)(cfg)
+        sd = model.state_dict()
+        rec["state_dict"] = [[k, list(v.shape)] for k, v in sd.items()]
+        rec["factor_module_class"] = sorted({type(m).__name__ for n, m in model.named_modules() if n in ranks})
+        rec["config_reads"] = "truncation_ranks"
+        rec["config_truncation_ranks_roundtrip"] = json.loads(json.dumps(cfg.to_dict()["truncation_ranks"]))
+        rec["exporter_config_entries"] = assigns[fam]
+        out["families"][fam] = rec
+    json.dump(out, open(os.path.join(OUT, "hf_export_ref.json"), "w"), indent=1)
+    print("hf_export_ref.json:", {f: (len(r["state_dict"]), r["plain_instantiation_error"]) for f, r in out["families"].items()})
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1 and sys.argv[1] == "fisher":  # regenerate only the fisher fixture
         gen_fisher()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "hf_export":  # only the exported-repo fixture
+        gen_hf_export()
         sys.exit(0)
     gen_rank()
     gen_hook()
@@ -380,5 +443,6 @@ if __name__ == "__main__":
     gen_search()
     gen_order_hf()
     gen_fisher()
+    gen_hf_export()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

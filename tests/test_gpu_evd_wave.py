@@ -1,0 +1,104 @@
+"""The wave-local 64x64 symmetric eigen-solver (csrc/evd_wave.hip) alone, through its test hook: one wave per matrix, registers only.
+Checked against numpy (eigenvalues, orthogonality, Q^T G Q), against the CPU prototype of the same data flow (tools/proto_evd_wave.py:
+identical arithmetic up to the hardware rcp / rsq approximations), and for the bookkeeping the kernels' epilogues rely on (closed-form
+diagonal, descending ranks with ties by index, column scales, off-diagonal measures)."""
+import ctypes
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _gram(rng, cond, n=64, rows=256):
+    X = rng.standard_normal((rows, n)) * np.logspace(0, -np.log10(cond) / 2, n)[None, :]
+    X = X + 0.3 * X @ np.linalg.qr(rng.standard_normal((n, n)))[0]
+    return (X.T @ X).astype(np.float32)
+
+
+def _run(gpu, G, sweeps):
+    from asvd4llm_amd import _lib
+    lib = _lib.load(True)
+    B = G.shape[0]
+    Gd = torch.from_numpy(G).to(gpu).contiguous()
+    Q = torch.empty_like(Gd)
+    Gout = torch.empty_like(Gd)
+    diag = torch.empty((B, 64), dtype=torch.float32, device=gpu)
+    cs = torch.empty((B, 64), dtype=torch.float32, device=gpu)
+    rnk = torch.empty((B, 64), dtype=torch.int32, device=gpu)
+    meas = torch.empty((B, 2), dtype=torch.float32, device=gpu)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    rc = lib.asvd_test_evd_wave(p(Gd), B, sweeps, p(Q), p(diag), p(rnk), p(cs), p(Gout), p(meas), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    torch.cuda.synchronize()
+    return [t.cpu().numpy() for t in (Q, diag, rnk, cs, Gout, meas)]
+
+
+def test_converged_solve_matches_numpy(gpu):
+    rng = np.random.default_rng(0)
+    G = np.stack([_gram(rng, c) for c in (1e1, 1e2, 1e3, 1e4, 1e5, 1e6) for _ in range(4)])
+    Q, diag, rnk, cs, Gout, meas = _run(gpu, G, sweeps=8)
+    for b in range(G.shape[0]):
+        w = np.linalg.eigvalsh(G[b].astype(np.float64))[::-1]
+        qd = Q[b].astype(np.float64)
+        assert np.abs(np.sort(diag[b].astype(np.float64))[::-1] - w).max() <= 2e-5 * w[0]
+        assert np.abs(qd.T @ qd - np.eye(64)).max() <= 5e-6            # product of unit-norm-corrected rotations
+        assert np.abs(qd.T @ G[b].astype(np.float64) @ qd - np.diag(diag[b])).max() <= 3e-5 * w[0]
+        # bookkeeping of the epilogues
+        order = np.argsort(-diag[b].astype(np.float64), kind="stable")
+        want = np.empty(64, np.int64)
+        want[order] = np.arange(64)
+        assert np.array_equal(rnk[b], want)
+        assert np.allclose(cs[b], 1.0 / np.linalg.norm(qd, axis=0), rtol=1e-6)
+        # the image the sweeps leave: its off-diagonal is what Q^T G Q says (the diagonal lives in `diag`)
+        T = qd.T @ G[b].astype(np.float64) @ qd
+        off = Gout[b].astype(np.float64) - np.diag(np.diag(Gout[b].astype(np.float64)))
+        assert np.abs(off - (T - np.diag(np.diag(T)))).max() <= 3e-5 * w[0]
+
+
+def test_measures_of_the_input(gpu):
+    rng = np.random.default_rng(1)
+    G = np.stack([_gram(rng, c) for c in (1e1, 1e3, 1e5)])
+    Q, diag, rnk, cs, Gout, meas = _run(gpu, G, sweeps=0)
+    for b in range(G.shape[0]):
+        g = G[b].astype(np.float64)
+        d = np.diag(g)
+        A = np.abs(g) / np.sqrt(np.outer(d, d))
+        np.fill_diagonal(A, 0)
+        At = np.abs(g) / np.maximum.outer(d, d)
+        np.fill_diagonal(At, 0)
+        lead = np.zeros((64, 64), bool)
+        lead[:32, :] = True   # the hook marks positions 0..31 as the leading panel
+        lead[:, :32] = True
+        assert abs(meas[b, 0] - A.max()) <= 1e-5 * A.max()
+        assert abs(meas[b, 1] - At[lead].max()) <= 1e-5 * At[lead].max()
+        assert np.array_equal(Q[b], np.eye(64, dtype=np.float32)) and np.array_equal(Gout[b], G[b])   # zero sweeps: nothing moves
+    bad = G.copy()
+    bad[1, 5, 7] = np.nan
+    bad[2, 9, 3] = np.inf
+    m = _run(gpu, bad, sweeps=0)[5]
+    assert np.isfinite(m[0]).all() and np.isnan(m[1]).all() and np.isnan(m[2]).all()
+
+
+def test_one_sweep_follows_the_cpu_prototype(gpu):
+    """one inner sweep (what the SVD runs per visit of a pair) against the numpy emulation of the lane / register data flow"""
+    spec = importlib.util.spec_from_file_location("proto_evd_wave", os.path.join(ROOT, "tools", "proto_evd_wave.py"))
+    proto = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(proto)
+    rng = np.random.default_rng(2)
+    G = np.stack([_gram(rng, c) for c in (1e1, 1e3, 1e5)])
+    Q, diag, rnk, cs, Gout, meas = _run(gpu, G, sweeps=1)
+    for b in range(G.shape[0]):
+        g, q, d, hist = proto.solve(G[b], sweeps=1)
+        scale = float(np.abs(d).max())
+        assert np.abs(diag[b] - d).max() <= 2e-4 * scale     # same rotations up to v_rcp / v_rsq (1 ulp) in the angles
+        assert np.abs(Q[b] - q).max() <= 2e-3
+        off_gpu = Gout[b] - np.diag(np.diag(Gout[b]))
+        off_cpu = g - np.diag(np.diag(g))
+        assert np.abs(off_gpu).max() <= 1.5 * np.abs(off_cpu).max() + 1e-6 * scale
+        qd = Q[b].astype(np.float64)
+        assert np.abs(qd.T @ qd - np.eye(64)).max() <= 3e-6

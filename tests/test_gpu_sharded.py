@@ -59,6 +59,8 @@ def _worker(rank, ws, port, q, tmpdir, kind, shard_calib):
         out = io.StringIO()
         with contextlib.redirect_stdout(out), contextlib.redirect_stderr(io.StringIO()):
             calib_input_distribution(model, calib, "abs_mean", use_cache=False, shard_samples=shard_calib)
+            scal = {n: m.scaling_diag_matrix.float().cpu().numpy().copy() for n, m in model.named_modules()
+                    if hasattr(m, "scaling_diag_matrix") and torch.is_tensor(m.scaling_diag_matrix)}  # before the search replaces modules
             sens = calib_sensitivity_ppl(model, calib, args, use_cache=False)
             binary_search_truncation_rank(model, sens, calib, args)
         torch.cuda.synchronize()
@@ -66,8 +68,6 @@ def _worker(rank, ws, port, q, tmpdir, kind, shard_calib):
         kinds = {n: type(m).__name__ for n, m in model.named_modules() if n in model._asvd_layers_min_ratio}
         ranks = {n: int(m.truncation_rank) for n, m in model.named_modules() if isinstance(m, SVDLinear)}
         state = {k: v.detach().float().cpu().numpy().copy() for k, v in model.state_dict().items()}
-        scal = {n: m.scaling_diag_matrix.float().cpu().numpy().copy() for n, m in model.named_modules()
-                if hasattr(m, "scaling_diag_matrix") and torch.is_tensor(m.scaling_diag_matrix)}
         q.put((rank, sens, dict(model._asvd_layers_min_ratio), kinds, ranks, state, swept, scal, getattr(model, "_asvd_factor_exchange", None)))
     finally:
         if ws > 1:
