@@ -26,6 +26,8 @@
 
 #include "common.h"
 #include "jacobi_shared.h"
+#include <cstdlib>
+#include <cstdio>
 
 namespace {
 using namespace asvdk;
@@ -328,22 +330,34 @@ __global__ __launch_bounds__(256, 2) void evdw0_kernel(Sched sc, const float* __
 //   step 1: wave sp solves sub-pair (sp, 3 - sp): diagonal blocks from step 0, cross block  Q0_sp[:, :32]^T MM Q0_(1-sp)[:, 32:]  with
 //           MM = M (sp = 0) or M^T (sp = 1), M = G[{0,2},{1,3}] assembled from the other four tiles — two small fp32-MFMA products;
 //           epilogue: the new carried blocks of its two panels (global) and its 128 x 64 column block of Qfin = Q^(0) Q^(1).
-// LDS (50,432 B: three workgroups per CU): four padded Q0 halves [64][33] + one 64 x 65 region that is, in turn, the step-0 diagonal
-// blocks, the padded M, and the staging of the cross blocks.  Row strides 33 / 65 make every MFMA operand read (lanes along a row OR
-// along a column) conflict free.
+// The step-0 eigenvectors travel between the two waves through GLOBAL memory (v3.Q0, 16 KB per solve, L2 resident; agent-scope loads): with
+// them in LDS the workgroup needed 50 KB = three workgroups per CU, and a launch of 1024 super-pairs ran as 768 + 256 workgroups with half
+// of the SIMDs idle in the second round (measured 570 us per launch; two workgroups per CU: 700 us).  LDS now (33,536 B: four workgroups
+// per CU, every SIMD holds two waves, ONE round):  one 64 x 65 region that is, in turn, the transposer of the step-0 images, the step-0
+// diagonal blocks, the padded M and the staging of the cross blocks, and two wave-private [64][33] slices where the epilogue stages the
+// Q0 half it multiplies.  Row strides 33 / 65 make every MFMA operand read (lanes along a row OR along a column) conflict free.
 constexpr int QH_LD = 33, QH_FLOATS = 64 * QH_LD;   // one half of a Q0: 64 rows x 32 sorted columns
 constexpr int M_LD = 65;
-constexpr int E12_R16 = 4 * QH_FLOATS;              // float offset of the multi-purpose region
-constexpr int E12_SMEM_FLOATS = E12_R16 + 64 * M_LD;
+constexpr int E12_SLICE = 64 * M_LD;                // float offset of the two epilogue slices
+constexpr int E12_SMEM_FLOATS = E12_SLICE + 2 * QH_FLOATS;
+
+// agent-scope load of data another wave of the workgroup (or this wave) wrote to global memory earlier in the launch: L2, never this CU's L1
+__device__ __forceinline__ float ldg_sc1(const float* p) { return __int_as_float(__hip_atomic_load((const int*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
 
 __device__ __forceinline__ int mfma_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }  // C/D row of v_mfma_f32_32x32x2_f32
 
 __global__ __launch_bounds__(128, 2) void evdw12_kernel(Sched sc, unsigned* __restrict__ maxoff_bits, int* __restrict__ nrot,
                                                         const int* __restrict__ done, float tol, int inner_sweeps, int nb, int step, int kb,
-                                                        EvdV3 v3) {
+                                                        EvdV3 v3, long long* __restrict__ trace) {
     extern __shared__ __attribute__((aligned(16))) float e12_smem[];
-    float* const Qh = e12_smem;                 // [4][64][33]: half index 2 * solve + (0: sorted columns 0..31, 1: 32..63)
-    float* const R16 = e12_smem + E12_R16;
+    // stage trace (ASVD_EVDW_TRACE=1): shader-clock stamps of workgroup (0, 0), one row of 16 per wave
+    int tstage = 0;
+    auto stamp = [&]() {
+        if (trace && blockIdx.x == 0 && blockIdx.y == 0 && (threadIdx.x & 63) == 0) trace[(threadIdx.x >> 6) * 16 + tstage] = (long long)__builtin_amdgcn_s_memtime();
+        ++tstage;
+    };
+    stamp();
+    float* const R16 = e12_smem;                // multi-purpose region (see above)
     const int tid = threadIdx.x, lane = tid & 63, sp = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hi = lane >> 5, cc = lane & 31;
     const int pair = blockIdx.x, b = blockIdx.y, npairs = gridDim.x;
@@ -381,15 +395,16 @@ __global__ __launch_bounds__(128, 2) void evdw12_kernel(Sched sc, unsigned* __re
             }
 #pragma unroll
             for (int r = 0; r < 32; ++r) g[32 + r] = dB[r * 32 + cc];
-            float* tr = Qh + (2 * sp) * QH_FLOATS;      // wave-private scratch until this wave's Q0 is written
+            float* tr = R16 + sp * (32 * 33);            // wave-private transposer
 #pragma unroll
             for (int r = 0; r < 32; ++r) tr[cc * 33 + r] = g[r];       // C[r][cc] -> tr[cc][r]
         }
         if (!hi) {
-            const float* tr = Qh + (2 * sp) * QH_FLOATS;
+            const float* tr = R16 + sp * (32 * 33);
 #pragma unroll
             for (int r = 0; r < 32; ++r) g[32 + r] = tr[r * 33 + cc];  // G[32 + r][cc] = C[cc][r]
         }
+        stamp();  // 1: image loaded
         evdw_init_state(g, lane, diag, bpiv);
         evdw_measure(g, diag, lane, I < kb, J < kb, off0, offt);
         const bool is_nan = off0 != off0;
@@ -400,16 +415,24 @@ __global__ __launch_bounds__(128, 2) void evdw12_kernel(Sched sc, unsigned* __re
             if (rotate && offt >= tol) atomicAdd(&nrot[b], 1);
         }
         evdw_identity(q, lane);
+        stamp();  // 2: measured
+        asm volatile("" ::: "memory");
         if (rotate) evdw_sweep(g, q, diag, bpiv, lane, ((off0 > 0.05f) ? inner_sweeps : min(1, inner_sweeps)) * sc.evd_pairs);
+        asm volatile("" ::: "memory");   // no load of a later stage is hoisted above the sweep (its registers would be spilled across it)
+        stamp();  // 3: swept
         evdw_finish(q, diag, lane, rotate, cs, rnk);
-        // sorted, rescaled eigenvectors: column `lane` goes to half rnk >> 5, column rnk & 31
-        float* qdst = Qh + (2 * sp + (rnk >> 5)) * QH_FLOATS + (rnk & 31);
+        stamp();  // 4: norms + ranks
+        // sorted, rescaled eigenvectors, row-major 64 x 64 in global memory: column `lane` goes to column rnk (a permutation inside a 256-byte row)
+        float* __restrict__ qdst = v3.Q0 + (slot * 2 + sp) * (PW * PW) + rnk;
 #pragma unroll
-        for (int r = 0; r < 64; ++r) qdst[r * QH_LD] = q[r] * cs;
+        for (int r = 0; r < 64; ++r) qdst[r * PW] = q[r] * cs;
+        __syncthreads();   // both transposers are done with: the region becomes the diagonal blocks
         // transformed diagonal blocks: sorted positions 0..31 -> block sp, 32..63 -> block 2 + sp
         evdw_store_diag_blocks(g, diag, cs, rnk, lane, R16 + sp * 1024, R16 + (2 + sp) * 1024);
     }
-    __syncthreads();   // Q0 halves and diagonal blocks of both solves are in LDS
+    stamp();  // 5: Q0 + diagonal blocks stored
+    __syncthreads();   // diagonal blocks of both solves are in LDS, both Q0 in global memory (stores acknowledged: workgroup-scope release)
+    stamp();  // 6
 
     // ================================ step 1: sub-pair (sp, 3 - sp) ================================
     const int I1 = 2 * S + sp, J1 = 2 * T + (1 - sp);
@@ -433,31 +456,48 @@ __global__ __launch_bounds__(128, 2) void evdw12_kernel(Sched sc, unsigned* __re
     {
         // M = G[{0,2},{1,3}] = [[tile 4, tile 1], [tile 2 ^T, tile 5]] (tiles [0,1] [0,3] [1,2] [2,3]), padded row stride M_LD, summed over the
         // partials in ascending order; every quadrant is read in the linear order of its tile (coalesced)
+        float mv[32];
+#pragma unroll
+        for (int e = 0; e < 32; ++e) mv[e] = 0.0f;
+        for (int s2 = 0; s2 < v3.nsplit6; ++s2) {   // partials outermost: 32 independent loads in flight per partial
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const int tile = qd == 0 ? 4 : (qd == 1 ? 1 : (qd == 2 ? 2 : 5));
+#pragma unroll
+                for (int j = 0; j < 8; ++j) mv[qd * 8 + j] += gx[(int64_t)s2 * 6144 + tile * 1024 + tid1 + 128 * j];
+            }
+        }
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
-            const int tile = qd == 0 ? 4 : (qd == 1 ? 1 : (qd == 2 ? 2 : 5));
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int e = tid1 + 128 * j, tr_ = e >> 5, tc = e & 31;
-                float v = 0.0f;
-                for (int s2 = 0; s2 < v3.nsplit6; ++s2) v += gx[(int64_t)s2 * 6144 + tile * 1024 + e];
                 const int mi = qd == 0 ? tr_ : (qd == 1 ? tr_ : (qd == 2 ? 32 + tc : 32 + tr_));
                 const int mk = qd == 0 ? tc : (qd == 1 ? 32 + tc : (qd == 2 ? tr_ : 32 + tc));
-                R16[mi * M_LD + mk] = v;
+                R16[mi * M_LD + mk] = mv[qd * 8 + j];
             }
         }
     }
     __syncthreads();
+    stamp();  // 7: M assembled
     f32x16 cacc = {0};
     {
         // T = MM QBh (64 x 32, K = 64):  MM = M (sp 0) or M^T (sp 1);  QBh = second half of the OTHER solve's Q0
-        const float* QB = Qh + (2 * (1 - sp) + 1) * QH_FLOATS;
-        const float* QA = Qh + (2 * sp) * QH_FLOATS;
+        const float* __restrict__ QB = v3.Q0 + (slot * 2 + (1 - sp)) * (PW * PW) + 32 + cc1;   // second half of the other solve's Q0
+        const float* __restrict__ QA = v3.Q0 + (slot * 2 + sp) * (PW * PW) + cc1;              // first half of this solve's
+        float bqv[32], qav[32];
+#pragma unroll
+        for (int k2 = 0; k2 < 32; ++k2) bqv[k2] = ldg_sc1(QB + (2 * k2 + hi1) * PW);            // all operand loads in flight at once
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            qav[2 * reg] = ldg_sc1(QA + mfma_row(reg, hi1) * PW);
+            qav[2 * reg + 1] = ldg_sc1(QA + (32 + mfma_row(reg, hi1)) * PW);
+        }
         f32x16 t0 = {0}, t1 = {0};
-#pragma unroll 8
+#pragma unroll
         for (int k2 = 0; k2 < 32; ++k2) {
             const int k = 2 * k2 + hi1;
-            const float bq = QB[k * QH_LD + cc1];
+            const float bq = bqv[k2];
             const float a0 = sp ? R16[k * M_LD + cc1] : R16[cc1 * M_LD + k];
             const float a1 = sp ? R16[k * M_LD + 32 + cc1] : R16[(32 + cc1) * M_LD + k];
             t0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bq, t0, 0, 0, 0);
@@ -467,9 +507,8 @@ __global__ __launch_bounds__(128, 2) void evdw12_kernel(Sched sc, unsigned* __re
         // permuted freely as long as both operands agree): register `reg` of tile rt holds rows k = 32 rt + mfma_row(reg, h)
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
-            const int k0 = mfma_row(reg, hi1);
-            cacc = __builtin_amdgcn_mfma_f32_32x32x2f32(QA[k0 * QH_LD + cc1], t0[reg], cacc, 0, 0, 0);
-            cacc = __builtin_amdgcn_mfma_f32_32x32x2f32(QA[(32 + k0) * QH_LD + cc1], t1[reg], cacc, 0, 0, 0);
+            cacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qav[2 * reg], t0[reg], cacc, 0, 0, 0);
+            cacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qav[2 * reg + 1], t1[reg], cacc, 0, 0, 0);
         }
     }
     __syncthreads();   // M consumed: the region becomes the staging of the two cross blocks
@@ -486,8 +525,11 @@ __global__ __launch_bounds__(128, 2) void evdw12_kernel(Sched sc, unsigned* __re
             for (int r = 0; r < 32; ++r) g[32 + r] = Cs[cc1 * 33 + r];     // G[32 + r][cc1] = C'[cc1][r]
         }
     }
+    stamp();  // 8: cross block computed, image complete
     evdw_init_state(g, lane1, diag, bpiv);
     evdw_measure(g, diag, lane1, I1 < kb, J1 < kb, off0, offt);
+    stamp();  // 9: measured
+    asm volatile("" ::: "memory");
     {
         const bool is_nan = off0 != off0;
         const bool rotate = !(is_nan || off0 < tol);
@@ -498,36 +540,54 @@ __global__ __launch_bounds__(128, 2) void evdw12_kernel(Sched sc, unsigned* __re
         }
         evdw_identity(q, lane1);
         if (rotate) evdw_sweep(g, q, diag, bpiv, lane1, ((off0 > 0.05f) ? inner_sweeps : min(1, inner_sweeps)) * sc.evd_pairs);
+        asm volatile("" ::: "memory");
+        stamp();  // 10: swept
         evdw_finish(q, diag, lane1, rotate, cs, rnk);
     }
+    stamp();  // 11
+    // thread index opaque once more: the per-lane addresses of the epilogue are not computed (and kept live) before the step-1 sweep
+    int tid2 = threadIdx.x;
+    asm volatile("" : "+v"(tid2));
+    const int lane2 = tid2 & 63, hi2 = lane2 >> 5, cc2 = lane2 & 31;
     // new carried diagonal blocks of the two panels
-    evdw_store_diag_blocks(g, diag, cs, rnk, lane1, v3.Gd32 + ((int64_t)b * v3.nbpan + I1) * 1024, v3.Gd32 + ((int64_t)b * v3.nbpan + J1) * 1024);
+    evdw_store_diag_blocks(g, diag, cs, rnk, lane2, v3.Gd32 + ((int64_t)b * v3.nbpan + I1) * 1024, v3.Gd32 + ((int64_t)b * v3.nbpan + J1) * 1024);
 
+    stamp();  // (between 11 and 12): diagonal blocks stored
     // Qfin[:, columns of blocks (ba, bb)] = Q^(0)[:, {ba, bb}] Q1,  ba = sp, bb = 3 - sp:
     //   rows of blocks {ba, ba + 2}  <-  Q0_ba[:, :32]       Q1[:32, :]        (product 0)
     //   rows of blocks {bb - 2, bb}  <-  Q0_(bb-2)[:, 32:]   Q1[32:, :]        (product 1)
-    // Q1 sits in registers, lane1 = (unsorted) column: one v_permlane32_swap per register pair (k, k + 1) turns it into the B operands of the
+    // Q1 sits in registers, lane2 = (unsorted) column: one v_permlane32_swap per register pair (k, k + 1) turns it into the B operands of the
     // two column tiles (lanes 0..31: positions 0..31 | 32..63, half-waves = the two k of an MFMA).  Columns are put in sorted order by the
     // store address.
     {
         const int ba = sp, bb = 3 - sp;
 #pragma unroll
         for (int r = 0; r < 64; ++r) q[r] *= cs;
-        const int rnk_lo = __shfl(rnk, cc1, 64), rnk_hi = __shfl(rnk, 32 + cc1, 64);   // sorted index of positions cc1 and 32 + cc1
+        const int rnk_lo = __shfl(rnk, cc2, 64), rnk_hi = __shfl(rnk, 32 + cc2, 64);   // sorted index of positions cc2 and 32 + cc2
         const int col_lo = rnk_lo < 32 ? 32 * ba + rnk_lo : 32 * bb + (rnk_lo - 32);
         const int col_hi = rnk_hi < 32 ? 32 * ba + rnk_hi : 32 * bb + (rnk_hi - 32);
         float* __restrict__ qf = v3.Qfin + slot * (128 * 128);
 #pragma unroll
         for (int prod = 0; prod < 2; ++prod) {
-            const float* A = Qh + (prod ? (2 * (bb - 2) + 1) : (2 * ba)) * QH_FLOATS;    // [64 rows][33], columns = the k of this product
+            // stage the 64 x 32 half this product multiplies: coalesced agent-scope loads, padded wave-private slice (a wave's LDS operations
+            // complete in order: no barrier)
+            float* A = e12_smem + E12_SLICE + sp * QH_FLOATS;                          // [64 rows][33], columns = the k of this product
+            {
+                const float* __restrict__ src = v3.Q0 + (slot * 2 + (prod ? bb - 2 : ba)) * (PW * PW) + (prod ? 32 : 0) + cc2;
+                float hv[32];
+#pragma unroll
+                for (int it = 0; it < 32; ++it) hv[it] = ldg_sc1(src + (2 * it + hi2) * PW);
+#pragma unroll
+                for (int it = 0; it < 32; ++it) A[(2 * it + hi2) * QH_LD + cc2] = hv[it];
+            }
             f32x16 d00 = {0}, d01 = {0}, d10 = {0}, d11 = {0};   // [row tile][column tile]
 #pragma unroll
             for (int kk = 0; kk < 16; ++kk) {
                 const int ra = 32 * prod + 2 * kk, rb = ra + 1;
                 const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(q[ra]), __float_as_uint(q[rb]), false, false);
                 const float b0 = __uint_as_float(sw[0]), b1 = __uint_as_float(sw[1]);   // column tiles 0 / 1, k = (ra | rb) by half-wave
-                const int kl = 2 * kk + hi1;                                              // this half-wave's k within the product
-                const float a0 = A[cc1 * QH_LD + kl], a1 = A[(32 + cc1) * QH_LD + kl];
+                const int kl = 2 * kk + hi2;                                              // this half-wave's k within the product
+                const float a0 = A[cc2 * QH_LD + kl], a1 = A[(32 + cc2) * QH_LD + kl];
                 d00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, d00, 0, 0, 0);
                 d01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, d01, 0, 0, 0);
                 d10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, d10, 0, 0, 0);
@@ -536,7 +596,7 @@ __global__ __launch_bounds__(128, 2) void evdw12_kernel(Sched sc, unsigned* __re
             const int rblk0 = prod ? bb - 2 : ba, rblk1 = prod ? bb : ba + 2;
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
-                const int i = mfma_row(reg, hi1);
+                const int i = mfma_row(reg, hi2);
                 qf[(32 * rblk0 + i) * 128 + col_lo] = d00[reg];
                 qf[(32 * rblk0 + i) * 128 + col_hi] = d01[reg];
                 qf[(32 * rblk1 + i) * 128 + col_lo] = d10[reg];
@@ -544,6 +604,7 @@ __global__ __launch_bounds__(128, 2) void evdw12_kernel(Sched sc, unsigned* __re
             }
         }
     }
+    stamp();  // 12: Qfin written
     ASVD_KERNEL_RELEASE(sc);
 }
 
@@ -601,8 +662,22 @@ void launch_evdw12(int npairs_s, int batch, hipStream_t st, const Sched& sc, uns
         (void)hipFuncSetAttribute((const void*)evdw12_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, evdw12_lds_bytes());
         attr_done = true;
     }
+    static long long* trace = nullptr;
+    static int traced = 0;
+    if (getenv("ASVD_EVDW_TRACE") && !trace) (void)hipMalloc(&trace, 32 * sizeof(long long));
     evdw12_kernel<<<dim3((unsigned)npairs_s, (unsigned)batch), 128, evdw12_lds_bytes(), st>>>(sc, maxoff_bits, nrot, done, tol, inner_sweeps, nb, step,
-                                                                                            kb, v3);
+                                                                                            kb, v3, traced < 3 ? trace : nullptr);
+    if (trace && traced < 3) {
+        long long h[32];
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(h, trace, sizeof(h), hipMemcpyDeviceToHost);
+        for (int w = 0; w < 2; ++w) {
+            fprintf(stderr, "[evdw12 trace] launch %d wave %d stage deltas (clocks):", traced, w);
+            for (int i = 1; i < 14; ++i) fprintf(stderr, " %lld", h[w * 16 + i] - h[w * 16 + i - 1]);
+            fprintf(stderr, "\n");
+        }
+        ++traced;
+    }
 }
 
 void launch_evdw_test(int batch, hipStream_t st, const float* G, int sweeps, float* Q, float* diag, int* rnk, float* cs, float* Gout, float* meas) {

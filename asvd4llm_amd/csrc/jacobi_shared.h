@@ -25,6 +25,7 @@ constexpr int PW = 2 * PB;   // pair width
 //   fence       agent-scope acquire / release at kernel boundaries (stream groups, common.h)
 struct Sched {
     int pair_order, super_order, evd_pairs, fence, gm;
+    int dbg_fill;   // experiments on the LDS solver (tools/repro_lds_fill.py): bit r = pre-fill LDS region r with NaN at kernel entry
     signed char gpair[8][4][2];
 };
 static Sched default_sched() {

@@ -261,10 +261,23 @@ __device__ __forceinline__ void evd_body(const Sched& sc, const BlockCtx& ctx, f
 
     const int pair = MODE ? (ctx.bx >> 1) : ctx.bx, b = ctx.by, npairs = MODE ? (ctx.gx >> 1) : ctx.gx;
     ASVD_KERNEL_ACQUIRE(sc);
+    if (sc.fence & 4) {  // experiment (ASVD_FENCE=4, tools/repro_two_streams.py): start from a zeroed LDS image
+        for (int e = threadIdx.x; e < EVD_SMEM_FLOATS(KEEPG); e += 256) smem[e] = 0.0f;
+        __syncthreads();
+    }
+    if (sc.dbg_fill) {  // experiment (ASVD_EVD_LDSFILL=mask): NaN into the regions G | Qs | sdiag | sb | redmax | cscale | rnk (bits 0..6)
+        const int base = (KEEPG ? 2 : 1) * PW * PW;
+        const int lo[7] = {0, PW * PW, base, base + 128, base + 192, base + 200, base + 264};
+        const int hi[7] = {PW * PW, KEEPG ? 2 * PW * PW : PW * PW, base + 128, base + 192, base + 200, base + 264, base + 328};
+        for (int r = 0; r < 7; ++r)
+            if ((sc.dbg_fill >> r) & 1)
+                for (int e = lo[r] + (int)threadIdx.x; e < hi[r]; e += 256) smem[e] = __builtin_nanf("");
+        __syncthreads();
+    }
     if (ld_flag(done + b)) return;
     // the eigen-solve is a dependent chain of short VALU/LDS phases on every group's critical path: let its waves win the issue
     // arbitration against the matrix-pipe-bound gram/update waves of the other stream groups that share the SIMD
-    __builtin_amdgcn_s_setprio(3);
+    if (!(sc.fence & 8)) __builtin_amdgcn_s_setprio(3);   // (ASVD_FENCE=8: experiment without the priority)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int sp = MODE ? (ctx.bx & 1) : 0;
     const int64_t slot = (int64_t)b * npairs + pair;
@@ -2118,9 +2131,10 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
         sc.pair_order = pair_order_xor() ? 1 : 0;
         // agent-scope fences at kernel boundaries: on with several stream groups (common.h); ASVD_FENCE=0/1 overrides (experiments)
         sc.fence = stream_groups_for(batch) > 1 ? 3 : 0;
-        if (getenv("ASVD_FENCE")) { const int f = atoi(getenv("ASVD_FENCE")); sc.fence = f == 1 ? 3 : (f == 2 ? 1 : (f == 3 ? 2 : 0)); }
+        if (getenv("ASVD_FENCE")) { const int f = atoi(getenv("ASVD_FENCE")); sc.fence = f == 1 ? 3 : (f == 2 ? 1 : (f == 3 ? 2 : (f == 4 ? 4 : (f == 8 ? 8 : (f == 12 ? 12 : 0))))); }
         sc.super_order = super_grouped_for(p) ? 2 : (super_rr_for(p) ? 0 : 1);
         if (sc.super_order == 2) set_group_table(sc, p.ns);
+        sc.dbg_fill = getenv("ASVD_EVD_LDSFILL") ? atoi(getenv("ASVD_EVD_LDSFILL")) : 0;
         sc.evd_pairs = getenv("ASVD_EVD_PAIRS") ? std::max(1, std::min(64, atoi(getenv("ASVD_EVD_PAIRS")))) : PW / 2;
     }
     const int nsteps = pair_order_xor() ? 2 * p.npairs - 1 : p.nb - 1;
