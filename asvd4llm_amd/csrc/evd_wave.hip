@@ -66,8 +66,12 @@ __device__ __forceinline__ float put_lane(float bn, float v, int L, int lane) { 
 
 // One phase.  bpiv: on entry the pivot b = G[lane + 1][lane] in the LOWER lane of every pair of this phase; on exit the same for the
 // next phase (the other parity).  diag: G[lane][lane], closed form.
+// Row coefficients: the (c, s) of row pair k are those of the lanes at the same positions.  They reach all lanes through 512 bytes of
+// wave-private LDS (one ds_write_b64 per lane, one broadcast ds_read_b64 per row pair) instead of two v_readlane per row pair: measured
+// 2.3 ns per v_readlane against 1.1 ns per plain VALU instruction on a saturated SIMD (tools/ubench/valu_cost.hip) — 14 % of a phase —
+// while the LDS pipe is idle during the sweep.  A wave's LDS operations complete in order: no barrier.
 template <int PAR>
-__device__ __forceinline__ void evdw_phase(float (&g)[64], float (&q)[64], float& diag, float& bpiv, const int lane) {
+__device__ __forceinline__ void evdw_phase(float (&g)[64], float (&q)[64], float& diag, float& bpiv, const int lane, float* __restrict__ cslds) {
     const bool odd = (lane & 1) != 0;
     float bn = 0.0f;
     int lane_o = lane;
@@ -81,9 +85,11 @@ __device__ __forceinline__ void evdw_phase(float (&g)[64], float (&q)[64], float
         jacobi_rot(a_, d_, b, c, s, t);
         diag = fmaf(lower ? t : -t, b, lower ? d_ : a_);   // position p now holds the rotated q and vice versa (swap): d + t b | a - t b
         const float own = lower ? s : -s;                   // new = own * x + c * x_partner
+        *(float2*)(cslds + 2 * lane) = make_float2(c, s);
 #pragma unroll
         for (int k = 0; k < 32; ++k) {
-            const float ck = rdlane(c, 2 * k), sk = rdlane(s, 2 * k);
+            const float2 cs2 = *(const float2*)(cslds + 2 * (2 * k));
+            const float ck = cs2.x, sk = cs2.y;
             const float x0 = g[2 * k], x1 = g[2 * k + 1];
             const float y0 = fmaf(ck, x1, sk * x0);         // rows: new[p] = s row[p] + c row[q] ; new[q] = c row[p] - s row[q]
             const float y1 = fmaf(-sk, x1, ck * x0);
@@ -92,13 +98,9 @@ __device__ __forceinline__ void evdw_phase(float (&g)[64], float (&q)[64], float
             g[2 * k] = z0;
             g[2 * k + 1] = z1;
             if (k >= 1) bn = put_lane(bn, z0, 2 * k - 1, lane_o);    // phase B: lower lanes are odd L, their pivot is register L + 1
-            if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);    // bounds the live ranges of the row / column temporaries (VGPR budget)
         }
 #pragma unroll
-        for (int r = 0; r < 64; ++r) {
-            q[r] = fmaf(own, q[r], c * dppf<DPP_XOR1>(q[r]));
-            if ((r & 7) == 7) __builtin_amdgcn_sched_barrier(0);    // the products land in fresh registers: keep only 8 of them in flight
-        }
+        for (int r = 0; r < 64; ++r) q[r] = fmaf(own, q[r], c * dppf<DPP_XOR1>(q[r]));
     } else {
         const bool lower = odd;                              // pairs (2k+1, 2k+2); lanes 0 and 63 idle
         const bool idle = (lane == 0) || (lane == 63);
@@ -114,10 +116,12 @@ __device__ __forceinline__ void evdw_phase(float (&g)[64], float (&q)[64], float
         const float cr = (!lower && !idle) ? c : 0.0f;       // weight of the value of lane - 1 (even lanes)
         c = idle ? 1.0f : c;                                 // rows 0 and 63 are idle too; the row loop below never reads lanes 0 / 63
         s = idle ? 0.0f : s;
+        *(float2*)(cslds + 2 * lane) = make_float2(c, s);
         g[0] = col_update_b(g[0], own, cl, cr);    // row 0 is idle: columns only
 #pragma unroll
         for (int k = 0; k < 31; ++k) {
-            const float ck = rdlane(c, 2 * k + 1), sk = rdlane(s, 2 * k + 1);
+            const float2 cs2 = *(const float2*)(cslds + 2 * (2 * k + 1));
+            const float ck = cs2.x, sk = cs2.y;
             const float x0 = g[2 * k + 1], x1 = g[2 * k + 2];
             const float y0 = fmaf(ck, x1, sk * x0);
             const float y1 = fmaf(-sk, x1, ck * x0);
@@ -126,7 +130,6 @@ __device__ __forceinline__ void evdw_phase(float (&g)[64], float (&q)[64], float
             g[2 * k + 1] = z0;
             g[2 * k + 2] = z1;
             bn = put_lane(bn, z0, 2 * k, lane_o);                    // phase A: lower lanes are even L, their pivot is register L + 1
-            if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
         {   // row 63 is idle
             const float z = col_update_b(g[63], own, cl, cr);
@@ -134,10 +137,7 @@ __device__ __forceinline__ void evdw_phase(float (&g)[64], float (&q)[64], float
             bn = put_lane(bn, z, 62, lane_o);
         }
 #pragma unroll
-        for (int r = 0; r < 64; ++r) {
-            q[r] = col_update_b(q[r], own, cl, cr);
-            if ((r & 7) == 7) __builtin_amdgcn_sched_barrier(0);
-        }
+        for (int r = 0; r < 64; ++r) q[r] = col_update_b(q[r], own, cl, cr);
     }
     bpiv = bn;
 }
@@ -187,11 +187,13 @@ __device__ __forceinline__ void evdw_measure(const float (&g)[64], const float d
 }
 
 // the sweeps: `loops` full odd-even cycles of 64 phases each are  loops * 32  (A, B) phase pairs
-__device__ __forceinline__ void evdw_sweep(float (&g)[64], float (&q)[64], float& diag, float& bpiv, const int lane, const int phase_pairs) {
+constexpr int EVDW_CS_FLOATS = 128;   // wave-private LDS of the row coefficients
+__device__ __forceinline__ void evdw_sweep(float (&g)[64], float (&q)[64], float& diag, float& bpiv, const int lane, const int phase_pairs,
+                                           float* __restrict__ cslds) {
 #pragma unroll 1
     for (int ph2 = 0; ph2 < phase_pairs; ++ph2) {
-        evdw_phase<0>(g, q, diag, bpiv, lane);
-        evdw_phase<1>(g, q, diag, bpiv, lane);
+        evdw_phase<0>(g, q, diag, bpiv, lane, cslds);
+        evdw_phase<1>(g, q, diag, bpiv, lane, cslds);
     }
 }
 
@@ -246,6 +248,7 @@ __global__ __launch_bounds__(256, 2) void evdw0_kernel(Sched sc, const float* __
                                                        const int* __restrict__ done, float tol, int inner_sweeps, int nb, int step, int kb,
                                                        const int* __restrict__ plist, int list_stride, int npairs, EvdV3 v3) {
     __shared__ float trbuf[4][EVDW_TR_FLOATS];
+    __shared__ __attribute__((aligned(16))) float csbuf[4][EVDW_CS_FLOATS];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int pair = blockIdx.x * 4 + wv, b = blockIdx.y;
     ASVD_KERNEL_ACQUIRE(sc);
@@ -311,7 +314,7 @@ __global__ __launch_bounds__(256, 2) void evdw0_kernel(Sched sc, const float* __
     }
     evdw_identity(q, lane);
     const int nsw = (off0 > 0.05f) ? inner_sweeps : min(1, inner_sweeps);
-    evdw_sweep(g, q, diag, bpiv, lane, nsw * sc.evd_pairs);
+    evdw_sweep(g, q, diag, bpiv, lane, nsw * sc.evd_pairs, csbuf[wv]);
     float cs;
     int rnk;
     evdw_finish(q, diag, lane, true, cs, rnk);
@@ -339,7 +342,8 @@ __global__ __launch_bounds__(256, 2) void evdw0_kernel(Sched sc, const float* __
 constexpr int QH_LD = 33, QH_FLOATS = 64 * QH_LD;   // one half of a Q0: 64 rows x 32 sorted columns
 constexpr int M_LD = 65;
 constexpr int E12_SLICE = 64 * M_LD;                // float offset of the two epilogue slices
-constexpr int E12_SMEM_FLOATS = E12_SLICE + 2 * QH_FLOATS;
+constexpr int E12_CS = E12_SLICE + 2 * QH_FLOATS;   // float offset of the two row-coefficient buffers
+constexpr int E12_SMEM_FLOATS = E12_CS + 2 * 128;
 
 // agent-scope load of data another wave of the workgroup (or this wave) wrote to global memory earlier in the launch: L2, never this CU's L1
 __device__ __forceinline__ float ldg_sc1(const float* p) { return __int_as_float(__hip_atomic_load((const int*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
@@ -417,7 +421,7 @@ __global__ __launch_bounds__(128, 2) void evdw12_kernel(Sched sc, unsigned* __re
         evdw_identity(q, lane);
         stamp();  // 2: measured
         asm volatile("" ::: "memory");
-        if (rotate) evdw_sweep(g, q, diag, bpiv, lane, ((off0 > 0.05f) ? inner_sweeps : min(1, inner_sweeps)) * sc.evd_pairs);
+        if (rotate) evdw_sweep(g, q, diag, bpiv, lane, ((off0 > 0.05f) ? inner_sweeps : min(1, inner_sweeps)) * sc.evd_pairs, e12_smem + E12_CS + sp * 128);
         asm volatile("" ::: "memory");   // no load of a later stage is hoisted above the sweep (its registers would be spilled across it)
         stamp();  // 3: swept
         evdw_finish(q, diag, lane, rotate, cs, rnk);
@@ -539,7 +543,7 @@ __global__ __launch_bounds__(128, 2) void evdw12_kernel(Sched sc, unsigned* __re
             if (rotate && offt >= tol) atomicAdd(&nrot[b], 1);
         }
         evdw_identity(q, lane1);
-        if (rotate) evdw_sweep(g, q, diag, bpiv, lane1, ((off0 > 0.05f) ? inner_sweeps : min(1, inner_sweeps)) * sc.evd_pairs);
+        if (rotate) evdw_sweep(g, q, diag, bpiv, lane1, ((off0 > 0.05f) ? inner_sweeps : min(1, inner_sweeps)) * sc.evd_pairs, e12_smem + E12_CS + sp * 128);
         asm volatile("" ::: "memory");
         stamp();  // 10: swept
         evdw_finish(q, diag, lane1, rotate, cs, rnk);
@@ -614,6 +618,7 @@ __global__ __launch_bounds__(64, 2) void evdw_test_kernel(const float* __restric
                                                        float* __restrict__ diag_out, int* __restrict__ rnk_out, float* __restrict__ cs_out,
                                                        float* __restrict__ Gout, float* __restrict__ meas_out) {
     const int lane = threadIdx.x, b = blockIdx.x;
+    __shared__ __attribute__((aligned(16))) float csbuf[EVDW_CS_FLOATS];
     float g[64], q[64];
 #pragma unroll
     for (int r = 0; r < 64; ++r) g[r] = Gin[(int64_t)b * 4096 + r * 64 + lane];
@@ -623,7 +628,7 @@ __global__ __launch_bounds__(64, 2) void evdw_test_kernel(const float* __restric
     evdw_measure(g, diag, lane, true, false, off0, offt);
     if (lane == 0) { meas_out[2 * b] = off0; meas_out[2 * b + 1] = offt; }
     evdw_identity(q, lane);
-    evdw_sweep(g, q, diag, bpiv, lane, sweeps * 32);
+    evdw_sweep(g, q, diag, bpiv, lane, sweeps * 32, csbuf);
     float cs;
     int rnk;
     evdw_finish(q, diag, lane, true, cs, rnk);

@@ -1882,6 +1882,19 @@ int make_plan(int batch, int64_t m, int64_t n, int want_u, int want_vv, Plan& p)
         // small batches: one round of 256 workgroups too (batch 4: 43.7 ms of supgram per step with 4 chunks, 47.3 with 8, 52.8 with 16);
         // the solves sum the partial tiles with independent loads, so their cost no longer grows with the chunk count
         int64_t nq = std::max<int64_t>(1, std::min<int64_t>(ceil_div64(256, quads), std::max<int64_t>(1, tiles / 8)));
+        {
+            // counts that are not a power of two (13B: 80 super-panels = 20 real quads per problem in a 32-quad grid): one workgroup per CU means
+            // the launch runs in whole rounds of 256 workgroups, and 320 real workgroups cost two rounds (measured 1179 us per launch at
+            // 16 x 5120^2; four row chunks = exactly five rounds of a quarter length: 737 us).  Pick the chunk count that wastes the least.
+            const int64_t real = ceil_div64(p.ns, 4) * batch;
+            if (real != quads && real >= 256) {
+                double best = 1e300;
+                for (int64_t c = 1; c <= 8 && c <= std::max<int64_t>(1, tiles / 8); c *= 2) {
+                    const double cost = (double)ceil_div64(real * c, 256) / (double)c * (1.0 + 0.03 * (double)c);
+                    if (cost < best) { best = cost; nq = c; }
+                }
+            }
+        }
         if (getenv("ASVD_SUPGRAM_CHUNKS")) nq = std::max<int64_t>(1, std::min<int64_t>(atoi(getenv("ASVD_SUPGRAM_CHUNKS")), tiles));
         p.rows_per_wg_q = (int)(ceil_div64(tiles, nq) * 32);
         p.nchunks_q = (int)ceil_div64(p.R_upd, p.rows_per_wg_q);
@@ -2485,7 +2498,10 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
             const int dup2 = std::min(nsuper, getenv("ASVD_DUP2") ? atoi(getenv("ASVD_DUP2")) : 0);
             // supgram: the update of step D also leaves the Gram tiles of the step that follows (one pass instead of two); the
             // stand-alone Gram pass then runs only in front of the first super-step.  Needs split-bf16; ASVD_SUPGRAM=0 turns it off.
-            const bool fuse_ug = split_bf16 && !super_rr && p.npairs_s >= 2 && !(getenv("ASVD_SUPGRAM") && atoi(getenv("ASVD_SUPGRAM")) == 0);
+            // (round 3: also on the GROUPED schedule of counts that are a multiple of 16 — inside a group the steps are XOR steps, and the
+            // 16 offsets of a group pair close quads {A_i, B_(i^s), B_(i^s'), A_(i^s^s')} as well; ASVD_SUPGRAM_GROUPED=0 keeps the separate passes)
+            const bool fuse_grp = super_grp && !(getenv("ASVD_SUPGRAM_GROUPED") && atoi(getenv("ASVD_SUPGRAM_GROUPED")) == 0);
+            const bool fuse_ug = split_bf16 && (!super_rr || fuse_grp) && p.npairs_s >= 2 && !(getenv("ASVD_SUPGRAM") && atoi(getenv("ASVD_SUPGRAM")) == 0);
             if (fuse_ug)
                 ASVD_HIP_CHECK(hipFuncSetAttribute((const void*)supgram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                    (int)(SUPGRAM_SMEM_FLOATS * sizeof(float))));
@@ -2504,6 +2520,11 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
                 auto real_pairs = [&](int d) { int n = 0; for (int S = 0; S < p.ns; ++S) n += ((S ^ d) > S && (S ^ d) < p.ns) ? 1 : 0; return n; };
                 auto fused_after = [&](int dj) {  // does the launch of super-step index dj also leave the tiles of index dj + 1 ?
                     if (!fuse_ug || dj < 0 || dj + 1 >= nsuper + dup2) return false;
+                    if (super_grp) {  // consecutive steps inside the groups (XOR distances 1..15), or consecutive offsets of the same round of group pairs
+                        const int s0 = level_of(dj) - 1, s1 = level_of(dj + 1) - 1;   // 0-based super-steps
+                        if (s1 != s0 + 1) return false;
+                        return s1 < 15 || (s0 >= 15 && ((s0 - 15) >> 4) == ((s1 - 15) >> 4));
+                    }
                     const int d0 = level_of(dj), d1 = level_of(dj + 1);
                     return d0 != d1 && (double)(real_pairs(d0) + real_pairs(d1)) >= fill_min * 2.0 * (p.ns / 2);
                 };

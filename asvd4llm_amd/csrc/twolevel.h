@@ -388,23 +388,41 @@ __global__ __launch_bounds__(512, 1) void supgram_kernel(Sched sc, float* __rest
     if (ld_flag(done + b)) return;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5, c = lane & 31;
     // ---- quad geometry (uniform) ----
-    const int h1 = 31 - __clz(D);
-    const int e1 = ((E >> h1) & 1) ? (E ^ D) : E;
-    const int h2 = 31 - __clz(e1);
-    const int a0 = insert_zero_bit(insert_zero_bit(quad, min(h1, h2)), max(h1, h2));
-    const int P0 = a0, P1 = a0 ^ D, P2 = a0 ^ E, P3 = a0 ^ D ^ E;  // super-panels in tile slots 0..3
+    // XOR steps (the whole schedule when ns is a power of two; the steps inside the groups of the grouped schedule): super-panels
+    // {a, a^D, a^E, a^D^E}.  Group-pair steps of the grouped schedule (sc.super_order == 2, 0-based step D-1 >= 15): round r pairs group gA with
+    // gB for the 16 offsets s (A_i <-> B_(i^s)); two consecutive offsets s, s' of a round close the quads {A_i, B_(i^s), B_(i^s'), A_(i^e)},
+    // e = s ^ s' — the same four slots with the same roles: slots (0,1) and (3,2) rotate now, slots (0,2) and (3,1) meet next.
+    int P0, P1, P2, P3, kcur0, kcur1, knxt0, knxt1;
+    bool swapB, swapD;
+    if (sc.super_order == 2 && D > 15) {
+        const int st = D - 1 - 15, rnd = st >> 4, s0 = st & 15, s1 = (E - 1 - 15) & 15, e = s0 ^ s1;
+        const int m = quad >> 3;
+        if (m >= sc.gm) return;
+        const int gA = sc.gpair[rnd][m][0], gB = sc.gpair[rnd][m][1];
+        const int i = insert_zero_bit(quad & 7, 31 - __clz(e));
+        P0 = 16 * gA + i; P1 = 16 * gB + (i ^ s0); P2 = 16 * gB + (i ^ s1); P3 = 16 * gA + (i ^ e);
+        swapB = true; swapD = true;
+        kcur0 = 16 * m + i; kcur1 = 16 * m + (i ^ e);
+        knxt0 = kcur0; knxt1 = kcur1;
+    } else {
+        const int h1 = 31 - __clz(D);
+        const int e1 = ((E >> h1) & 1) ? (E ^ D) : E;
+        const int h2 = 31 - __clz(e1);
+        const int a0 = insert_zero_bit(insert_zero_bit(quad, min(h1, h2)), max(h1, h2));
+        P0 = a0; P1 = a0 ^ D; P2 = a0 ^ E; P3 = a0 ^ D ^ E;   // super-panels in tile slots 0..3
+        // current pairs (step D): A = slots (0,1), B = slots (2,3); Q order is (lower, upper) = (bit h1 clear, set)
+        swapB = (P2 >> h1) & 1;
+        const int hE = 31 - __clz(E);
+        swapD = (P1 >> hE) & 1;
+        kcur0 = remove_bit(P0, h1); kcur1 = remove_bit(swapB ? P3 : P2, h1);
+        knxt0 = remove_bit(P0, hE); knxt1 = remove_bit(swapD ? P3 : P1, hE);
+    }
     auto Pof = [&](int slot) { return slot == 0 ? P0 : (slot == 1 ? P1 : (slot == 2 ? P2 : P3)); };  // no indexed arrays: they go to scratch
-    // current pairs (step D): A = slots (0,1), B = slots (2,3); Q order is (lower, upper) = (bit h1 clear, set)
-    const bool swapB = (P2 >> h1) & 1;
     const int curS1 = swapB ? 3 : 2, curT1 = swapB ? 2 : 3;  // pair A: S = slot 0, T = slot 1
-    const int kcur0 = remove_bit(P0, h1), kcur1 = remove_bit(Pof(curS1), h1);
     const bool act0 = P0 < ns && P1 < ns && pair_active(subact, (int64_t)b * npairs + kcur0);
     const bool act1 = P2 < ns && P3 < ns && pair_active(subact, (int64_t)b * npairs + kcur1);
     // next pairs (step E): C = slots (0,2), D' = slots (1,3)
-    const int hE = 31 - __clz(E);
-    const bool swapD = (P1 >> hE) & 1;
     const int nxtS1 = swapD ? 3 : 1, nxtT1 = swapD ? 1 : 3;  // pair C: S = slot 0, T = slot 2
-    const int knxt0 = remove_bit(P0, hE), knxt1 = remove_bit(Pof(nxtS1), hE);
     const bool have0 = P0 < ns && P2 < ns, have1 = P1 < ns && P3 < ns;
     if (chunk == 0 && tid == 0) {
         const int n = (act0 ? 1 : 0) + (act1 ? 1 : 0);

@@ -253,6 +253,29 @@ def test_svd_llama13b_shapes(gpu, shape):
     assert info.sweeps <= 20
 
 
+@pytest.mark.timeout(900)
+def test_grouped_schedule_fused_and_separate_passes_agree(gpu, monkeypatch):
+    """13B column counts (80 super-panels) run the grouped super-panel schedule; round 3 fuses the update of a super-step with the Gram
+    tiles of the next one there too (inside the groups AND between the offsets of a group pair).  Both forms of the sweep must meet parity
+    with the same sweep count, and agree with each other to rounding."""
+    from asvd4llm_amd import ops
+    W, s = llm_like(5120, 5120, seed=29)
+    Wd, sd = W.to(gpu), s.to(gpu)
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("ASVD_SUPGRAM_GROUPED", flag)
+        U, S, V, info = ops.svd(Wd, sd)
+        assert info.status == 0
+        res[flag] = (S.cpu(), info.sweeps)
+    monkeypatch.delenv("ASVD_SUPGRAM_GROUPED")
+    So = torch.linalg.svdvals(O.scaled_weight(W, s).double())
+    r = O.rank_from_ratio(5120, 5120, 0.9)
+    for flag in ("1", "0"):
+        assert O.sigma_rel_err(res[flag][0], So.float(), r) <= SIG_TOL
+    assert abs(res["1"][1] - res["0"][1]) <= 1
+    assert ((res["1"][0].double() - res["0"][0].double()).abs().max() / So[0]).item() <= 2e-6
+
+
 @pytest.mark.timeout(1500)
 @pytest.mark.parametrize("shape", [(32000, 4096), (50272, 768)])
 def test_svd_lm_head_shapes(gpu, shape):
