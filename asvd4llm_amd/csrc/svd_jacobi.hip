@@ -984,6 +984,125 @@ __global__ __launch_bounds__(256) void fullcheck_kernel(Sched sc, const float* _
     ASVD_KERNEL_RELEASE(sc);
 }
 
+// One 32x32 block of the snapshot: scaled couplings of panel I's columns against panel J's, mark + termination measure.
+__device__ __forceinline__ void fullcheck_block(const f32x16& acc, int I, int J, int lane, const float* __restrict__ dnb, float dj, float tol, int kb,
+                                                int nb, int64_t b, unsigned char* __restrict__ pflag, unsigned* __restrict__ maxoff_bits) {
+    const int h = lane >> 5, c = lane & 31;
+    float v = 0.0f, vt = 0.0f;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int i = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        if (I == J && i == c) continue;
+        const float di = dnb[I * PB + i];
+        const float g = acc[reg];
+        const float dd = di * dj;
+        float x = (dd > 0.0f) ? fabsf(g) * rsqrtf(dd) : 0.0f;
+        if (g != g || dd != dd) x = __builtin_nanf("");
+        const float mx = fmaxf(di, dj);
+        float xt = (mx > 0.0f) ? fabsf(g) / mx : 0.0f;
+        if (x != x) xt = x;
+        v = nanmax(v, x);
+        vt = nanmax(vt, xt);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        v = nanmax(v, __shfl_xor(v, o, 64));
+        vt = nanmax(vt, __shfl_xor(vt, o, 64));
+    }
+    if (lane == 0) {
+        if (v != v) {
+            atomicMax(&maxoff_bits[b], 0x7fc00000u);
+        } else {
+            if (v >= tol) {  // a coupling inside a panel is repaired by any visit of that panel: mark its neighbour pair
+                const int A = (I == J) ? min(I, I ^ 1) : I, Bp = (I == J) ? max(I, I ^ 1) : J;
+                pflag[(b * nb + A) * nb + Bp] = 1;
+            }
+            if (I < kb || J < kb) atomicMax(&maxoff_bits[b], __float_as_uint(vt));
+        }
+    }
+}
+
+// The same snapshot on 256x256 tiles: grid (ceil(nb/8), ceil(nb/8), batch), 512 threads, wave w owns panel J = 8*jg + w against the
+// eight panels I = 8*ig + a.  fullcheck_kernel<1> re-reads every panel nb/4 times and was bound by that traffic (39 GB per launch
+// measured at the fabric for 2 GB of panels, round 2); doubling the tile edge halves it at the same matrix-pipe work.  The sixteen
+// operand images of a 32-row chunk take 96 KB of LDS, one workgroup (two waves per SIMD) per CU.
+constexpr int FC8_LDS_BYTES = 16 * 2 * 3 * 64 * 16;
+__global__ __launch_bounds__(512, 1) void fullcheck8_kernel(Sched sc, const float* __restrict__ X, int64_t panel_stride, int64_t batch_stride, int nb,
+                                                            int m_pad, int n_pad, const float* __restrict__ dn, float tol, int kb,
+                                                            unsigned char* __restrict__ pflag, unsigned* __restrict__ maxoff_bits,
+                                                            const int* __restrict__ done) {
+    const int ig = blockIdx.x, jg = blockIdx.y, b = blockIdx.z;
+    if (ig > jg || ld_flag(done + b)) return;
+    ASVD_KERNEL_ACQUIRE(sc);
+    extern __shared__ __attribute__((aligned(16))) u32x4 fc8_oimg[];  // [16 panels][2 k-steps][3 parts][64 lanes]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int J = jg * 8 + w;
+    const float* __restrict__ Xb = X + (int64_t)b * batch_stride;
+    f32x16 acc[8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) acc[a] = (f32x16){0};
+    // thread t builds the operands (panel slot (t >> 7) + 4 j, k-step (t >> 6) & 1, lane t & 63), j = 0..3; slots 0..7 = A side, 8..15 = B side
+    const int sks = (tid >> 6) & 1, sl = tid & 63, q0 = tid >> 7;
+    const float* src[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int q = q0 + 4 * j;
+        const int pnl = (q < 8) ? ig * 8 + q : jg * 8 + q - 8;
+        src[j] = Xb + (int64_t)(pnl < nb ? pnl : nb - 1) * panel_stride + (int64_t)(16 * sks + 8 * (sl >> 5)) * PB + (sl & 31);
+    }
+    float pre[4][8];
+    auto fetch = [&](int r0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pre[j][e] = src[j][(int64_t)(r0 + e) * PB];
+    };
+    fetch(0);
+    for (int r0 = 0; r0 < m_pad; r0 += 32) {
+        __syncthreads();  // previous chunk's operands fully consumed
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            u32x4 p1, p2, p3;
+#pragma unroll
+            for (int e2 = 0; e2 < 4; ++e2) {
+                unsigned x, y, z;
+                split3(pre[j][2 * e2], pre[j][2 * e2 + 1], x, y, z);
+                p1[e2] = x; p2[e2] = y; p3[e2] = z;
+            }
+            u32x4* o = fc8_oimg + (((q0 + 4 * j) * 2 + sks) * 3) * 64 + sl;
+            o[0] = p1; o[64] = p2; o[128] = p3;
+        }
+        __syncthreads();
+        if (r0 + 32 < m_pad) fetch(r0 + 32);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const u32x4* ob = fc8_oimg + (((8 + w) * 2 + ks) * 3) * 64 + lane;
+            const bf16x8 B1 = __builtin_bit_cast(bf16x8, ob[0]), B2 = __builtin_bit_cast(bf16x8, ob[64]), B3 = __builtin_bit_cast(bf16x8, ob[128]);
+#pragma unroll
+            for (int a = 0; a < 8; ++a) {
+                const u32x4* oa = fc8_oimg + ((a * 2 + ks) * 3) * 64 + lane;
+                const bf16x8 A1 = __builtin_bit_cast(bf16x8, oa[0]), A2 = __builtin_bit_cast(bf16x8, oa[64]), A3 = __builtin_bit_cast(bf16x8, oa[128]);
+                acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A3, B1, acc[a], 0, 0, 0);
+                acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B3, acc[a], 0, 0, 0);
+                acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, B2, acc[a], 0, 0, 0);
+                acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, B1, acc[a], 0, 0, 0);
+                acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B2, acc[a], 0, 0, 0);
+                acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B1, acc[a], 0, 0, 0);
+            }
+        }
+    }
+    if (J >= nb) { ASVD_KERNEL_RELEASE(sc); return; }
+    const float* __restrict__ dnb = dn + (int64_t)b * n_pad;
+    const float dj = dnb[J * PB + (lane & 31)];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+        const int I = ig * 8 + a;
+        if (I > J) continue;  // blocks below the diagonal are mirrors
+        fullcheck_block(acc[a], I, J, lane, dnb, dj, tol, kb, nb, b, pflag, maxoff_bits);
+    }
+    ASVD_KERNEL_RELEASE(sc);
+}
+
 // --------------------------------------------------------------------------------------------------
 // upgram: update of step d fused with the Gram matrices of step e (the step that follows).  Under the XOR ordering the four
 // panels {a, a^d, a^e, a^d^e} are closed under both steps: pairs (a, a^d), (a^e, a^d^e) rotate now, pairs (a, a^e), (a^d, a^d^e)
@@ -1482,7 +1601,7 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ G,
 
 // trailing update  G_{ib,kb} -= R_{jb,ib}^T R_{jb,kb}  (jb < ib <= kb), fp64 MFMA, one workgroup per 64x64 block
 __global__ __launch_bounds__(256) void chol_syrk_kernel(double* __restrict__ G, int64_t ldg, int64_t g_batch_stride, int jb, int nbk) {
-    const int ib = jb + 1 + blockIdx.x, kb = jb + 1 + blockIdx.y, b = blockIdx.z;
+    const int ib = jb + 1 + blockIdx.x, kb = jb + 1 + blockIdx.y, b = blockIdx.z;  // gridDim.x may stop short of the last block row (strip of a group)
     if (kb < ib || kb >= nbk) return;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int kk = lane >> 4, cc = lane & 15;
@@ -1497,6 +1616,38 @@ __global__ __launch_bounds__(256) void chol_syrk_kernel(double* __restrict__ G, 
         const double a = Ra[(int64_t)k0 * ldg];
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Rb[(int64_t)k0 * ldg + t * 16], acc[t], 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t row = (int64_t)ib * CB + w * 16 + kk + 4 * q, col = (int64_t)kb * CB + t * 16 + cc;
+            Gb[row * ldg + col] -= acc[t][q];
+        }
+}
+
+// The same update for a GROUP of nj finished block rows j0 .. j0+nj-1 at once (K = 64 nj): blocks (ib, kb), j0+nj <= ib <= kb.  With one
+// block row per pass (chol_syrk_kernel over the whole trailing matrix) the factorisation streams the trailing matrix nbk times —
+// 2.8 GB read + written per 4096-column problem, the pass was bound by that, not by the fp64 pipe (22 TFLOP/s); grouping four block
+// rows makes it a quarter.  Inside a group the rows still see each other through chol_syrk_kernel restricted to the group's strip.
+__global__ __launch_bounds__(256) void chol_syrk_multi_kernel(double* __restrict__ G, int64_t ldg, int64_t g_batch_stride, int j0, int nj, int nbk) {
+    const int ib = j0 + nj + blockIdx.x, kb = j0 + nj + blockIdx.y, b = blockIdx.z;
+    if (kb < ib || kb >= nbk) return;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int kk = lane >> 4, cc = lane & 15;
+    double* Gb = G + (int64_t)b * g_batch_stride;
+    const double* __restrict__ Ra = Gb + ((int64_t)j0 * CB + kk) * ldg + (int64_t)ib * CB + w * 16 + cc;
+    const double* __restrict__ Rb = Gb + ((int64_t)j0 * CB + kk) * ldg + (int64_t)kb * CB + cc;
+    f64x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    for (int j = 0; j < nj; ++j, Ra += (int64_t)CB * ldg, Rb += (int64_t)CB * ldg) {
+#pragma unroll 4
+        for (int k0 = 0; k0 < CB; k0 += 4) {
+            const double a = Ra[(int64_t)k0 * ldg];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Rb[(int64_t)k0 * ldg + t * 16], acc[t], 0, 0, 0);
+        }
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -2242,7 +2393,18 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
                 panel_sumsq_kernel<<<dim3(p.nb, nbg), 256, 0, gst[g]>>>(sc, Xg, p.panel_stride, p.batch_stride, p.m_pad, p.n_pad,
                                                                         dnorm + (size_t)b0 * p.n_pad, done + b0);
                 const unsigned nt = (unsigned)ceil_div64(p.nb, 4);
-                if (split_check)
+                static const int fc_tile = getenv("ASVD_SNAPSHOT_TILE") ? atoi(getenv("ASVD_SNAPSHOT_TILE")) : 128;  // 256 (fullcheck8_kernel) measured slower: 58.2 vs 56.1 ms for the three snapshots
+                if (split_check && fc_tile == 256 && p.nb >= 16) {
+                    static bool fc8_attr = false;
+                    if (!fc8_attr) {
+                        ASVD_HIP_CHECK(hipFuncSetAttribute((const void*)fullcheck8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FC8_LDS_BYTES));
+                        fc8_attr = true;
+                    }
+                    const unsigned nt8 = (unsigned)ceil_div64(p.nb, 8);
+                    fullcheck8_kernel<<<dim3(nt8, nt8, nbg), 512, FC8_LDS_BYTES, gst[g]>>>(sc, Xg, p.panel_stride, p.batch_stride, p.nb, p.m_pad, p.n_pad,
+                                                                                         dnorm + (size_t)b0 * p.n_pad, tol, kb,
+                                                                                         pflag + (size_t)b0 * p.nb * p.nb, maxoff + b0, done + b0);
+                } else if (split_check)
                     fullcheck_kernel<1><<<dim3(nt, nt, nbg), 256, 0, gst[g]>>>(sc, Xg, p.panel_stride, p.batch_stride, p.nb, p.m_pad, p.n_pad,
                                                                                dnorm + (size_t)b0 * p.n_pad, tol, kb,
                                                                                pflag + (size_t)b0 * p.nb * p.nb, maxoff + b0, done + b0);
@@ -2798,9 +2960,16 @@ static int svd_tall(int batch, const void* const* a_host, int a_dtype, int64_t m
         if (sort_cols) rank_kernel<<<dim3((unsigned)ceil_div64(p.n_pad, 256), batch), 256, 0, st>>>(dF, p.n_pad, cperm);
         else iota_kernel<<<dim3((unsigned)ceil_div64(p.n_pad, 256), batch), 256, 0, st>>>(cperm, p.n_pad);
         g_permute_scale_kernel<<<dim3((unsigned)ceil_div64(p.n_pad, 256), p.n_pad, batch), 256, 0, st>>>(G, ldg, gbs, d, cperm, p.n_pad, Gs, dp);
-        for (int jb = 0; jb < nbk; ++jb) {
-            chol_panel_kernel<<<dim3(std::min(nbk - jb, 16), batch), 256, 0, st>>>(Gs, ldg, gbs, jb, fail, Dg, nbk);
-            if (jb + 1 < nbk) chol_syrk_kernel<<<dim3(nbk - jb - 1, nbk - jb - 1, batch), 256, 0, st>>>(Gs, ldg, gbs, jb, nbk);
+        // block rows in groups of `cg`: inside a group each finished row updates the rest of the group's strip (K = 64), the matrix behind
+        // the group is updated once per group (K = 64 cg)
+        static const int cg = std::max(1, getenv("ASVD_CHOL_GROUP") ? atoi(getenv("ASVD_CHOL_GROUP")) : 4);
+        for (int j0 = 0; j0 < nbk; j0 += cg) {
+            const int j1 = std::min(nbk, j0 + cg);
+            for (int jb = j0; jb < j1; ++jb) {
+                chol_panel_kernel<<<dim3(std::min(nbk - jb, 16), batch), 256, 0, st>>>(Gs, ldg, gbs, jb, fail, Dg, nbk);
+                if (jb + 1 < j1) chol_syrk_kernel<<<dim3(j1 - jb - 1, nbk - jb - 1, batch), 256, 0, st>>>(Gs, ldg, gbs, jb, nbk);
+            }
+            if (j1 < nbk) chol_syrk_multi_kernel<<<dim3(nbk - j1, nbk - j1, batch), 256, 0, st>>>(Gs, ldg, gbs, j0, j1 - j0, nbk);
         }
         r_to_f32_kernel<<<dim3((unsigned)ceil_div64(p.n_pad, 256), p.n_pad, batch), 256, 0, st>>>(Gs, ldg, gbs, Dg, dp, p.n_pad, use_rt ? 1 : 0, R, gbs);
     }

@@ -522,23 +522,33 @@ __global__ __launch_bounds__(512, 1) void supgram_kernel(Sched sc, float* __rest
                 o[0] = p1; o[SG_BLK] = p2; o[2 * SG_BLK] = p3;
             }
         };
-        auto gram = [&]() {
-            auto mm = [&](int pa, int pb, f32x16 acc) {
-                const u32x4* oa = opnd + ((pa * 2 + kh) * 3) * 64 + lane;
-                const u32x4* ob_ = opnd + ((pb * 2 + kh) * 3) * 64 + lane;
-                const bf16x8 a1 = __builtin_bit_cast(bf16x8, oa[0]), a2 = __builtin_bit_cast(bf16x8, oa[64]), a3 = __builtin_bit_cast(bf16x8, oa[128]);
-                const bf16x8 b1 = __builtin_bit_cast(bf16x8, ob_[0]), b2 = __builtin_bit_cast(bf16x8, ob_[64]), b3 = __builtin_bit_cast(bf16x8, ob_[128]);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc, 0, 0, 0);
-                return acc;
-            };
-            if (gon0) g0 = mm(ga0, gb0, g0);
-            if (gon1) g1 = mm(ga1, gb1, g1);
-            if (gon2) g2 = mm(ga2, gb2, g2);
+        // The matrix instructions of a tile — 18 for the Gram half-tiles of the previous tile, 48 for the update — read all their A operands
+        // (and the Gram B operands) from LDS.  Left to the compiler every ds_read sits right in front of its consumer (s_waitcnt lgkmcnt(0)
+        // before each MFMA group) and the LDS latency is exposed 11 times per tile and wave; here the reads of stage i+1 are issued before the
+        // MFMAs of stage i (stages: Gram unit 0, 1, 2, update k-step 0..7), pinned with sched_barrier.
+        struct Opnd6 { bf16x8 a1, a2, a3, b1, b2, b3; };
+        struct Opnd3 { bf16x8 a1, a2, a3; };
+        auto ldG = [&](int pa, int pb) {
+            const u32x4* oa = opnd + ((pa * 2 + kh) * 3) * 64 + lane;
+            const u32x4* ob_ = opnd + ((pb * 2 + kh) * 3) * 64 + lane;
+            Opnd6 r;
+            r.a1 = __builtin_bit_cast(bf16x8, oa[0]); r.a2 = __builtin_bit_cast(bf16x8, oa[64]); r.a3 = __builtin_bit_cast(bf16x8, oa[128]);
+            r.b1 = __builtin_bit_cast(bf16x8, ob_[0]); r.b2 = __builtin_bit_cast(bf16x8, ob_[64]); r.b3 = __builtin_bit_cast(bf16x8, ob_[128]);
+            return r;
+        };
+        auto mmG = [&](const Opnd6& r, f32x16 acc) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.a3, r.b1, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.a1, r.b3, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.a2, r.b2, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.a2, r.b1, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.a1, r.b2, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.a1, r.b1, acc, 0, 0, 0);
+            return acc;
+        };
+        auto gram_tail = [&]() {  // after the last tile: nothing to overlap with
+            if (gon0) g0 = mmG(ldG(ga0, gb0), g0);
+            if (gon1) g1 = mmG(ldG(ga1, gb1), g1);
+            if (gon2) g2 = mmG(ldG(ga2, gb2), g2);
         };
         int cur = 0;
         fetch(r_begin);
@@ -549,21 +559,45 @@ __global__ __launch_bounds__(512, 1) void supgram_kernel(Sched sc, float* __rest
             const bool more = r0 + 32 < r_end;
             if (more) fetch(r0 + 32);
             const u32x4* img = (cur ? aimg1 : aimg0) + (mypr * 8 * 3) * SG_BLK + h * SG_HB + c;
-            if (pending) gram();  // reads opnd of the previous tile
+            auto ldA = [&](int s) {
+                Opnd3 r;
+                r.a1 = __builtin_bit_cast(bf16x8, img[(3 * s + 0) * SG_BLK]);
+                r.a2 = __builtin_bit_cast(bf16x8, img[(3 * s + 1) * SG_BLK]);
+                r.a3 = __builtin_bit_cast(bf16x8, img[(3 * s + 2) * SG_BLK]);
+                return r;
+            };
+            Opnd3 ua;
+            if (pending) {  // reads opnd of the previous tile
+                Opnd6 x = ldG(ga0, gb0);
+                Opnd6 y = ldG(ga1, gb1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (gon0) g0 = mmG(x, g0);
+                x = ldG(ga2, gb2);
+                __builtin_amdgcn_sched_barrier(0);
+                if (gon1) g1 = mmG(y, g1);
+                ua = ldA(0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (gon2) g2 = mmG(x, g2);
+            } else {
+                ua = ldA(0);
+            }
             f32x16 acc;
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[q] = 0.f;
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
-                const bf16x8 A1 = __builtin_bit_cast(bf16x8, img[(3 * s + 0) * SG_BLK]), A2 = __builtin_bit_cast(bf16x8, img[(3 * s + 1) * SG_BLK]),
-                             A3 = __builtin_bit_cast(bf16x8, img[(3 * s + 2) * SG_BLK]);
+                Opnd3 un = ua;
+                if (s + 1 < 8) un = ldA(s + 1);
+                __builtin_amdgcn_sched_barrier(0);
                 const bf16x8 B1 = __builtin_bit_cast(bf16x8, q1[s]), B2 = __builtin_bit_cast(bf16x8, q2[s]), B3 = __builtin_bit_cast(bf16x8, q3[s]);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A3, B1, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B3, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, B2, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, B1, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B2, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B1, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.a3, B1, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.a1, B3, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.a2, B2, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.a2, B1, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.a1, B2, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.a1, B1, acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                ua = un;
             }
             if (mine) {
 #pragma unroll
@@ -593,7 +627,7 @@ __global__ __launch_bounds__(512, 1) void supgram_kernel(Sched sc, float* __rest
             pending = gram_rows;
             cur ^= 1;
         }
-        if (pending) gram();
+        if (pending) gram_tail();
     }
 
     // ---- the two k-steps of a tile sit in waves 2t and 2t+1 (j = 0), 2t-8 .. (j = 1), ...: sum through LDS, coalesced store ----
