@@ -878,9 +878,11 @@ __global__ __launch_bounds__(256) void fullcheck_kernel(Sched sc, const float* _
 #pragma unroll
                 for (int e = 0; e < 8; ++e) pre[j][e] = src[j][(int64_t)(r0 + e) * PB];
         };
+        const int abl = sc.dbg_fill >> 16;  // ASVD_FC_ABLATE: 1 no MFMAs, 2 no split / LDS stores, 4 no panel loads after the first chunk (timing only)
         fetch(0);
         for (int r0 = 0; r0 < m_pad; r0 += 32) {
             __syncthreads();  // previous chunk's operands fully consumed
+            if (!(abl & 2)) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 u32x4 p1, p2, p3;
@@ -893,8 +895,10 @@ __global__ __launch_bounds__(256) void fullcheck_kernel(Sched sc, const float* _
                 u32x4* o = oimg + ((((tid >> 7) + 2 * j) * 2 + sks) * 3) * 64 + sl;
                 o[0] = p1; o[64] = p2; o[128] = p3;
             }
+            }
             __syncthreads();
-            if (r0 + 32 < m_pad) fetch(r0 + 32);
+            if (r0 + 32 < m_pad && !(abl & 4)) fetch(r0 + 32);
+            if (abl & 1) continue;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const u32x4* ob = oimg + (((4 + w) * 2 + ks) * 3) * 64 + lane;
@@ -1432,6 +1436,9 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 // G[b][I*32.., J*32..] (upper blocks, I <= J) = X_I^T X_J in fp64 with v_mfma_f64_16x16x4_f64.  One wave per 32x32 block,
 // whole K range (no split, no reduction: deterministic).  The 4 waves of a workgroup share panel I through L1.
+// 49.5 TFLOP/s, which is what this instruction delivers here: a variant on 64x64 blocks per wave with 16-byte loads (one eighth of the
+// vector-memory instructions per MFMA) ran the same 44.4 ms per 32 x 4096^2, i.e. ~100 cycles per v_mfma_f64_16x16x4 and SIMD rather
+// than the 64 the 78.6 TFLOP/s figure implies (profiles/r3_fp64_mfma_rate.txt).
 __global__ __launch_bounds__(256) void gram64_kernel(const float* __restrict__ X, int64_t panel_stride, int64_t batch_stride, int nb,
                                                      int m_pad, double* __restrict__ G, int64_t ldg, int64_t g_batch_stride) {
     const int I = blockIdx.x, jg = blockIdx.y, b = blockIdx.z;
@@ -2299,6 +2306,7 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
         sc.super_order = super_grouped_for(p) ? 2 : (super_rr_for(p) ? 0 : 1);
         if (sc.super_order == 2) set_group_table(sc, p.ns);
         sc.dbg_fill = getenv("ASVD_EVD_LDSFILL") ? atoi(getenv("ASVD_EVD_LDSFILL")) : 0;
+        if (getenv("ASVD_FC_ABLATE")) sc.dbg_fill |= atoi(getenv("ASVD_FC_ABLATE")) << 16;  // timing-only ablations of the snapshot kernel (wrong results)
         sc.evd_pairs = getenv("ASVD_EVD_PAIRS") ? std::max(1, std::min(64, atoi(getenv("ASVD_EVD_PAIRS")))) : PW / 2;
     }
     const int nsteps = pair_order_xor() ? 2 * p.npairs - 1 : p.nb - 1;
@@ -3117,7 +3125,8 @@ int asvd_test_supgram(float* X, int64_t panel_stride, int64_t batch_stride, int 
         R < 32 || (R % 32) || (m_pad % 32) || rows_per_wg < 32 || (rows_per_wg % 32))
         return ASVD_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
-    const Sched sc = default_sched();
+    Sched sc = default_sched();
+    if (getenv("ASVD_SG_ABLATE")) sc.dbg_fill = atoi(getenv("ASVD_SG_ABLATE")) << 8;  // tools/bench_supgram.py
     ASVD_HIP_CHECK(hipFuncSetAttribute((const void*)supgram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SUPGRAM_SMEM_FLOATS * sizeof(float))));
     supgram_kernel<<<dim3(nchunks, (2 * npairs) / 4, batch), 512, SUPGRAM_SMEM_FLOATS * sizeof(float), st>>>(sc, X, panel_stride, batch_stride, ns, D, E, R, m_pad,
                                                                                                            rows_per_wg, Qfin, subact, Gx, done, nupd, npairs);

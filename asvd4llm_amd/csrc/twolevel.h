@@ -550,6 +550,7 @@ __global__ __launch_bounds__(512, 1) void supgram_kernel(Sched sc, float* __rest
             if (gon1) g1 = mmG(ldG(ga1, gb1), g1);
             if (gon2) g2 = mmG(ldG(ga2, gb2), g2);
         };
+        const int abl = sc.dbg_fill >> 8;  // tools/bench_supgram.py: timing-only ablations (results are wrong), always 0 in the product path
         int cur = 0;
         fetch(r_begin);
         stash(aimg0);
@@ -557,7 +558,7 @@ __global__ __launch_bounds__(512, 1) void supgram_kernel(Sched sc, float* __rest
         bool pending = false;  // Gram of the previous tile not yet accumulated (its operands are in opnd)
         for (int r0 = r_begin; r0 < r_end; r0 += 32) {
             const bool more = r0 + 32 < r_end;
-            if (more) fetch(r0 + 32);
+            if (more && !(abl & 8)) fetch(r0 + 32);
             const u32x4* img = (cur ? aimg1 : aimg0) + (mypr * 8 * 3) * SG_BLK + h * SG_HB + c;
             auto ldA = [&](int s) {
                 Opnd3 r;
@@ -571,13 +572,13 @@ __global__ __launch_bounds__(512, 1) void supgram_kernel(Sched sc, float* __rest
                 Opnd6 x = ldG(ga0, gb0);
                 Opnd6 y = ldG(ga1, gb1);
                 __builtin_amdgcn_sched_barrier(0);
-                if (gon0) g0 = mmG(x, g0);
+                if (gon0 && !(abl & 4)) g0 = mmG(x, g0);
                 x = ldG(ga2, gb2);
                 __builtin_amdgcn_sched_barrier(0);
-                if (gon1) g1 = mmG(y, g1);
+                if (gon1 && !(abl & 4)) g1 = mmG(y, g1);
                 ua = ldA(0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (gon2) g2 = mmG(x, g2);
+                if (gon2 && !(abl & 4)) g2 = mmG(x, g2);
             } else {
                 ua = ldA(0);
             }
@@ -590,16 +591,18 @@ __global__ __launch_bounds__(512, 1) void supgram_kernel(Sched sc, float* __rest
                 if (s + 1 < 8) un = ldA(s + 1);
                 __builtin_amdgcn_sched_barrier(0);
                 const bf16x8 B1 = __builtin_bit_cast(bf16x8, q1[s]), B2 = __builtin_bit_cast(bf16x8, q2[s]), B3 = __builtin_bit_cast(bf16x8, q3[s]);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.a3, B1, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.a1, B3, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.a2, B2, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.a2, B1, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.a1, B2, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.a1, B1, acc, 0, 0, 0);
+                if (s == 0 || !(abl & 2)) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.a3, B1, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.a1, B3, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.a2, B2, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.a2, B1, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.a1, B2, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.a1, B1, acc, 0, 0, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 ua = un;
             }
-            if (mine) {
+            if (mine && !(abl & 1)) {
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
                     const int i = (reg & 3) + 8 * (reg >> 2) + 4 * h;
@@ -608,7 +611,7 @@ __global__ __launch_bounds__(512, 1) void supgram_kernel(Sched sc, float* __rest
             }
             __syncthreads();  // every wave is done with the previous tile's operands (and with tile[cur] as far as the stash below matters)
             const bool gram_rows = r0 < m_pad;  // rows of the matrix proper only, not accumulated V rows
-            if (gram_rows) {
+            if (gram_rows && !(abl & 16)) {
 #pragma unroll
                 for (int k2 = 0; k2 < 2; ++k2) {
                     u32x4 p1, p2, p3;
@@ -622,7 +625,7 @@ __global__ __launch_bounds__(512, 1) void supgram_kernel(Sched sc, float* __rest
                     o[0] = p1; o[64] = p2; o[128] = p3;
                 }
             }
-            if (more) stash(cur ? aimg0 : aimg1);
+            if (more && !(abl & 32)) stash(cur ? aimg0 : aimg1);
             __syncthreads();
             pending = gram_rows;
             cur ^= 1;
