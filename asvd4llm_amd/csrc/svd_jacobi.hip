@@ -878,11 +878,9 @@ __global__ __launch_bounds__(256) void fullcheck_kernel(Sched sc, const float* _
 #pragma unroll
                 for (int e = 0; e < 8; ++e) pre[j][e] = src[j][(int64_t)(r0 + e) * PB];
         };
-        const int abl = sc.dbg_fill >> 16;  // ASVD_FC_ABLATE: 1 no MFMAs, 2 no split / LDS stores, 4 no panel loads after the first chunk (timing only)
         fetch(0);
         for (int r0 = 0; r0 < m_pad; r0 += 32) {
             __syncthreads();  // previous chunk's operands fully consumed
-            if (!(abl & 2)) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 u32x4 p1, p2, p3;
@@ -895,10 +893,8 @@ __global__ __launch_bounds__(256) void fullcheck_kernel(Sched sc, const float* _
                 u32x4* o = oimg + ((((tid >> 7) + 2 * j) * 2 + sks) * 3) * 64 + sl;
                 o[0] = p1; o[64] = p2; o[128] = p3;
             }
-            }
             __syncthreads();
-            if (r0 + 32 < m_pad && !(abl & 4)) fetch(r0 + 32);
-            if (abl & 1) continue;
+            if (r0 + 32 < m_pad) fetch(r0 + 32);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const u32x4* ob = oimg + (((4 + w) * 2 + ks) * 3) * 64 + lane;
@@ -1606,6 +1602,85 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ G,
     }
 }
 
+// The same block step as two launches: the diagonal factorisation WAVE-LOCAL, one wave per problem, and the block row by fp64 MFMA.
+// chol_panel_kernel spends ~150 of its 183 us in 64 column steps of three workgroup barriers each, in every workgroup of the block row
+// (the Cholesky of a 4096-column Gram matrix is a chain of 64 such launches: 11.7 ms per step of 32 problems).  chol_diag_wave_kernel holds
+// the block with lane = column, registers = rows (64 doubles): a column step is two v_readlane for the pivot, two per row multiplier and one
+// v_fma_f64 per remaining row, no barrier; the inverse is a back substitution per lane against R read as LDS broadcasts.  R_jj goes to the
+// side buffer Dg (r_to_f32 reads the diagonal blocks there), R_jj^-1 over the block itself, where chol_trsm_kernel — one workgroup per
+// block of the block row, Y = R_jj^-T G_jq with v_mfma_f64_16x16x4, wave w: rows 16 w .. 16 w + 15 — reads it.
+// (Factorising inside every workgroup of the block row, as chol_panel_kernel does, was measured at 384 us per launch with this wave-local
+// form: 2048 one-wave-busy workgroups of 256 VGPRs and 67 KB LDS run in four rounds.)
+__device__ __forceinline__ double rdlane_f64(double v, int l) {
+    const long long x = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_readlane((int)(x & 0xffffffffll), l), hi = __builtin_amdgcn_readlane((int)(x >> 32), l);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+}
+__global__ __launch_bounds__(64) void chol_diag_wave_kernel(double* __restrict__ G, int64_t ldg, int64_t g_batch_stride, int jb,
+                                                            int* __restrict__ fail, double* __restrict__ Dg, int nbk) {
+    __shared__ double Rs[CB * CLD];
+    __shared__ double dinv[CB];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    double* Gb = G + (int64_t)b * g_batch_stride;
+    const int64_t o = (int64_t)jb * CB;
+    double a[CB];
+#pragma unroll
+    for (int i = 0; i < CB; ++i) a[i] = (lane >= i) ? Gb[(o + i) * ldg + o + lane] : 0.0;
+    bool bad = false;
+#pragma unroll
+    for (int c = 0; c < CB; ++c) {
+        double piv = rdlane_f64(a[c], c);
+        if (!(piv > 1e-13)) { bad = true; piv = 1e-13; }  // unit-diagonal scaling: pivots live in (0, 1]
+        const double r = sqrt(piv), rinv = 1.0 / r;
+        a[c] = (lane == c) ? r : ((lane > c) ? a[c] * rinv : 0.0);
+        if (lane == c) dinv[c] = rinv;
+#pragma unroll
+        for (int i = c + 1; i < CB; ++i) a[i] = fma(-rdlane_f64(a[c], i), a[c], a[i]);  // lanes < i carry junk below the diagonal: never read
+    }
+    if (bad && lane == 0) atomicMax(&fail[b], jb + 1);
+    double* dgo = Dg + ((int64_t)b * nbk + jb) * (CB * CB);
+#pragma unroll
+    for (int i = 0; i < CB; ++i) {
+        const double v = (lane >= i) ? a[i] : 0.0;
+        Rs[i * CLD + lane] = v;
+        dgo[i * CB + lane] = v;
+    }
+    // inverse: lane j solves R z = e_j from the bottom up; z_i = 0 for i > j falls out of the masks (a wave's LDS operations complete in order)
+    double z[CB];
+#pragma unroll
+    for (int i = CB - 1; i >= 0; --i) {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = i + 1; k < CB; ++k) acc = fma(Rs[i * CLD + k], z[k], acc);
+        const double di = dinv[i];
+        z[i] = (lane == i) ? di : ((lane > i) ? -acc * di : 0.0);
+    }
+#pragma unroll
+    for (int i = 0; i < CB; ++i) Gb[(o + i) * ldg + o + lane] = z[i];
+}
+// grid (nbk - jb - 1, batch): block q + 1 of block row jb.  Y[i][c] = sum_{k <= i} Ri[k][i] B[k][c], in place.
+__global__ __launch_bounds__(256) void chol_trsm_kernel(double* __restrict__ G, int64_t ldg, int64_t g_batch_stride, int jb) {
+    const int q = blockIdx.x + 1, b = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    double* Gb = G + (int64_t)b * g_batch_stride;
+    const int64_t o = (int64_t)jb * CB, oc = (int64_t)(jb + q) * CB;
+    const int kk = lane >> 4, cc = lane & 15;
+    const double* __restrict__ Rip = Gb + (o + kk) * ldg + o + 16 * w + cc;
+    double* Bp = Gb + (o + kk) * ldg + oc + cc;
+    f64x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    for (int k0 = 0; k0 < 16 * (w + 1); k0 += 4) {  // wave w owns rows 16 w .. 16 w + 15: k runs to its last row only
+        const double av = Rip[(int64_t)k0 * ldg];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Bp[(int64_t)k0 * ldg + t * 16], acc[t], 0, 0, 0);
+    }
+    __syncthreads();  // every wave has read the rows of B it needs (all rows <= its own last one) before any row is overwritten
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) Gb[(o + 16 * w + kk + 4 * u) * ldg + oc + t * 16 + cc] = acc[t][u];
+}
+
 // trailing update  G_{ib,kb} -= R_{jb,ib}^T R_{jb,kb}  (jb < ib <= kb), fp64 MFMA, one workgroup per 64x64 block
 __global__ __launch_bounds__(256) void chol_syrk_kernel(double* __restrict__ G, int64_t ldg, int64_t g_batch_stride, int jb, int nbk) {
     const int ib = jb + 1 + blockIdx.x, kb = jb + 1 + blockIdx.y, b = blockIdx.z;  // gridDim.x may stop short of the last block row (strip of a group)
@@ -1679,6 +1754,36 @@ __global__ void r_to_f32_kernel(const double* __restrict__ G, int64_t ldg, int64
     float* Rb = R + (int64_t)b * r_batch_stride;
     if (!transposed) Rb[(int64_t)i * n_pad + j] = (float)v;
     else Rb[(int64_t)j * n_pad + i] = (float)v;
+}
+
+// R^T through 32x32 LDS tiles: r_to_f32_kernel with transposed != 0 stores one float per 4-byte-strided row, a column at a time
+// (3.4 ms per 32 x 4096^2); here both the fp64 reads and the fp32 stores run along rows.  grid (n_pad/32, n_pad/32, batch), 256 threads.
+__global__ __launch_bounds__(256) void r_to_f32_t_kernel(const double* __restrict__ G, int64_t ldg, int64_t g_batch_stride, const double* __restrict__ Dg,
+                                                         const double* __restrict__ d, int n_pad, float* __restrict__ R, int64_t r_batch_stride) {
+    __shared__ float tile[32][33];
+    const int tj = blockIdx.x, ti = blockIdx.y, b = blockIdx.z;  // tile rows ti (of R), columns tj
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    float* Rb = R + (int64_t)b * r_batch_stride;
+    if (tj < ti) {  // strictly below the block diagonal of R: zeros (its transpose is the tile (tj, ti) of R^T)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) Rb[(int64_t)(tj * 32 + ty + 8 * u) * n_pad + ti * 32 + tx] = 0.0f;
+        return;
+    }
+    const int j = tj * 32 + tx;
+    const double dj = d[(int64_t)b * n_pad + j];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int i = ti * 32 + ty + 8 * u;
+        double rv = 0.0;
+        if (j >= i) {
+            if ((i / CB) == (j / CB)) rv = Dg[((int64_t)b * (n_pad / CB) + i / CB) * (CB * CB) + (i % CB) * CB + (j % CB)];  // diagonal blocks
+            else rv = G[(int64_t)b * g_batch_stride + (int64_t)i * ldg + j];
+        }
+        tile[ty + 8 * u][tx] = (float)(rv * dj);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) Rb[(int64_t)(tj * 32 + ty + 8 * u) * n_pad + ti * 32 + tx] = tile[tx][ty + 8 * u];
 }
 
 // out[rows, k] = X[rows, cols] * Vr[cols, k] * diag(1 / S)   — left vectors of the tall problem from the packed panels.
@@ -2306,7 +2411,6 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
         sc.super_order = super_grouped_for(p) ? 2 : (super_rr_for(p) ? 0 : 1);
         if (sc.super_order == 2) set_group_table(sc, p.ns);
         sc.dbg_fill = getenv("ASVD_EVD_LDSFILL") ? atoi(getenv("ASVD_EVD_LDSFILL")) : 0;
-        if (getenv("ASVD_FC_ABLATE")) sc.dbg_fill |= atoi(getenv("ASVD_FC_ABLATE")) << 16;  // timing-only ablations of the snapshot kernel (wrong results)
         sc.evd_pairs = getenv("ASVD_EVD_PAIRS") ? std::max(1, std::min(64, atoi(getenv("ASVD_EVD_PAIRS")))) : PW / 2;
     }
     const int nsteps = pair_order_xor() ? 2 * p.npairs - 1 : p.nb - 1;
@@ -2974,12 +3078,20 @@ static int svd_tall(int batch, const void* const* a_host, int a_dtype, int64_t m
         for (int j0 = 0; j0 < nbk; j0 += cg) {
             const int j1 = std::min(nbk, j0 + cg);
             for (int jb = j0; jb < j1; ++jb) {
-                chol_panel_kernel<<<dim3(std::min(nbk - jb, 16), batch), 256, 0, st>>>(Gs, ldg, gbs, jb, fail, Dg, nbk);
+                static const bool panel_wave = !(getenv("ASVD_CHOL_PANEL_WAVE") && atoi(getenv("ASVD_CHOL_PANEL_WAVE")) == 0);
+                if (panel_wave) {
+                    chol_diag_wave_kernel<<<batch, 64, 0, st>>>(Gs, ldg, gbs, jb, fail, Dg, nbk);
+                    if (jb + 1 < nbk) chol_trsm_kernel<<<dim3(nbk - jb - 1, batch), 256, 0, st>>>(Gs, ldg, gbs, jb);
+                }
+                else chol_panel_kernel<<<dim3(std::min(nbk - jb, 16), batch), 256, 0, st>>>(Gs, ldg, gbs, jb, fail, Dg, nbk);
                 if (jb + 1 < j1) chol_syrk_kernel<<<dim3(j1 - jb - 1, nbk - jb - 1, batch), 256, 0, st>>>(Gs, ldg, gbs, jb, nbk);
             }
             if (j1 < nbk) chol_syrk_multi_kernel<<<dim3(nbk - j1, nbk - j1, batch), 256, 0, st>>>(Gs, ldg, gbs, j0, j1 - j0, nbk);
         }
-        r_to_f32_kernel<<<dim3((unsigned)ceil_div64(p.n_pad, 256), p.n_pad, batch), 256, 0, st>>>(Gs, ldg, gbs, Dg, dp, p.n_pad, use_rt ? 1 : 0, R, gbs);
+        if (use_rt)  // n_pad is a multiple of 64
+            r_to_f32_t_kernel<<<dim3((unsigned)(p.n_pad / 32), (unsigned)(p.n_pad / 32), batch), 256, 0, st>>>(Gs, ldg, gbs, Dg, dp, p.n_pad, R, gbs);
+        else
+            r_to_f32_kernel<<<dim3((unsigned)ceil_div64(p.n_pad, 256), p.n_pad, batch), 256, 0, st>>>(Gs, ldg, gbs, Dg, dp, p.n_pad, 0, R, gbs);
     }
     std::vector<int> hfail(batch, 0);
     ASVD_HIP_CHECK(hipMemcpyAsync(hfail.data(), fail, (size_t)batch * sizeof(int), hipMemcpyDeviceToHost, st));
