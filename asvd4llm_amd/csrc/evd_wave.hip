@@ -345,12 +345,178 @@ constexpr int E12_SLICE = 64 * M_LD;                // float offset of the two e
 constexpr int E12_CS = E12_SLICE + 2 * QH_FLOATS;   // float offset of the two row-coefficient buffers
 constexpr int E12_SMEM_FLOATS = E12_CS + 2 * 128;
 
+// --------------------------------------------------------------------------------------------------
+// Cooperative sweep (latency form): NW waves share ONE solve, wave h holds rows r0 = h * 64 / NW .. of the image and of Q (lane = column
+// as before).  A lone wave issues one VALU instruction per ~4.7 cycles, so a launch with fewer solves than SIMDs (batch 1, 768-column
+// problems, any batch <= 8 at 4096 columns) waits 91 us per sweep with 3/4 of the chip idle; split four ways a phase is ~180 instead of
+// ~600 instructions per wave plus one workgroup barrier.  Same arithmetic, element for element, as evdw_phase (bit-identical results):
+//   * every wave computes all 64 rotations itself (diagonal vector and pivot vector are replicated) and rotates only its own rows;
+//   * the pivots of the next phase are elements of rows that live in different waves: each wave publishes the ones it owns into a
+//     shared vector (one per parity: written in one phase, read in the next, rewritten two barriers later);
+//   * phase B pairs rows (2k+1, 2k+2): the pair at a block boundary needs the neighbour's boundary row as it was after phase A —
+//     published together with the pivots, one barrier per phase in total.
+// LDS per solve (floats): XG 64x64 (scatter / gather of the image) | XQ 64x64 (gather of Q) | PIV 2x64 | BROW 2 x NW x 64 | CS NW x 128 | DIAG 64 | FLAG 4
+template <int NW> struct Coop {
+    static constexpr int RB = 64 / NW;
+    static constexpr int XG = 0, XQ = 4096, PIV = 8192, BROW = PIV + 128, CS = BROW + 2 * NW * 64, DIAG = CS + NW * 128, FLAG = DIAG + 64;
+    static constexpr int FLOATS = FLAG + 4;
+};
+
+template <int NW>
+__device__ __forceinline__ void coop_phase_a(float (&gl)[64 / NW], float (&ql)[64 / NW], float& diag, const float bpiv, const int lane, const int r0,
+                                             const int h, float* __restrict__ L) {
+    constexpr int RB = 64 / NW;
+    float* __restrict__ cslds = L + Coop<NW>::CS + h * 128;
+    const bool odd = (lane & 1) != 0, lower = !odd;
+    const float dpart = dppf<DPP_XOR1>(diag), bo = dppf<DPP_XOR1>(bpiv);
+    const float b = lower ? bpiv : bo;
+    const float a_ = lower ? diag : dpart, d_ = lower ? dpart : diag;
+    float c, s, t;
+    jacobi_rot(a_, d_, b, c, s, t);
+    diag = fmaf(lower ? t : -t, b, lower ? d_ : a_);
+    const float own = lower ? s : -s;
+    *(float2*)(cslds + 2 * lane) = make_float2(c, s);
+    float bn = 0.0f;
+#pragma unroll
+    for (int kp = 0; kp < RB / 2; ++kp) {
+        const float2 cs2 = *(const float2*)(cslds + 2 * (r0 + 2 * kp));
+        const float ck = cs2.x, sk = cs2.y;
+        const float x0 = gl[2 * kp], x1 = gl[2 * kp + 1];
+        const float y0 = fmaf(ck, x1, sk * x0);
+        const float y1 = fmaf(-sk, x1, ck * x0);
+        const float z0 = fmaf(own, y0, c * dppf<DPP_XOR1>(y0));
+        const float z1 = fmaf(own, y1, c * dppf<DPP_XOR1>(y1));
+        gl[2 * kp] = z0;
+        gl[2 * kp + 1] = z1;
+        bn = (lane == r0 + 2 * kp - 1) ? z0 : bn;   // phase B: lower lanes are odd L, their pivot is row L + 1
+    }
+    if (odd && lane + 1 >= r0 && lane + 1 < r0 + RB) L[Coop<NW>::PIV + lane] = bn;           // pivots of phase B (parity buffer 0)
+    L[Coop<NW>::BROW + (2 * h) * 64 + lane] = gl[0];                                           // boundary rows as phase B will find them
+    L[Coop<NW>::BROW + (2 * h + 1) * 64 + lane] = gl[RB - 1];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) ql[i] = fmaf(own, ql[i], c * dppf<DPP_XOR1>(ql[i]));        // Q last: the stores above are under way meanwhile
+}
+
+template <int NW>
+__device__ __forceinline__ void coop_phase_b(float (&gl)[64 / NW], float (&ql)[64 / NW], float& diag, const float bpiv, const int lane, const int r0,
+                                             const int h, float* __restrict__ L) {
+    constexpr int RB = 64 / NW;
+    float* __restrict__ cslds = L + Coop<NW>::CS + h * 128;
+    const bool odd = (lane & 1) != 0, lower = odd;
+    const bool idle = (lane == 0) || (lane == 63);
+    const float d_up = dppf<DPP_SHL1>(diag), d_dn = dppf<DPP_SHR1>(diag), b_dn = dppf<DPP_SHR1>(bpiv);
+    const float b = lower ? bpiv : b_dn;
+    const float a_ = lower ? diag : d_dn, d_ = lower ? d_up : diag;
+    float c, s, t;
+    jacobi_rot(a_, d_, b, c, s, t);
+    const float nd = fmaf(lower ? t : -t, b, lower ? d_ : a_);
+    diag = idle ? diag : nd;
+    const float own = idle ? 1.0f : (lower ? s : -s);
+    const float cl = (lower && !idle) ? c : 0.0f;
+    const float cr = (!lower && !idle) ? c : 0.0f;
+    c = idle ? 1.0f : c;
+    s = idle ? 0.0f : s;
+    *(float2*)(cslds + 2 * lane) = make_float2(c, s);
+    float bn = 0.0f;
+    if (h == 0) {   // row 0 is idle: columns only
+        gl[0] = col_update_b(gl[0], own, cl, cr);
+    } else {        // upper member of the pair (r0 - 1, r0): the lower member is the previous wave's last row
+        const float2 cs2 = *(const float2*)(cslds + 2 * (r0 - 1));
+        const float xp = L[Coop<NW>::BROW + (2 * (h - 1) + 1) * 64 + lane];
+        gl[0] = col_update_b(fmaf(-cs2.y, gl[0], cs2.x * xp), own, cl, cr);
+    }
+#pragma unroll
+    for (int j = 0; j < RB / 2 - 1; ++j) {
+        const int pl = 2 * j + 1;
+        const float2 cs2 = *(const float2*)(cslds + 2 * (r0 + pl));
+        const float ck = cs2.x, sk = cs2.y;
+        const float x0 = gl[pl], x1 = gl[pl + 1];
+        const float y0 = fmaf(ck, x1, sk * x0);
+        const float y1 = fmaf(-sk, x1, ck * x0);
+        const float z0 = col_update_b(y0, own, cl, cr);
+        const float z1 = col_update_b(y1, own, cl, cr);
+        gl[pl] = z0;
+        gl[pl + 1] = z1;
+        bn = (lane == r0 + pl - 1) ? z0 : bn;       // phase A: lower lanes are even L, their pivot is row L + 1
+    }
+    if (h == NW - 1) {   // row 63 is idle
+        const float z = col_update_b(gl[RB - 1], own, cl, cr);
+        gl[RB - 1] = z;
+        bn = (lane == 62) ? z : bn;
+    } else {             // lower member of the pair (r0 + RB - 1, r0 + RB): the upper member is the next wave's first row
+        const float2 cs2 = *(const float2*)(cslds + 2 * (r0 + RB - 1));
+        const float xq = L[Coop<NW>::BROW + (2 * (h + 1)) * 64 + lane];
+        const float z0 = col_update_b(fmaf(cs2.x, xq, cs2.y * gl[RB - 1]), own, cl, cr);
+        gl[RB - 1] = z0;
+        bn = (lane == r0 + RB - 2) ? z0 : bn;
+    }
+    if (!odd && lane + 1 >= r0 && lane + 1 < r0 + RB) L[Coop<NW>::PIV + 64 + lane] = bn;      // pivots of phase A (parity buffer 1)
+#pragma unroll
+    for (int i = 0; i < RB; ++i) ql[i] = col_update_b(ql[i], own, cl, cr);
+}
+
+// One full inner sweep (32 phase pairs) of the solve whose LDS block is L.  MAIN (h == 0) enters with the image in g, the state in
+// diag / bpiv and `rotate`; it leaves with g, q, diag as evdw_sweep would (q = identity when the solve does not rotate).  Helpers pass
+// dummies.  Every wave of the workgroup executes the same 66 barriers whether its solve rotates or not.
+template <int NW>
+__device__ __forceinline__ void coop_sweep(float (&g)[64], float (&q)[64], float& diag, const float bpiv_in, const bool rotate, const int lane, const int h,
+                                           float* __restrict__ L) {
+    constexpr int RB = 64 / NW;
+    const int r0 = h * RB;
+    if (h == 0) {
+        if (rotate) {
+#pragma unroll
+            for (int r = 0; r < 64; ++r) L[Coop<NW>::XG + r * 64 + lane] = g[r];
+        }
+        L[Coop<NW>::DIAG + lane] = diag;
+        L[Coop<NW>::PIV + 64 + lane] = bpiv_in;   // first phase is A: parity buffer 1
+        L[Coop<NW>::PIV + lane] = 0.0f;
+        if (lane == 0) ((int*)L)[Coop<NW>::FLAG] = rotate ? 1 : 0;
+    }
+    __syncthreads();
+    const bool live = ((const int*)L)[Coop<NW>::FLAG] != 0;
+    float gl[RB], ql[RB];
+    float dg = L[Coop<NW>::DIAG + lane];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        gl[i] = live ? L[Coop<NW>::XG + (r0 + i) * 64 + lane] : 0.0f;
+        ql[i] = (lane == r0 + i) ? 1.0f : 0.0f;
+    }
+#pragma unroll 1
+    for (int ph2 = 0; ph2 < 32; ++ph2) {
+        if (live) coop_phase_a<NW>(gl, ql, dg, L[Coop<NW>::PIV + 64 + lane], lane, r0, h, L);
+        __syncthreads();
+        if (live) coop_phase_b<NW>(gl, ql, dg, L[Coop<NW>::PIV + lane], lane, r0, h, L);
+        __syncthreads();
+    }
+    if (live) {
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            L[Coop<NW>::XG + (r0 + i) * 64 + lane] = gl[i];
+            L[Coop<NW>::XQ + (r0 + i) * 64 + lane] = ql[i];
+        }
+    }
+    __syncthreads();
+    if (h == 0 && live) {
+#pragma unroll
+        for (int r = 0; r < 64; ++r) {
+            g[r] = L[Coop<NW>::XG + r * 64 + lane];
+            q[r] = L[Coop<NW>::XQ + r * 64 + lane];
+        }
+        diag = dg;
+    }
+}
+
 // agent-scope load of data another wave of the workgroup (or this wave) wrote to global memory earlier in the launch: L2, never this CU's L1
 __device__ __forceinline__ float ldg_sc1(const float* p) { return __int_as_float(__hip_atomic_load((const int*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
 
 __device__ __forceinline__ int mfma_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }  // C/D row of v_mfma_f32_32x32x2_f32
 
-__global__ __launch_bounds__(128, 2) void evdw12_kernel(Sched sc, unsigned* __restrict__ maxoff_bits, int* __restrict__ nrot,
+// NW = 1: two waves per super-pair, each solve wave-local (throughput form).  NW = 4: eight waves, waves 0 / 1 are the MAIN waves of the two
+// solves and run exactly the code of the NW = 1 form except that their sweeps are cooperative (coop_sweep) with the helper waves
+// 2 h + sp, h = 1..3, which only take part in the sweeps and the workgroup barriers (latency form: one workgroup per CU).
+template <int NW>
+__global__ __launch_bounds__(128 * NW, NW == 1 ? 2 : 1) void evdw12_kernel(Sched sc, unsigned* __restrict__ maxoff_bits, int* __restrict__ nrot,
                                                         const int* __restrict__ done, float tol, int inner_sweeps, int nb, int step, int kb,
                                                         EvdV3 v3, long long* __restrict__ trace) {
     extern __shared__ __attribute__((aligned(16))) float e12_smem[];
@@ -362,9 +528,10 @@ __global__ __launch_bounds__(128, 2) void evdw12_kernel(Sched sc, unsigned* __re
     };
     stamp();
     float* const R16 = e12_smem;                // multi-purpose region (see above)
-    const int tid = threadIdx.x, lane = tid & 63, sp = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid = threadIdx.x, lane = tid & 63, wv_ = __builtin_amdgcn_readfirstlane(tid >> 6), sp = wv_ & 1, hw = wv_ >> 1;
     const int hi = lane >> 5, cc = lane & 31;
     const int pair = blockIdx.x, b = blockIdx.y, npairs = gridDim.x;
+    float* const LC = e12_smem + E12_SMEM_FLOATS + sp * Coop<NW == 1 ? 4 : NW>::FLOATS;   // cooperative-sweep block of this solve (NW > 1 only)
     ASVD_KERNEL_ACQUIRE(sc);
     if (ld_flag(done + b)) return;              // uniform over the workgroup
     const int64_t slot = (int64_t)b * npairs + pair;
@@ -379,6 +546,16 @@ __global__ __launch_bounds__(128, 2) void evdw12_kernel(Sched sc, unsigned* __re
     float g[64], q[64];
     float diag, bpiv, off0, offt, cs;
     int rnk;
+    if constexpr (NW > 1) {
+        if (hw > 0) {   // helper wave: the two cooperative sweeps and the barriers of the main waves in between, nothing else
+            float dd = 0.0f;
+            coop_sweep<NW>(g, q, dd, 0.0f, false, lane, hw, LC);
+            __syncthreads(); __syncthreads();                       // end of step 0
+            __syncthreads(); __syncthreads(); __syncthreads();      // step-1 image assembly
+            coop_sweep<NW>(g, q, dd, 0.0f, false, lane, hw, LC);
+            return;
+        }
+    }
 
     // ================================ step 0: sub-pair (sp, 2 + sp) ================================
     {
@@ -421,7 +598,8 @@ __global__ __launch_bounds__(128, 2) void evdw12_kernel(Sched sc, unsigned* __re
         evdw_identity(q, lane);
         stamp();  // 2: measured
         asm volatile("" ::: "memory");
-        if (rotate) evdw_sweep(g, q, diag, bpiv, lane, ((off0 > 0.05f) ? inner_sweeps : min(1, inner_sweeps)) * sc.evd_pairs, e12_smem + E12_CS + sp * 128);
+        if constexpr (NW > 1) coop_sweep<NW>(g, q, diag, bpiv, rotate, lane, 0, LC);
+        else if (rotate) evdw_sweep(g, q, diag, bpiv, lane, ((off0 > 0.05f) ? inner_sweeps : min(1, inner_sweeps)) * sc.evd_pairs, e12_smem + E12_CS + sp * 128);
         asm volatile("" ::: "memory");   // no load of a later stage is hoisted above the sweep (its registers would be spilled across it)
         stamp();  // 3: swept
         evdw_finish(q, diag, lane, rotate, cs, rnk);
@@ -543,7 +721,8 @@ __global__ __launch_bounds__(128, 2) void evdw12_kernel(Sched sc, unsigned* __re
             if (rotate && offt >= tol) atomicAdd(&nrot[b], 1);
         }
         evdw_identity(q, lane1);
-        if (rotate) evdw_sweep(g, q, diag, bpiv, lane1, ((off0 > 0.05f) ? inner_sweeps : min(1, inner_sweeps)) * sc.evd_pairs, e12_smem + E12_CS + sp * 128);
+        if constexpr (NW > 1) coop_sweep<NW>(g, q, diag, bpiv, rotate, lane1, 0, LC);
+        else if (rotate) evdw_sweep(g, q, diag, bpiv, lane1, ((off0 > 0.05f) ? inner_sweeps : min(1, inner_sweeps)) * sc.evd_pairs, e12_smem + E12_CS + sp * 128);
         asm volatile("" ::: "memory");
         stamp();  // 10: swept
         evdw_finish(q, diag, lane1, rotate, cs, rnk);
@@ -659,19 +838,31 @@ void launch_evdw0(bool keepg, int npairs, int batch, hipStream_t st, const Sched
 }
 
 int evdw12_lds_bytes() { return (int)(E12_SMEM_FLOATS * sizeof(float)); }
+constexpr int EVDQ_NW = 4;
+static int evdq12_lds_bytes() { return (int)((E12_SMEM_FLOATS + 2 * Coop<EVDQ_NW>::FLOATS) * sizeof(float)); }
 
 void launch_evdw12(int npairs_s, int batch, hipStream_t st, const Sched& sc, unsigned* maxoff_bits, int* nrot, const int* done, float tol,
                    int inner_sweeps, int nb, int step, int kb, const EvdV3& v3) {
-    static bool attr_done = false;   // idempotent; a race only repeats the call
+    static bool attr_done = false;   // idempotent; a race only repeats the calls
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)evdw12_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, evdw12_lds_bytes());
+        (void)hipFuncSetAttribute((const void*)evdw12_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, evdw12_lds_bytes());
+        (void)hipFuncSetAttribute((const void*)evdw12_kernel<EVDQ_NW>, hipFuncAttributeMaxDynamicSharedMemorySize, evdq12_lds_bytes());
         attr_done = true;
+    }
+    // latency form when the launch cannot even give every CU one workgroup: four waves per solve (bit-identical results).  It needs one
+    // full inner sweep per visit (the default) and the standard 32 phase pairs.  ASVD_EVDQ=0 / 1 forces the choice.
+    static const int evdq_env = getenv("ASVD_EVDQ") ? atoi(getenv("ASVD_EVDQ")) : -1;
+    const bool coop = inner_sweeps == 1 && sc.evd_pairs == 32 && (evdq_env == 1 || (evdq_env != 0 && (long long)npairs_s * batch <= 256));
+    if (coop) {
+        evdw12_kernel<EVDQ_NW><<<dim3((unsigned)npairs_s, (unsigned)batch), 128 * EVDQ_NW, evdq12_lds_bytes(), st>>>(sc, maxoff_bits, nrot, done, tol, inner_sweeps, nb,
+                                                                                                              step, kb, v3, nullptr);
+        return;
     }
     static long long* trace = nullptr;
     static int traced = 0;
     if (getenv("ASVD_EVDW_TRACE") && !trace) (void)hipMalloc(&trace, 32 * sizeof(long long));
-    evdw12_kernel<<<dim3((unsigned)npairs_s, (unsigned)batch), 128, evdw12_lds_bytes(), st>>>(sc, maxoff_bits, nrot, done, tol, inner_sweeps, nb, step,
-                                                                                            kb, v3, traced < 3 ? trace : nullptr);
+    evdw12_kernel<1><<<dim3((unsigned)npairs_s, (unsigned)batch), 128, evdw12_lds_bytes(), st>>>(sc, maxoff_bits, nrot, done, tol, inner_sweeps, nb, step,
+                                                                                               kb, v3, traced < 3 ? trace : nullptr);
     if (trace && traced < 3) {
         long long h[32];
         (void)hipStreamSynchronize(st);

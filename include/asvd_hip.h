@@ -110,8 +110,9 @@ int asvd_scale_cols(const void* w, int w_dtype, int64_t m, int64_t n, int64_t ld
  *
  * Algorithm: the oriented matrix (rows >= cols) is reduced to a square one by a Cholesky-QR in fp64 (Gram matrix
  * by fp64 MFMA, columns ordered by norm), then one-sided block Jacobi runs on R^T: XOR pair schedule over 32-column panels;
- * dense sweeps work on 64-column super-panels (one 6-tile Gram pass, two launches of 64x64 eigen-solves in LDS, one 128-wide
- * update pass in split-bf16 arithmetic per step), tail sweeps rotate only the pairs a blocked X^T X snapshot marks.  Right
+ * dense sweeps work on 64-column super-panels (per step ONE launch of wave-local 64x64 eigen-solves — one wave per solve, the
+ * matrix in registers, both inner steps of a super-pair — and one 128-wide update pass in split-bf16 arithmetic fused with the
+ * Gram tiles of the next step), tail sweeps rotate only the pairs a blocked X^T X snapshot marks.  Right
  * vectors are the rotated columns, left vectors X V by one GEMM, sigma_j = |X v_j| in fp64.  No vector is accumulated during
  * the sweeps.  Problems too small or rank-deficient for the reduction take the same sweeps on the matrix itself.
  *
@@ -129,8 +130,12 @@ int asvd_scale_cols(const void* w, int w_dtype, int64_t m, int64_t n, int64_t ld
  * Host-synchronous: the call returns when S/U/V are complete.  Sync points: one after the reduction (Cholesky breakdown flag),
  * one per Jacobi sweep (convergence flags; a second one when a sparse sweep reads back its pair marks), one at the end.
  * Everything is enqueued on `stream` (no other stream is used unless ASVD_GROUPS / ASVD_EPI_STREAMS ask for it); concurrent
- * calls from different host threads on different streams and workspaces are safe (no shared mutable state; the profiling
- * counters are per thread).  Returns worst status over the batch.
+ * calls from different host threads on different streams and workspaces are safe: no shared mutable state — schedule tables
+ * and modes travel by value in the kernel arguments, not in __constant__ memory; the profiling counters are per thread — and
+ * no kernel uses scratch.  tests/test_gpu_concurrency.py holds the library to it (two threads x 8 x 4096^2 next to a stream of
+ * foreign GEMMs: bit-identical results and sweep counts against serial runs).  Rounds 1-2 did NOT keep this promise: their LDS
+ * eigen-solver raced under concurrent load; it is reachable only through ASVD_EVDW=0 now.
+ * Returns worst status over the batch.
  */
 int asvd_svd_worksize(int batch, int64_t m, int64_t n, int want_vectors, size_t* bytes);
 int asvd_svd_batched(int batch, const void* const* a_host, int a_dtype, int64_t m, int64_t n, int64_t lda,

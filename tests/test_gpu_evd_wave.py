@@ -102,3 +102,35 @@ def test_one_sweep_follows_the_cpu_prototype(gpu):
         assert np.abs(off_gpu).max() <= 1.5 * np.abs(off_cpu).max() + 1e-6 * scale
         qd = Q[b].astype(np.float64)
         assert np.abs(qd.T @ qd - np.eye(64)).max() <= 3e-6
+
+
+_COOP_SNIPPET = r"""
+import os, sys, numpy as np, torch
+sys.path.insert(0, {root!r})
+from asvd4llm_amd import ops
+g = torch.Generator().manual_seed(11)
+n, batch = {n}, {batch}
+mats = [(torch.randn(n, n, generator=g) / n ** 0.5).cuda() for _ in range(batch)]
+scales = [torch.rand(n, generator=g).add_(0.5).cuda() for _ in range(batch)]
+U, S, V, infos = ops.svd_batched(mats, scales)
+torch.cuda.synchronize()
+np.savez({out!r}, S=torch.stack(S).cpu().numpy(), U=torch.stack(U).cpu().numpy(), V=torch.stack(V).cpu().numpy(),
+         sweeps=np.array([i.sweeps for i in infos]), status=np.array([i.status for i in infos]))
+"""
+
+
+@pytest.mark.parametrize("n,batch", [(768, 3), (2048, 2)])
+def test_cooperative_launch_is_bit_identical(gpu, tmp_path, n, batch):
+    """launches with at most 256 super-pairs run four waves per solve (coop_sweep, evd_wave.hip): same arithmetic element for element as the
+    wave-local sweep, so the whole SVD must come out bit-identical with ASVD_EVDQ=0 (wave-local forced) and ASVD_EVDQ=1 (cooperative forced)"""
+    import subprocess
+    import sys
+    res = {}
+    for mode in ("0", "1"):
+        out = str(tmp_path / f"evdq{mode}.npz")
+        env = dict(os.environ, ASVD_EVDQ=mode)
+        subprocess.run([sys.executable, "-c", _COOP_SNIPPET.format(root=ROOT, n=n, batch=batch, out=out)], check=True, env=env, timeout=600)
+        res[mode] = np.load(out)
+    assert (res["0"]["status"] == 0).all() and np.array_equal(res["0"]["sweeps"], res["1"]["sweeps"])
+    for k in ("S", "U", "V"):
+        assert np.array_equal(res["0"][k].view(np.uint32), res["1"][k].view(np.uint32)), k
