@@ -238,114 +238,6 @@ __device__ __forceinline__ void evdw_store_diag_blocks(const float (&g)[64], con
 }
 
 // --------------------------------------------------------------------------------------------------
-// Single-level solves: the body of evd_kernel<0, KEEPG>, one WAVE per pair, four pairs per 256-thread workgroup.
-// LDS: one 32 x 33 transposer per wave (the JI block of the image is the mirror of the stored IJ block).
-constexpr int EVDW_TR_FLOATS = 32 * 33;
-
-template <int KEEPG>
-__global__ __launch_bounds__(256, 2) void evdw0_kernel(Sched sc, const float* __restrict__ Gpart, int nsplit, float* __restrict__ Qbuf,
-                                                       int* __restrict__ active, unsigned* __restrict__ maxoff_bits, int* __restrict__ nrot,
-                                                       const int* __restrict__ done, float tol, int inner_sweeps, int nb, int step, int kb,
-                                                       const int* __restrict__ plist, int list_stride, int npairs, EvdV3 v3) {
-    __shared__ float trbuf[4][EVDW_TR_FLOATS];
-    __shared__ __attribute__((aligned(16))) float csbuf[4][EVDW_CS_FLOATS];
-    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int pair = blockIdx.x * 4 + wv, b = blockIdx.y;
-    ASVD_KERNEL_ACQUIRE(sc);
-    if (pair >= npairs || ld_flag(done + b)) return;   // no workgroup barrier below: the waves are independent
-    const int64_t slot = (int64_t)b * npairs + pair;
-    int* act_flag = active + slot;
-    int I, J;
-    if (!get_pair(sc, plist, list_stride, b, nb, step, pair, I, J)) {  // padding pair / empty slot: nothing to rotate
-        if (lane == 0) *act_flag = 0;
-        return;
-    }
-    float g[64], q[64];
-    {
-        // image rows 0..31: [II | IJ] read as two 128-byte row segments per register; rows 32..63: the JJ block for the upper lanes,
-        // the lower lanes get IJ^T through the transposer.  Partials are summed in ascending order (as evd_body does).
-        const float* __restrict__ gp = Gpart + slot * nsplit * 3072;
-        const int hi = lane >> 5, cc = lane & 31;
-#pragma unroll
-        for (int r = 0; r < 64; ++r) g[r] = 0.0f;
-#pragma unroll 2
-        for (int s2 = 0; s2 < nsplit; ++s2) {
-            const float* __restrict__ p = gp + (int64_t)s2 * 3072;
-#pragma unroll
-            for (int r = 0; r < 32; ++r) g[r] += p[hi * 1024 + r * 32 + cc];
-#pragma unroll
-            for (int r = 0; r < 32; ++r) g[32 + r] += p[2048 + r * 32 + cc];
-        }
-        float* tr = trbuf[wv];
-        if (hi) {
-#pragma unroll
-            for (int r = 0; r < 32; ++r) tr[cc * 33 + r] = g[r];      // IJ[r][cc]  ->  tr[cc][r]
-        }
-        // a wave's LDS operations complete in order: no barrier needed for a wave-private buffer
-        if (!hi) {
-#pragma unroll
-            for (int r = 0; r < 32; ++r) g[32 + r] = tr[r * 33 + cc];  // G[32 + r][cc] = IJ[cc][r]
-        }
-    }
-    float diag, bpiv;
-    evdw_init_state(g, lane, diag, bpiv);
-    float off0, offt;
-    evdw_measure(g, diag, lane, I < kb, J < kb, off0, offt);
-    const bool is_nan = off0 != off0;
-    const bool rotate = !(is_nan || off0 < tol);
-    if (lane == 0) {
-        atomicMax(&maxoff_bits[b], is_nan ? 0x7fc00000u : __float_as_uint(offt));
-        *act_flag = rotate ? 1 : 0;
-        if (rotate && offt >= tol) atomicAdd(&nrot[b], 1);
-    }
-    float* d0 = KEEPG ? v3.Gd32 + ((int64_t)b * v3.nbpan + I) * 1024 : nullptr;
-    float* d1 = KEEPG ? v3.Gd32 + ((int64_t)b * v3.nbpan + J) * 1024 : nullptr;
-    if (!rotate) {
-        if (KEEPG && v3.Gd32) {  // carried diagonal blocks of the two panels = the blocks of the matrix itself
-            const int hi = lane >> 5, cc = lane & 31;
-#pragma unroll
-            for (int r = 0; r < 32; ++r) {
-                if (!hi) d0[r * 32 + cc] = g[r];
-                else d1[r * 32 + cc] = g[32 + r];
-            }
-        }
-        ASVD_KERNEL_RELEASE(sc);
-        return;
-    }
-    evdw_identity(q, lane);
-    const int nsw = (off0 > 0.05f) ? inner_sweeps : min(1, inner_sweeps);
-    evdw_sweep(g, q, diag, bpiv, lane, nsw * sc.evd_pairs, csbuf[wv]);
-    float cs;
-    int rnk;
-    evdw_finish(q, diag, lane, true, cs, rnk);
-    float* __restrict__ qo = Qbuf + slot * (PW * PW);
-#pragma unroll
-    for (int r = 0; r < 64; ++r) qo[r * PW + rnk] = q[r] * cs;
-    if (KEEPG && v3.Gd32) evdw_store_diag_blocks(g, diag, cs, rnk, lane, d0, d1);
-    ASVD_KERNEL_RELEASE(sc);
-}
-
-// --------------------------------------------------------------------------------------------------
-// Both inner steps of a super-pair (S, T) in ONE launch: the work of evd_kernel<1,1> + evd_kernel<2,1>.  Two waves per super-pair; the four
-// 32-blocks are S0, S1, T0, T1 = 0..3.
-//   step 0: wave sp solves sub-pair (sp, 2 + sp): carried diagonal blocks of its two panels + the summed cross tile [0,2] / [1,3];
-//           its sorted, rescaled eigenvectors Q0_sp (two 64 x 32 halves) and the two transformed diagonal blocks go to LDS;
-//   step 1: wave sp solves sub-pair (sp, 3 - sp): diagonal blocks from step 0, cross block  Q0_sp[:, :32]^T MM Q0_(1-sp)[:, 32:]  with
-//           MM = M (sp = 0) or M^T (sp = 1), M = G[{0,2},{1,3}] assembled from the other four tiles — two small fp32-MFMA products;
-//           epilogue: the new carried blocks of its two panels (global) and its 128 x 64 column block of Qfin = Q^(0) Q^(1).
-// The step-0 eigenvectors travel between the two waves through GLOBAL memory (v3.Q0, 16 KB per solve, L2 resident; agent-scope loads): with
-// them in LDS the workgroup needed 50 KB = three workgroups per CU, and a launch of 1024 super-pairs ran as 768 + 256 workgroups with half
-// of the SIMDs idle in the second round (measured 570 us per launch; two workgroups per CU: 700 us).  LDS now (33,536 B: four workgroups
-// per CU, every SIMD holds two waves, ONE round):  one 64 x 65 region that is, in turn, the transposer of the step-0 images, the step-0
-// diagonal blocks, the padded M and the staging of the cross blocks, and two wave-private [64][33] slices where the epilogue stages the
-// Q0 half it multiplies.  Row strides 33 / 65 make every MFMA operand read (lanes along a row OR along a column) conflict free.
-constexpr int QH_LD = 33, QH_FLOATS = 64 * QH_LD;   // one half of a Q0: 64 rows x 32 sorted columns
-constexpr int M_LD = 65;
-constexpr int E12_SLICE = 64 * M_LD;                // float offset of the two epilogue slices
-constexpr int E12_CS = E12_SLICE + 2 * QH_FLOATS;   // float offset of the two row-coefficient buffers
-constexpr int E12_SMEM_FLOATS = E12_CS + 2 * 128;
-
-// --------------------------------------------------------------------------------------------------
 // Cooperative sweep (latency form): NW waves share ONE solve, wave h holds rows r0 = h * 64 / NW .. of the image and of Q (lane = column
 // as before).  A lone wave issues one VALU instruction per ~4.7 cycles, so a launch with fewer solves than SIMDs (batch 1, 768-column
 // problems, any batch <= 8 at 4096 columns) waits 91 us per sweep with 3/4 of the chip idle; split four ways a phase is ~180 instead of
@@ -506,6 +398,131 @@ __device__ __forceinline__ void coop_sweep(float (&g)[64], float (&q)[64], float
         diag = dg;
     }
 }
+
+// --------------------------------------------------------------------------------------------------
+// Single-level solves: the body of evd_kernel<0, KEEPG>, one WAVE per pair, four pairs per 256-thread workgroup.
+// LDS: one 32 x 33 transposer per wave (the JI block of the image is the mirror of the stored IJ block).
+constexpr int EVDW_TR_FLOATS = 32 * 33;
+
+// NW = 1: four independent pairs per workgroup.  NW = 4 (latency form, launches with few pairs): ONE pair per workgroup, wave 0 is the
+// main wave, waves 1..3 only help in the sweep (coop_sweep); every exit below is uniform over the workgroup.
+template <int KEEPG, int NW>
+__global__ __launch_bounds__(256, 2) void evdw0_kernel(Sched sc, const float* __restrict__ Gpart, int nsplit, float* __restrict__ Qbuf,
+                                                       int* __restrict__ active, unsigned* __restrict__ maxoff_bits, int* __restrict__ nrot,
+                                                       const int* __restrict__ done, float tol, int inner_sweeps, int nb, int step, int kb,
+                                                       const int* __restrict__ plist, int list_stride, int npairs, EvdV3 v3) {
+    __shared__ float trbuf[NW == 1 ? 4 : 1][EVDW_TR_FLOATS];
+    __shared__ __attribute__((aligned(16))) float csbuf[NW == 1 ? 4 : 1][EVDW_CS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float coopbuf[NW == 1 ? 4 : Coop<NW == 1 ? 4 : NW>::FLOATS];
+    const int lane = threadIdx.x & 63, wv_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wv = NW == 1 ? wv_ : 0, hw = NW == 1 ? 0 : wv_;
+    const int pair = NW == 1 ? blockIdx.x * 4 + wv_ : blockIdx.x, b = blockIdx.y;
+    ASVD_KERNEL_ACQUIRE(sc);
+    if (pair >= npairs || ld_flag(done + b)) return;   // NW = 1: no workgroup barrier below, the waves are independent
+    const int64_t slot = (int64_t)b * npairs + pair;
+    int* act_flag = active + slot;
+    int I, J;
+    if (!get_pair(sc, plist, list_stride, b, nb, step, pair, I, J)) {  // padding pair / empty slot: nothing to rotate
+        if (lane == 0 && hw == 0) *act_flag = 0;
+        return;
+    }
+    float g[64], q[64];
+    if constexpr (NW > 1) {
+        if (hw > 0) {
+            float dd = 0.0f;
+            coop_sweep<NW>(g, q, dd, 0.0f, false, lane, hw, coopbuf);
+            return;
+        }
+    }
+    {
+        // image rows 0..31: [II | IJ] read as two 128-byte row segments per register; rows 32..63: the JJ block for the upper lanes,
+        // the lower lanes get IJ^T through the transposer.  Partials are summed in ascending order (as evd_body does).
+        const float* __restrict__ gp = Gpart + slot * nsplit * 3072;
+        const int hi = lane >> 5, cc = lane & 31;
+#pragma unroll
+        for (int r = 0; r < 64; ++r) g[r] = 0.0f;
+#pragma unroll 2
+        for (int s2 = 0; s2 < nsplit; ++s2) {
+            const float* __restrict__ p = gp + (int64_t)s2 * 3072;
+#pragma unroll
+            for (int r = 0; r < 32; ++r) g[r] += p[hi * 1024 + r * 32 + cc];
+#pragma unroll
+            for (int r = 0; r < 32; ++r) g[32 + r] += p[2048 + r * 32 + cc];
+        }
+        float* tr = trbuf[wv];
+        if (hi) {
+#pragma unroll
+            for (int r = 0; r < 32; ++r) tr[cc * 33 + r] = g[r];      // IJ[r][cc]  ->  tr[cc][r]
+        }
+        // a wave's LDS operations complete in order: no barrier needed for a wave-private buffer
+        if (!hi) {
+#pragma unroll
+            for (int r = 0; r < 32; ++r) g[32 + r] = tr[r * 33 + cc];  // G[32 + r][cc] = IJ[cc][r]
+        }
+    }
+    float diag, bpiv;
+    evdw_init_state(g, lane, diag, bpiv);
+    float off0, offt;
+    evdw_measure(g, diag, lane, I < kb, J < kb, off0, offt);
+    const bool is_nan = off0 != off0;
+    const bool rotate = !(is_nan || off0 < tol);
+    if (lane == 0) {
+        atomicMax(&maxoff_bits[b], is_nan ? 0x7fc00000u : __float_as_uint(offt));
+        *act_flag = rotate ? 1 : 0;
+        if (rotate && offt >= tol) atomicAdd(&nrot[b], 1);
+    }
+    float* d0 = KEEPG ? v3.Gd32 + ((int64_t)b * v3.nbpan + I) * 1024 : nullptr;
+    float* d1 = KEEPG ? v3.Gd32 + ((int64_t)b * v3.nbpan + J) * 1024 : nullptr;
+    if constexpr (NW > 1) {   // the helpers are waiting in coop_sweep whether this pair rotates or not
+        evdw_identity(q, lane);
+        coop_sweep<NW>(g, q, diag, bpiv, rotate, lane, 0, coopbuf);
+    }
+    if (!rotate) {
+        if (KEEPG && v3.Gd32) {  // carried diagonal blocks of the two panels = the blocks of the matrix itself
+            const int hi = lane >> 5, cc = lane & 31;
+#pragma unroll
+            for (int r = 0; r < 32; ++r) {
+                if (!hi) d0[r * 32 + cc] = g[r];
+                else d1[r * 32 + cc] = g[32 + r];
+            }
+        }
+        ASVD_KERNEL_RELEASE(sc);
+        return;
+    }
+    if constexpr (NW == 1) {
+        evdw_identity(q, lane);
+        const int nsw = (off0 > 0.05f) ? inner_sweeps : min(1, inner_sweeps);
+        evdw_sweep(g, q, diag, bpiv, lane, nsw * sc.evd_pairs, csbuf[wv]);
+    }
+    float cs;
+    int rnk;
+    evdw_finish(q, diag, lane, true, cs, rnk);
+    float* __restrict__ qo = Qbuf + slot * (PW * PW);
+#pragma unroll
+    for (int r = 0; r < 64; ++r) qo[r * PW + rnk] = q[r] * cs;
+    if (KEEPG && v3.Gd32) evdw_store_diag_blocks(g, diag, cs, rnk, lane, d0, d1);
+    ASVD_KERNEL_RELEASE(sc);
+}
+
+// --------------------------------------------------------------------------------------------------
+// Both inner steps of a super-pair (S, T) in ONE launch: the work of evd_kernel<1,1> + evd_kernel<2,1>.  Two waves per super-pair; the four
+// 32-blocks are S0, S1, T0, T1 = 0..3.
+//   step 0: wave sp solves sub-pair (sp, 2 + sp): carried diagonal blocks of its two panels + the summed cross tile [0,2] / [1,3];
+//           its sorted, rescaled eigenvectors Q0_sp (two 64 x 32 halves) and the two transformed diagonal blocks go to LDS;
+//   step 1: wave sp solves sub-pair (sp, 3 - sp): diagonal blocks from step 0, cross block  Q0_sp[:, :32]^T MM Q0_(1-sp)[:, 32:]  with
+//           MM = M (sp = 0) or M^T (sp = 1), M = G[{0,2},{1,3}] assembled from the other four tiles — two small fp32-MFMA products;
+//           epilogue: the new carried blocks of its two panels (global) and its 128 x 64 column block of Qfin = Q^(0) Q^(1).
+// The step-0 eigenvectors travel between the two waves through GLOBAL memory (v3.Q0, 16 KB per solve, L2 resident; agent-scope loads): with
+// them in LDS the workgroup needed 50 KB = three workgroups per CU, and a launch of 1024 super-pairs ran as 768 + 256 workgroups with half
+// of the SIMDs idle in the second round (measured 570 us per launch; two workgroups per CU: 700 us).  LDS now (33,536 B: four workgroups
+// per CU, every SIMD holds two waves, ONE round):  one 64 x 65 region that is, in turn, the transposer of the step-0 images, the step-0
+// diagonal blocks, the padded M and the staging of the cross blocks, and two wave-private [64][33] slices where the epilogue stages the
+// Q0 half it multiplies.  Row strides 33 / 65 make every MFMA operand read (lanes along a row OR along a column) conflict free.
+constexpr int QH_LD = 33, QH_FLOATS = 64 * QH_LD;   // one half of a Q0: 64 rows x 32 sorted columns
+constexpr int M_LD = 65;
+constexpr int E12_SLICE = 64 * M_LD;                // float offset of the two epilogue slices
+constexpr int E12_CS = E12_SLICE + 2 * QH_FLOATS;   // float offset of the two row-coefficient buffers
+constexpr int E12_SMEM_FLOATS = E12_CS + 2 * 128;
 
 // agent-scope load of data another wave of the workgroup (or this wave) wrote to global memory earlier in the launch: L2, never this CU's L1
 __device__ __forceinline__ float ldg_sc1(const float* p) { return __int_as_float(__hip_atomic_load((const int*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
@@ -825,16 +842,33 @@ __global__ __launch_bounds__(64, 2) void evdw_test_kernel(const float* __restric
 
 namespace asvdk {
 
+static int evdq_env() {
+    static const int v = getenv("ASVD_EVDQ") ? atoi(getenv("ASVD_EVDQ")) : -1;   // 0 / 1 force the wave-local / cooperative launches
+    return v;
+}
+
 void launch_evdw0(bool keepg, int npairs, int batch, hipStream_t st, const Sched& sc, const float* Gpart, int nsplit, float* Qbuf, int* active,
                   unsigned* maxoff_bits, int* nrot, const int* done, float tol, int inner_sweeps, int nb, int step, int kb, const int* plist,
                   int list_stride, const EvdV3& v3) {
+    // latency form (one pair per workgroup, four waves per solve; bit-identical) when the pairs of the launch would leave most SIMDs idle
+    const bool coop = inner_sweeps == 1 && sc.evd_pairs == 32 && (evdq_env() == 1 || (evdq_env() != 0 && (long long)npairs * batch <= 512));
+    if (coop) {
+        const dim3 grid((unsigned)npairs, (unsigned)batch);
+        if (keepg)
+            evdw0_kernel<1, 4><<<grid, 256, 0, st>>>(sc, Gpart, nsplit, Qbuf, active, maxoff_bits, nrot, done, tol, inner_sweeps, nb, step, kb, plist,
+                                                     list_stride, npairs, v3);
+        else
+            evdw0_kernel<0, 4><<<grid, 256, 0, st>>>(sc, Gpart, nsplit, Qbuf, active, maxoff_bits, nrot, done, tol, inner_sweeps, nb, step, kb, plist,
+                                                     list_stride, npairs, v3);
+        return;
+    }
     const dim3 grid((unsigned)((npairs + 3) / 4), (unsigned)batch);
     if (keepg)
-        evdw0_kernel<1><<<grid, 256, 0, st>>>(sc, Gpart, nsplit, Qbuf, active, maxoff_bits, nrot, done, tol, inner_sweeps, nb, step, kb, plist, list_stride,
-                                              npairs, v3);
+        evdw0_kernel<1, 1><<<grid, 256, 0, st>>>(sc, Gpart, nsplit, Qbuf, active, maxoff_bits, nrot, done, tol, inner_sweeps, nb, step, kb, plist, list_stride,
+                                                 npairs, v3);
     else
-        evdw0_kernel<0><<<grid, 256, 0, st>>>(sc, Gpart, nsplit, Qbuf, active, maxoff_bits, nrot, done, tol, inner_sweeps, nb, step, kb, plist, list_stride,
-                                              npairs, v3);
+        evdw0_kernel<0, 1><<<grid, 256, 0, st>>>(sc, Gpart, nsplit, Qbuf, active, maxoff_bits, nrot, done, tol, inner_sweeps, nb, step, kb, plist, list_stride,
+                                                 npairs, v3);
 }
 
 int evdw12_lds_bytes() { return (int)(E12_SMEM_FLOATS * sizeof(float)); }
@@ -851,8 +885,7 @@ void launch_evdw12(int npairs_s, int batch, hipStream_t st, const Sched& sc, uns
     }
     // latency form when the launch cannot even give every CU one workgroup: four waves per solve (bit-identical results).  It needs one
     // full inner sweep per visit (the default) and the standard 32 phase pairs.  ASVD_EVDQ=0 / 1 forces the choice.
-    static const int evdq_env = getenv("ASVD_EVDQ") ? atoi(getenv("ASVD_EVDQ")) : -1;
-    const bool coop = inner_sweeps == 1 && sc.evd_pairs == 32 && (evdq_env == 1 || (evdq_env != 0 && (long long)npairs_s * batch <= 256));
+    const bool coop = inner_sweeps == 1 && sc.evd_pairs == 32 && (evdq_env() == 1 || (evdq_env() != 0 && (long long)npairs_s * batch <= 256));
     if (coop) {
         evdw12_kernel<EVDQ_NW><<<dim3((unsigned)npairs_s, (unsigned)batch), 128 * EVDQ_NW, evdq12_lds_bytes(), st>>>(sc, maxoff_bits, nrot, done, tol, inner_sweeps, nb,
                                                                                                               step, kb, v3, nullptr);

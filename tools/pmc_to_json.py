@@ -13,7 +13,7 @@ def table(path):
             out[(p[0], p[1])] = {"calls": int(p[-3]), "avg": float(p[-2]), "avg_dur_us": float(p[-1])}
     return out
 fetch, write = table(os.path.join(d, "pmc_FETCH_SIZE.txt")), table(os.path.join(d, "pmc_WRITE_SIZE.txt"))
-names = {"supgram": "supgram_kernel", "supdate": "supdate_split_kernel", "sgram": "sgram6_kernel", "evd": "evd_kernel", "snapshot": "fullcheck_kernel"}
+names = {"supgram": "supgram_kernel", "supdate": "supdate_split_kernel", "sgram": "sgram6_kernel", "evd": "evdw12_kernel", "snapshot": "fullcheck_kernel"}
 import hashlib
 _lib_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "asvd4llm_amd", "libasvd_hip.so")
 res = {"batch": int(os.environ.get("PMC_BATCH", "16")), "lib_sha256": hashlib.sha256(open(_lib_path, "rb").read()).hexdigest() if os.path.exists(_lib_path) else None, "source": "profiles/" + os.path.basename(d).replace("prof_", "") + "_pmc_*.txt",
