@@ -63,6 +63,15 @@ __device__ __forceinline__ float col_update_b(float y, float own, float cl, floa
 // one element of the next phase's pivot vector: bn[L] = v[L].  `lane` is made opaque once per phase (an empty asm) so that the 32 lane
 // masks of a phase are not hoisted out of the sweep loop and kept in (spilled) SGPRs.
 __device__ __forceinline__ float put_lane(float bn, float v, int L, int lane) { return (lane == L) ? v : bn; }
+// The same select with the lane mask built on the SCALAR unit (one s_lshl_b64 of an opaque 1) instead of a v_cmp: one VALU instruction per
+// register instead of two (a compare + select pair costs 2.75 ns on a saturated SIMD, tools/ubench/valu_cost.hip), and nothing for the
+// compiler to hoist out of the sweep loop as 32 live masks — `one` is redefined (empty asm) once per phase.
+__device__ __forceinline__ float put_lane_s(float bn, float v, int L, unsigned long long one) {
+    const unsigned long long m = one << L;
+    float r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(bn), "v"(v), "s"(m));
+    return r;
+}
 
 // One phase.  bpiv: on entry the pivot b = G[lane + 1][lane] in the LOWER lane of every pair of this phase; on exit the same for the
 // next phase (the other parity).  diag: G[lane][lane], closed form.
@@ -74,8 +83,8 @@ template <int PAR>
 __device__ __forceinline__ void evdw_phase(float (&g)[64], float (&q)[64], float& diag, float& bpiv, const int lane, float* __restrict__ cslds) {
     const bool odd = (lane & 1) != 0;
     float bn = 0.0f;
-    int lane_o = lane;
-    asm volatile("" : "+v"(lane_o));
+    unsigned long long one = 1ull;
+    asm volatile("" : "+s"(one));
     if constexpr (PAR == 0) {
         const bool lower = !odd;
         const float dpart = dppf<DPP_XOR1>(diag), bo = dppf<DPP_XOR1>(bpiv);
@@ -97,7 +106,7 @@ __device__ __forceinline__ void evdw_phase(float (&g)[64], float (&q)[64], float
             const float z1 = fmaf(own, y1, c * dppf<DPP_XOR1>(y1));
             g[2 * k] = z0;
             g[2 * k + 1] = z1;
-            if (k >= 1) bn = put_lane(bn, z0, 2 * k - 1, lane_o);    // phase B: lower lanes are odd L, their pivot is register L + 1
+            if (k >= 1) bn = put_lane_s(bn, z0, 2 * k - 1, one);    // phase B: lower lanes are odd L, their pivot is register L + 1
         }
 #pragma unroll
         for (int r = 0; r < 64; ++r) q[r] = fmaf(own, q[r], c * dppf<DPP_XOR1>(q[r]));
@@ -129,12 +138,12 @@ __device__ __forceinline__ void evdw_phase(float (&g)[64], float (&q)[64], float
             const float z1 = col_update_b(y1, own, cl, cr);
             g[2 * k + 1] = z0;
             g[2 * k + 2] = z1;
-            bn = put_lane(bn, z0, 2 * k, lane_o);                    // phase A: lower lanes are even L, their pivot is register L + 1
+            bn = put_lane_s(bn, z0, 2 * k, one);                    // phase A: lower lanes are even L, their pivot is register L + 1
         }
         {   // row 63 is idle
             const float z = col_update_b(g[63], own, cl, cr);
             g[63] = z;
-            bn = put_lane(bn, z, 62, lane_o);
+            bn = put_lane_s(bn, z, 62, one);
         }
 #pragma unroll
         for (int r = 0; r < 64; ++r) q[r] = col_update_b(q[r], own, cl, cr);
@@ -269,6 +278,8 @@ __device__ __forceinline__ void coop_phase_a(float (&gl)[64 / NW], float (&ql)[6
     const float own = lower ? s : -s;
     *(float2*)(cslds + 2 * lane) = make_float2(c, s);
     float bn = 0.0f;
+    unsigned long long one = 1ull;
+    asm volatile("" : "+s"(one));
 #pragma unroll
     for (int kp = 0; kp < RB / 2; ++kp) {
         const float2 cs2 = *(const float2*)(cslds + 2 * (r0 + 2 * kp));
@@ -280,7 +291,7 @@ __device__ __forceinline__ void coop_phase_a(float (&gl)[64 / NW], float (&ql)[6
         const float z1 = fmaf(own, y1, c * dppf<DPP_XOR1>(y1));
         gl[2 * kp] = z0;
         gl[2 * kp + 1] = z1;
-        bn = (lane == r0 + 2 * kp - 1) ? z0 : bn;   // phase B: lower lanes are odd L, their pivot is row L + 1
+        if (kp > 0 || h > 0) bn = put_lane_s(bn, z0, r0 + 2 * kp - 1, one);   // phase B: lower lanes are odd L, their pivot is row L + 1 (row 0 has none)
     }
     if (odd && lane + 1 >= r0 && lane + 1 < r0 + RB) L[Coop<NW>::PIV + lane] = bn;           // pivots of phase B (parity buffer 0)
     L[Coop<NW>::BROW + (2 * h) * 64 + lane] = gl[0];                                           // boundary rows as phase B will find them
@@ -310,6 +321,8 @@ __device__ __forceinline__ void coop_phase_b(float (&gl)[64 / NW], float (&ql)[6
     s = idle ? 0.0f : s;
     *(float2*)(cslds + 2 * lane) = make_float2(c, s);
     float bn = 0.0f;
+    unsigned long long one = 1ull;
+    asm volatile("" : "+s"(one));
     if (h == 0) {   // row 0 is idle: columns only
         gl[0] = col_update_b(gl[0], own, cl, cr);
     } else {        // upper member of the pair (r0 - 1, r0): the lower member is the previous wave's last row
@@ -329,18 +342,18 @@ __device__ __forceinline__ void coop_phase_b(float (&gl)[64 / NW], float (&ql)[6
         const float z1 = col_update_b(y1, own, cl, cr);
         gl[pl] = z0;
         gl[pl + 1] = z1;
-        bn = (lane == r0 + pl - 1) ? z0 : bn;       // phase A: lower lanes are even L, their pivot is row L + 1
+        bn = put_lane_s(bn, z0, r0 + pl - 1, one);  // phase A: lower lanes are even L, their pivot is row L + 1
     }
     if (h == NW - 1) {   // row 63 is idle
         const float z = col_update_b(gl[RB - 1], own, cl, cr);
         gl[RB - 1] = z;
-        bn = (lane == 62) ? z : bn;
+        bn = put_lane_s(bn, z, 62, one);
     } else {             // lower member of the pair (r0 + RB - 1, r0 + RB): the upper member is the next wave's first row
         const float2 cs2 = *(const float2*)(cslds + 2 * (r0 + RB - 1));
         const float xq = L[Coop<NW>::BROW + (2 * (h + 1)) * 64 + lane];
         const float z0 = col_update_b(fmaf(cs2.x, xq, cs2.y * gl[RB - 1]), own, cl, cr);
         gl[RB - 1] = z0;
-        bn = (lane == r0 + RB - 2) ? z0 : bn;
+        bn = put_lane_s(bn, z0, r0 + RB - 2, one);
     }
     if (!odd && lane + 1 >= r0 && lane + 1 < r0 + RB) L[Coop<NW>::PIV + 64 + lane] = bn;      // pivots of phase A (parity buffer 1)
 #pragma unroll

@@ -1,5 +1,6 @@
 #!/bin/bash
-# Reproduces the round's evidence on one MI355X (about 45 minutes).  Outputs under gpurun_out/; copy what should be kept to profiles/.
+# Reproduces the round's evidence on one MI355X (about 45 minutes).  Round 3 used tools/r3_final.sh (same steps, PMC passes first so that the
+# bench line carries roofline.traffic of the same library binary).  Outputs under gpurun_out/; copy what should be kept to profiles/.
 #   bash tools/reproduce_evidence.sh            # everything
 #   bash tools/reproduce_evidence.sh quick      # tests + smoke + bench only (about 10 minutes)
 set -u
