@@ -95,9 +95,21 @@ __device__ __forceinline__ void evdw_phase(float (&g)[64], float (&q)[64], float
         diag = fmaf(lower ? t : -t, b, lower ? d_ : a_);   // position p now holds the rotated q and vice versa (swap): d + t b | a - t b
         const float own = lower ? s : -s;                   // new = own * x + c * x_partner
         *(float2*)(cslds + 2 * lane) = make_float2(c, s);
+        // row coefficients in batches of eight broadcast reads, the next batch issued before the current one is consumed: left to the
+        // compiler every ds_read_b64 sat right in front of its row pair and the LDS latency was exposed some twenty times per phase
+        float2 csb[2][8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) csb[0][j] = *(const float2*)(cslds + 2 * (2 * j));
 #pragma unroll
         for (int k = 0; k < 32; ++k) {
-            const float2 cs2 = *(const float2*)(cslds + 2 * (2 * k));
+            if ((k & 7) == 0) {
+                if (k + 8 < 32) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) csb[((k >> 3) + 1) & 1][j] = *(const float2*)(cslds + 2 * (2 * (k + 8 + j)));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const float2 cs2 = csb[(k >> 3) & 1][k & 7];
             const float ck = cs2.x, sk = cs2.y;
             const float x0 = g[2 * k], x1 = g[2 * k + 1];
             const float y0 = fmaf(ck, x1, sk * x0);         // rows: new[p] = s row[p] + c row[q] ; new[q] = c row[p] - s row[q]
@@ -127,9 +139,20 @@ __device__ __forceinline__ void evdw_phase(float (&g)[64], float (&q)[64], float
         s = idle ? 0.0f : s;
         *(float2*)(cslds + 2 * lane) = make_float2(c, s);
         g[0] = col_update_b(g[0], own, cl, cr);    // row 0 is idle: columns only
+        float2 csb[2][8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) csb[0][j] = *(const float2*)(cslds + 2 * (2 * j + 1));
 #pragma unroll
         for (int k = 0; k < 31; ++k) {
-            const float2 cs2 = *(const float2*)(cslds + 2 * (2 * k + 1));
+            if ((k & 7) == 0) {
+                if (k + 8 < 31) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (k + 8 + j < 31) csb[((k >> 3) + 1) & 1][j] = *(const float2*)(cslds + 2 * (2 * (k + 8 + j) + 1));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const float2 cs2 = csb[(k >> 3) & 1][k & 7];
             const float ck = cs2.x, sk = cs2.y;
             const float x0 = g[2 * k + 1], x1 = g[2 * k + 2];
             const float y0 = fmaf(ck, x1, sk * x0);
@@ -280,9 +303,13 @@ __device__ __forceinline__ void coop_phase_a(float (&gl)[64 / NW], float (&ql)[6
     float bn = 0.0f;
     unsigned long long one = 1ull;
     asm volatile("" : "+s"(one));
+    float2 csb[RB / 2];   // all row coefficients of this wave in one batch of broadcast reads (see evdw_phase)
+#pragma unroll
+    for (int kp = 0; kp < RB / 2; ++kp) csb[kp] = *(const float2*)(cslds + 2 * (r0 + 2 * kp));
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int kp = 0; kp < RB / 2; ++kp) {
-        const float2 cs2 = *(const float2*)(cslds + 2 * (r0 + 2 * kp));
+        const float2 cs2 = csb[kp];
         const float ck = cs2.x, sk = cs2.y;
         const float x0 = gl[2 * kp], x1 = gl[2 * kp + 1];
         const float y0 = fmaf(ck, x1, sk * x0);
@@ -323,17 +350,26 @@ __device__ __forceinline__ void coop_phase_b(float (&gl)[64 / NW], float (&ql)[6
     float bn = 0.0f;
     unsigned long long one = 1ull;
     asm volatile("" : "+s"(one));
+    // every LDS value of the phase in one batch: coefficients of the pair below the block, of the interior pairs and of the pair above, and
+    // the two neighbour rows (the idle ends read a valid address and ignore the value)
+    float2 csb[RB / 2 + 1];
+    csb[0] = *(const float2*)(cslds + 2 * (h == 0 ? 0 : r0 - 1));
+#pragma unroll
+    for (int j = 0; j < RB / 2 - 1; ++j) csb[1 + j] = *(const float2*)(cslds + 2 * (r0 + 2 * j + 1));
+    csb[RB / 2] = *(const float2*)(cslds + 2 * (r0 + RB - 1));
+    const float xp_n = L[Coop<NW>::BROW + (2 * (h == 0 ? 0 : h - 1) + 1) * 64 + lane];
+    const float xq_n = L[Coop<NW>::BROW + (2 * (h == NW - 1 ? h : h + 1)) * 64 + lane];
+    __builtin_amdgcn_sched_barrier(0);
     if (h == 0) {   // row 0 is idle: columns only
         gl[0] = col_update_b(gl[0], own, cl, cr);
     } else {        // upper member of the pair (r0 - 1, r0): the lower member is the previous wave's last row
-        const float2 cs2 = *(const float2*)(cslds + 2 * (r0 - 1));
-        const float xp = L[Coop<NW>::BROW + (2 * (h - 1) + 1) * 64 + lane];
-        gl[0] = col_update_b(fmaf(-cs2.y, gl[0], cs2.x * xp), own, cl, cr);
+        const float2 cs2 = csb[0];
+        gl[0] = col_update_b(fmaf(-cs2.y, gl[0], cs2.x * xp_n), own, cl, cr);
     }
 #pragma unroll
     for (int j = 0; j < RB / 2 - 1; ++j) {
         const int pl = 2 * j + 1;
-        const float2 cs2 = *(const float2*)(cslds + 2 * (r0 + pl));
+        const float2 cs2 = csb[1 + j];
         const float ck = cs2.x, sk = cs2.y;
         const float x0 = gl[pl], x1 = gl[pl + 1];
         const float y0 = fmaf(ck, x1, sk * x0);
@@ -349,9 +385,8 @@ __device__ __forceinline__ void coop_phase_b(float (&gl)[64 / NW], float (&ql)[6
         gl[RB - 1] = z;
         bn = put_lane_s(bn, z, 62, one);
     } else {             // lower member of the pair (r0 + RB - 1, r0 + RB): the upper member is the next wave's first row
-        const float2 cs2 = *(const float2*)(cslds + 2 * (r0 + RB - 1));
-        const float xq = L[Coop<NW>::BROW + (2 * (h + 1)) * 64 + lane];
-        const float z0 = col_update_b(fmaf(cs2.x, xq, cs2.y * gl[RB - 1]), own, cl, cr);
+        const float2 cs2 = csb[RB / 2];
+        const float z0 = col_update_b(fmaf(cs2.x, xq_n, cs2.y * gl[RB - 1]), own, cl, cr);
         gl[RB - 1] = z0;
         bn = put_lane_s(bn, z0, r0 + RB - 2, one);
     }

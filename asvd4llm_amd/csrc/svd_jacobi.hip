@@ -895,21 +895,33 @@ __global__ __launch_bounds__(256) void fullcheck_kernel(Sched sc, const float* _
             }
             __syncthreads();
             if (r0 + 32 < m_pad) fetch(r0 + 32);
+            // eight stages (k-step, A panel) of six MFMAs; the operands of stage i + 1 are read from LDS before the MFMAs of stage i are
+            // issued (left to the compiler each ds_read sat in front of its consumer: 51 % of the wave cycles waiting to issue)
+            struct Op3 { bf16x8 p1, p2, p3; };
+            auto ld3 = [&](int slot, int ks) {
+                const u32x4* o = oimg + ((slot * 2 + ks) * 3) * 64 + lane;
+                Op3 r;
+                r.p1 = __builtin_bit_cast(bf16x8, o[0]); r.p2 = __builtin_bit_cast(bf16x8, o[64]); r.p3 = __builtin_bit_cast(bf16x8, o[128]);
+                return r;
+            };
+            Op3 Bc = ld3(4 + w, 0), Ac = ld3(0, 0);
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const u32x4* ob = oimg + (((4 + w) * 2 + ks) * 3) * 64 + lane;
-                const bf16x8 B1 = __builtin_bit_cast(bf16x8, ob[0]), B2 = __builtin_bit_cast(bf16x8, ob[64]), B3 = __builtin_bit_cast(bf16x8, ob[128]);
-#pragma unroll
-                for (int a = 0; a < 4; ++a) {
-                    const u32x4* oa = oimg + ((a * 2 + ks) * 3) * 64 + lane;
-                    const bf16x8 A1 = __builtin_bit_cast(bf16x8, oa[0]), A2 = __builtin_bit_cast(bf16x8, oa[64]), A3 = __builtin_bit_cast(bf16x8, oa[128]);
-                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A3, B1, acc[a], 0, 0, 0);
-                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B3, acc[a], 0, 0, 0);
-                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, B2, acc[a], 0, 0, 0);
-                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, B1, acc[a], 0, 0, 0);
-                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B2, acc[a], 0, 0, 0);
-                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B1, acc[a], 0, 0, 0);
-                }
+            for (int st = 0; st < 8; ++st) {
+                const int ks = st >> 2, a = st & 3;
+                Op3 An = Ac, Bn = Bc;
+                if (st + 1 < 8) An = ld3((st + 1) & 3, (st + 1) >> 2);
+                if (st == 3) Bn = ld3(4 + w, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ac.p3, Bc.p1, acc[a], 0, 0, 0);
+                acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ac.p1, Bc.p3, acc[a], 0, 0, 0);
+                acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ac.p2, Bc.p2, acc[a], 0, 0, 0);
+                acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ac.p2, Bc.p1, acc[a], 0, 0, 0);
+                acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ac.p1, Bc.p2, acc[a], 0, 0, 0);
+                acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ac.p1, Bc.p1, acc[a], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                Ac = An;
+                if (st == 3) Bc = Bn;
+                (void)ks;
             }
         }
     } else {

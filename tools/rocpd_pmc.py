@@ -15,5 +15,5 @@ try:
 except Exception as ex:
     print("query failed:", ex, "\npmc_event cols", pc, "\ninfo_pmc cols", ic); sys.exit(1)
 print(f"{'kernel':60s} {'counter':12s} {'calls':>7s} {'avg_value':>14s} {'avg_dur_us':>10s}")
-for n, c, cnt, avg, tot, dur in rows[:12]:
+for n, c, cnt, avg, tot, dur in rows[:int(sys.argv[2]) if len(sys.argv) > 2 else 12]:
     print(f"{n.split('(')[0][-60:]:60s} {c:12s} {cnt:7d} {avg:14.1f} {dur/1e3:10.1f}")
