@@ -2,12 +2,12 @@
 # Round-3 evidence refresh after the last library change (everything of tools/r3_final.sh except the two end-to-end pipeline runs, whose
 # time is PyTorch forwards): tests, smoke, PMC + kernel-trace passes, bench (traffic of the same binary), shapes, full models, latency form.
 set -u
-O=gpurun_out/final3; mkdir -p $O
+O=gpurun_out/final4; mkdir -p $O
 export ASVD_STRICT=1
 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed" | tail -1
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
-PMC_BATCH=32 bash tools/prof_final.sh r3c > $O/prof.log 2>&1
-cp gpurun_out/prof_r3c/pmc_traffic.json profiles/pmc_traffic.json
+PMC_BATCH=32 bash tools/prof_final.sh r3d > $O/prof.log 2>&1
+cp gpurun_out/prof_r3d/pmc_traffic.json profiles/pmc_traffic.json
 python bench.py > $O/bench.json 2> $O/bench.err; tail -c 400 $O/bench.json
 bash tools/r2_job14.sh 2>&1 | tee $O/shapes.txt
 python tools/full_model_bench.py --model llama-2-7b 2>/dev/null | tail -1 > $O/full_7b.json
