@@ -54,10 +54,16 @@ def _allreduce_statistics(model, method):
     batch by batch in that dtype: equal up to that rounding, which is why this is opt-in)."""
     import torch.distributed as dist
     from . import parallel
-    mods = [m for _, m in model.named_modules() if isinstance(m, nn.Linear) and torch.is_tensor(m.scaling_diag_matrix)]
+    # the buffer layout comes from the model's STRUCTURE, identical on every rank: a rank that ran no sample (fewer samples than ranks) or
+    # whose forward never reached a Linear still holds the python int 0 there and contributes zeros (the neutral element of both the sum
+    # and the max of absolute values)
+    mods = [m for _, m in model.named_modules() if isinstance(m, nn.Linear)]
     if not mods:
         return
     dev = parallel._comm_device()
+    for m in mods:
+        if not torch.is_tensor(m.scaling_diag_matrix):
+            m.scaling_diag_matrix = torch.zeros(m.in_features, dtype=m.weight.dtype, device=m.weight.device)
     flat = torch.cat([m.scaling_diag_matrix.float().reshape(-1) for m in mods]).to(dev)
     dist.all_reduce(flat, op=dist.ReduceOp.MAX if "abs_max" in method else dist.ReduceOp.SUM)
     off = 0
@@ -74,7 +80,8 @@ def calib_input_distribution(model, calib_loader, method, use_cache=True, shard_
     statistics on every rank, no collective)."""
     model_id = model.config._name_or_path
     cache_file = f"cache/{model_id.replace('/','_')}_calib_input_distribution_{method}.pt"
-    if os.path.exists(cache_file) and use_cache:
+    from . import parallel
+    if use_cache and parallel.cache_exists(cache_file):
         all_scaling_diag_matrix = torch.load(cache_file, map_location="cpu")
         for name, module in model.named_modules():
             if isinstance(module, nn.Linear):
@@ -89,7 +96,6 @@ def calib_input_distribution(model, calib_loader, method, use_cache=True, shard_
             module.scaling_diag_matrix = 0
             module.register_forward_hook(hook)
 
-    from . import parallel
     rank, ws = parallel.world()
     shard = bool(shard_samples) and ws > 1
     for i, batch in enumerate(tqdm(calib_loader, disable=(rank != 0))):
@@ -106,8 +112,7 @@ def calib_input_distribution(model, calib_loader, method, use_cache=True, shard_
         if isinstance(module, nn.Linear):
             module._forward_hooks.clear()  # the reference clears ALL forward hooks of every Linear (act_aware_utils.py:93)
             all_scaling_diag_matrix[name] = module.scaling_diag_matrix
-    os.makedirs(os.path.dirname(cache_file), exist_ok=True)
-    torch.save(all_scaling_diag_matrix, cache_file)
+    parallel.save_cache(all_scaling_diag_matrix, cache_file)  # rank 0 writes (temporary name + rename), every rank waits for it
 
 
 def calib_fisher_info(model, calib_loader, use_cache=True):
@@ -116,7 +121,8 @@ def calib_fisher_info(model, calib_loader, use_cache=True):
     the per-input-channel statistic of the gradient is the sq_mean mode of the hook kernel (asvd_absstat_accum)."""
     model_id = model.config._name_or_path
     cache_file = f"cache/{model_id.replace('/','_')}_calib_fisher_info.pt"
-    if os.path.exists(cache_file) and use_cache:
+    from . import parallel
+    if use_cache and parallel.cache_exists(cache_file):
         all_fisher_info = torch.load(cache_file, map_location="cpu")
         for name, module in model.named_modules():
             if isinstance(module, nn.Linear):
@@ -146,5 +152,4 @@ def calib_fisher_info(model, calib_loader, use_cache=True):
         if isinstance(module, nn.Linear):
             module._forward_hooks.clear()
             all_fisher_info[name] = module.fisher_info
-    os.makedirs(os.path.dirname(cache_file), exist_ok=True)
-    torch.save(all_fisher_info, cache_file)
+    parallel.save_cache(all_fisher_info, cache_file)

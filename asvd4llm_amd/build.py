@@ -20,13 +20,16 @@ def _newest_source_mtime():
 EXTRA_FLAGS = {"evd_wave.hip": ["-fno-slp-vectorize"]}
 
 
-def build(force=False, verbose=True):
-    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _newest_source_mtime():
-        return LIB
+def build(force=False, verbose=True, extra_flags=None, out=None):
+    """extra_flags / out: MEASUREMENT builds only (tools/bench_supgram.py: -DASVD_SG_TIMING into libasvd_hip_meas.so) — the product library is
+    always built without extra flags into libasvd_hip.so."""
+    lib_path = out or LIB
+    if not force and os.path.exists(lib_path) and os.path.getmtime(lib_path) >= _newest_source_mtime():
+        return lib_path
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build" if not out else "build_" + os.path.splitext(os.path.basename(out))[0])
     os.makedirs(objdir, exist_ok=True)
-    common = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+    common = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + list(extra_flags or [])
     procs, objs = [], []
     for src in SOURCES:  # one hipcc per translation unit, all at once
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
@@ -38,11 +41,11 @@ def build(force=False, verbose=True):
     failed = [src for src, p in procs if p.wait() != 0]
     if failed:
         raise subprocess.CalledProcessError(1, f"hipcc -c {failed}")
-    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path] + objs + ["-ldl"]
     if verbose:
         print(" ".join(link), flush=True)
     subprocess.check_call(link)
-    return LIB
+    return lib_path
 
 
 if __name__ == "__main__":

@@ -3258,6 +3258,14 @@ int asvd_test_supgram(float* X, int64_t panel_stride, int64_t batch_stride, int 
     return ASVD_OK;
 }
 
+#ifdef ASVD_SG_TIMING
+int asvd_test_sg_timing(unsigned long long* out_host) {  // [2][64][10] s_memtime stamps of the last supgram launch (timing builds only)
+    ASVD_HIP_CHECK(hipDeviceSynchronize());
+    ASVD_HIP_CHECK(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_sg_ts), 2 * 64 * 10 * sizeof(unsigned long long)));
+    return ASVD_OK;
+}
+#endif
+
 // Test hook (tests/test_gpu_evd_wave.py): the wave-local 64x64 eigen-solver alone.  G: [batch][64][64] symmetric (device); outputs
 // Q [batch][64][64] (unsorted, unscaled), diag / rnk / cs [batch][64], Gout [batch][64][64] (the image the sweeps leave), meas [batch][2].
 int asvd_test_evd_wave(const float* G, int batch, int sweeps, float* Q, float* diag, int* rnk, float* cs, float* Gout, float* meas, void* stream) {

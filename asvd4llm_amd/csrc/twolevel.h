@@ -356,28 +356,47 @@ __global__ __launch_bounds__(256, 2) void supdate_split_kernel(Sched sc, float* 
 }
 
 // --------------------------------------------------------------------------------------------------
-// supgram: the update of super-step D fused with the Gram tiles of super-step E (the step that follows) — the two-level form of
-// upgram_kernel.  Under the XOR ordering the four super-panels {a, a^D, a^E, a^D^E} (a QUAD) are closed under both steps: the pairs
-// (a, a^D) and (a^E, a^D^E) rotate now, the pairs (a, a^E) and (a^D, a^D^E) meet next.  One workgroup of EIGHT waves streams a row
-// chunk of a quad ONCE: 32-row tiles of the eight panels go through a double-buffered LDS image; wave w owns output panel w
-// (waves 0-3: first pair, 4-7: second pair; its 128x32 slice of Qfin sits pre-split in 96 VGPRs), writes it back, and leaves it —
-// already split into three bf16 parts, in MFMA operand order — in LDS.  The C layout of the update (lane = column, registers =
-// rows) IS the A/B operand layout of the Gram product over rows (the reduction index may be permuted freely as long as both
-// operands agree), so the twelve 32x32 tiles of the two next pairs are accumulated from those images without any transpose:
-// 24 half-tiles (tile x 16-row k-step), three per wave, held in registers over the whole chunk.
-// HBM traffic of a super-step drops from read + (read + write) to one read + one write: the separate sgram6 pass (1/3 of the
-// streaming bytes, and an fp32-MFMA-bound one) disappears; MFMA work per tile: 8 x 48 (update) + 8 x 18 (Gram) bf16 instructions.
-// Super-panels beyond ns (power-of-two padding of the schedule) read as absent: no loads, no stores, their pairs are skipped.
-// The incoming tile is split ONCE, by the thread that fetched it, and stored as the A operands of the update (the four waves of a pair
-// would otherwise each split the same 32x128 values): image [pair][k-step][part][lane] of 16-byte operands, double buffered.
-// A 32-lane half block is padded to 36 operands (one (k-step, part) block = 72): the stash writes of a quarter wave — four rows x
-// four (k-step, lane group) targets — then fall on distinct banks; the reads are lane-contiguous either way.
+// supgram: the update of super-step D fused with the Gram tiles of super-step E (the step that follows).  Under the XOR ordering the
+// four super-panels {a, a^D, a^E, a^D^E} (a QUAD) are closed under both steps: the pairs (a, a^D) and (a^E, a^D^E) rotate now, the
+// pairs (a, a^E) and (a^D, a^D^E) meet next.  One workgroup of EIGHT waves streams a row chunk of a quad ONCE, in 32-row tiles; wave w
+// owns output panel w (waves 0-3: first pair, 4-7: second pair; its 128x32 slice of Qfin sits pre-split in 96 VGPRs), writes it back,
+// and leaves it — already split into three bf16 parts, in MFMA operand order — in LDS.  The C layout of the update (lane = column,
+// registers = rows) IS the A/B operand layout of the Gram product over rows (the reduction index may be permuted freely as long as both
+// operands agree), so the twelve 32x32 tiles of the two next pairs are accumulated from those images without any transpose: 24
+// half-tiles (tile x 16-row k-step), three per wave, held in registers over the whole chunk.
+// HBM traffic of a super-step: one read + one write instead of read + (read + write); MFMA work per tile and wave: 48 (update) + 18
+// (Gram) v_mfma_f32_32x32x16_bf16.  Super-panels beyond ns (power-of-two padding of the schedule) read as absent: no loads, no stores.
+//
+// PING-PONG SCHEDULE (round 4).  Rounds 2-3 ran all eight waves through the same phases between two barriers per tile — fetch / split /
+// LDS stores, then 66 matrix instructions, then panel stores — so the matrix pipe, the VALU and the memory pipe took turns: the kernel
+// ran at the SUM of its HBM time and its MFMA time (48 % MFMA-busy, 0.44 of the HBM spec).  The two waves of a SIMD are w and w + 4, i.e.
+// one wave of each pair.  Now the pairs run HALF A TILE APART: between two barriers the waves of one pair are in their COMPUTE segment
+// (Gram MFMAs of an earlier tile + the 48 update MFMAs of this one, operands from LDS) while the waves of the other pair are in their
+// MEMORY segment (panel stores of the tile just computed, split of its accumulators into Gram operands, split + LDS stores of the next
+// incoming tile, global loads of the tile after that), then they swap.  Every SIMD therefore holds one wave that feeds the matrix pipe
+// and one that feeds VALU / LDS / HBM at any time.  What makes it fit: every pair stages only ITS OWN 32 x 128 incoming tile — written
+// in its memory segment, read in its compute segment — so the incoming image needs no double buffer (54 KiB instead of 108); the Gram
+// operand image is double buffered instead (2 x 48 KiB), because the tiles of the next step need the updated panels of BOTH pairs and
+// pair B's lag half a tile behind: pair A accumulates the Gram units of tile t - 2 next to the update of tile t, pair B those of tile
+// t - 1 (timeline in segments: A computes tile t in segment 2t and publishes its operands in 2t + 1, B computes in 2t + 1 and publishes
+// in 2t + 2; the operand buffer (t & 1) is complete after segment 2t + 2, read in 2t + 3 (B) and 2t + 4 (A), and rewritten from 2t + 5).
+// Two barriers per tile as before; global loads and stores stay in flight across them (s_barrier waits for lgkmcnt only).
+//
+// The incoming tile is split ONCE, by the thread that fetched it, and stored as the A operands of the update: image [pair][k-step][part]
+// [lane] of 16-byte operands.  A 32-lane half block is padded to 36 operands (one (k-step, part) block = 72): the stash writes of a
+// quarter wave — four rows x four (k-step, lane group) targets — then fall on distinct banks; the reads are lane-contiguous either way.
 constexpr int SG_HB = 36, SG_BLK = 2 * SG_HB;
 constexpr int SUPGRAM_AIMG_WORDS = 2 * 8 * 3 * SG_BLK * 4;         // one 32-row image of the eight panels, as bf16x3 A operands (54 KiB)
-constexpr int SUPGRAM_OPND_WORDS = 8 * 2 * 3 * 64 * 4;             // updated panels as Gram operands [panel][k-step][part][lane] x 16 B
-constexpr int SUPGRAM_SMEM_FLOATS = 2 * SUPGRAM_AIMG_WORDS + SUPGRAM_OPND_WORDS;  // 159,744 B of the CU's 160 KiB
+constexpr int SUPGRAM_OPND_WORDS = 8 * 2 * 3 * 64 * 4;             // updated panels as Gram operands [panel][k-step][part][lane] x 16 B (48 KiB)
+constexpr int SUPGRAM_SMEM_FLOATS = SUPGRAM_AIMG_WORDS + 2 * SUPGRAM_OPND_WORDS;  // 153,600 B of the CU's 160 KiB
 static_assert(SUPGRAM_SMEM_FLOATS >= 24 * 1024, "the final reduction reuses the whole buffer");
 
+#ifdef ASVD_SG_TIMING   // tools/bench_supgram.py --timing: s_memtime stamps of one wave per pair of workgroup (0, 0, 0), 64 tiles x 6 stamps
+__device__ unsigned long long g_sg_ts[2][64][10];
+#define SG_TS(i) do { __builtin_amdgcn_sched_barrier(0); if (sg_ts_on && t < 64) g_sg_ts[mypr][t][i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define SG_TS(i) do { } while (0)
+#endif
 __global__ __launch_bounds__(512, 1) void supgram_kernel(Sched sc, float* __restrict__ X, int64_t panel_stride, int64_t batch_stride, int ns, int D,
                                                          int E, int R, int m_pad, int rows_per_wg, const float* __restrict__ Qfin,
                                                          const int* __restrict__ subact, float* __restrict__ Gx, const int* __restrict__ done,
@@ -456,9 +475,9 @@ __global__ __launch_bounds__(512, 1) void supgram_kernel(Sched sc, float* __rest
         }
     }
 
-    u32x4* aimg0 = (u32x4*)sg_smem;
-    u32x4* aimg1 = (u32x4*)(sg_smem + SUPGRAM_AIMG_WORDS);
-    u32x4* opnd = (u32x4*)(sg_smem + 2 * SUPGRAM_AIMG_WORDS);
+    u32x4* aimg = (u32x4*)sg_smem;
+    u32x4* opnd0 = (u32x4*)(sg_smem + SUPGRAM_AIMG_WORDS);
+    constexpr int OPND_VECS = SUPGRAM_OPND_WORDS / 4;  // 16-byte operands per buffer
 
     // ---- this wave's three Gram half-tiles: unit u = w + 8 j -> tile u >> 1 (0..5 pair C, 6..11 pair D'), k-step u & 1 ----
     // sgram6 tile order [0,2] [0,3] [1,2] [1,3] [0,1] [2,3] over the pair's panels (0,1 = lower super-panel, 2,3 = upper)
@@ -481,35 +500,36 @@ __global__ __launch_bounds__(512, 1) void supgram_kernel(Sched sc, float* __rest
 
     const int r_begin = chunk * rows_per_wg;
     const int r_end = min(r_begin + rows_per_wg, R);
-    if (r_begin < r_end) {
-        // a thread fetches two 8-column pieces (32 B) of the tile: piece q = tid + 512 jj -> panel q >> 7, row (q & 127) >> 2, columns
-        // 8 (q & 3) .. +7; as an A operand that is k-step / lane group (k >> 4, (k >> 3) & 1) of its pair, k = its column in Q order
+    const int ntiles = (r_end - r_begin) / 32;   // R and rows_per_wg are multiples of 32
+    if (ntiles > 0) {
+        // a thread fetches two 8-column pieces (32 B) of ITS PAIR's 32 x 128 tile: piece q = (tid & 255) + 256 jj -> panel q >> 7 of the pair in Q
+        // order (0, 1: lower super-panel S, 2, 3: upper super-panel T), row (q & 127) >> 2, columns 8 (q & 3) .. +7; as an A operand that is
+        // k-step / lane group (k >> 4, (k >> 3) & 1), k = 32 (q >> 7) + 8 (q & 3) its column in Q order
         f32x4 pre[2][2];
         int dst[2];
+        const float* src[2];
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
-            const int q = tid + 512 * jj, tp = q >> 7, row = (q & 127) >> 2, slot = tp >> 1;
-            const int pr = (slot >= 2) ? 1 : 0;
-            const bool isT = pr ? (slot == curT1) : (slot == 1);
-            const int k = (isT ? 64 : 0) + (tp & 1) * 32 + 8 * (q & 3);
-            dst[jj] = ((pr * 8 + (k >> 4)) * 3) * SG_BLK + ((k >> 3) & 1) * SG_HB + row;
+            const int q = (tid & 255) + 256 * jj, lp = q >> 7, row = (q & 127) >> 2;
+            const int k = 32 * lp + 8 * (q & 3);
+            dst[jj] = ((mypr * 8 + (k >> 4)) * 3) * SG_BLK + ((k >> 3) & 1) * SG_HB + row;
+            const int sp = Pof(jj ? mT : mS);   // jj = 0: pieces of S (lp = 0, 1), jj = 1: pieces of T (lp = 2, 3)
+            src[jj] = sp < ns ? Xb + (int64_t)(2 * sp + (lp & 1)) * panel_stride + (int64_t)r_begin * PB + (q & 127) * 8 : nullptr;
         }
-        auto fetch = [&](int r0) {
+        auto fetch = [&](int t) {
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
-                const int q = tid + 512 * jj, tp = q >> 7, idx = q & 127;
-                const int sp = Pof(tp >> 1);
-                if (sp < ns) {
-                    const float* src = Xb + (int64_t)(2 * sp + (tp & 1)) * panel_stride + (int64_t)r0 * PB + idx * 8;
-                    pre[jj][0] = *(const f32x4*)(src);
-                    pre[jj][1] = *(const f32x4*)(src + 4);
+                if (src[jj]) {
+                    const float* s_ = src[jj] + (int64_t)t * (32 * PB);
+                    pre[jj][0] = *(const f32x4*)(s_);
+                    pre[jj][1] = *(const f32x4*)(s_ + 4);
                 } else {
                     pre[jj][0] = f32x4{0.f, 0.f, 0.f, 0.f};
                     pre[jj][1] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
             }
         };
-        auto stash = [&](u32x4* img) {
+        auto stash = [&]() {
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
                 u32x4 p1, p2, p3;
@@ -518,19 +538,19 @@ __global__ __launch_bounds__(512, 1) void supgram_kernel(Sched sc, float* __rest
                 split3(pre[jj][0][2], pre[jj][0][3], x, y, z); p1[1] = x; p2[1] = y; p3[1] = z;
                 split3(pre[jj][1][0], pre[jj][1][1], x, y, z); p1[2] = x; p2[2] = y; p3[2] = z;
                 split3(pre[jj][1][2], pre[jj][1][3], x, y, z); p1[3] = x; p2[3] = y; p3[3] = z;
-                u32x4* o = img + dst[jj];
+                u32x4* o = aimg + dst[jj];
                 o[0] = p1; o[SG_BLK] = p2; o[2 * SG_BLK] = p3;
             }
         };
-        // The matrix instructions of a tile — 18 for the Gram half-tiles of the previous tile, 48 for the update — read all their A operands
-        // (and the Gram B operands) from LDS.  Left to the compiler every ds_read sits right in front of its consumer (s_waitcnt lgkmcnt(0)
-        // before each MFMA group) and the LDS latency is exposed 11 times per tile and wave; here the reads of stage i+1 are issued before the
-        // MFMAs of stage i (stages: Gram unit 0, 1, 2, update k-step 0..7), pinned with sched_barrier.
+        // The matrix instructions of a compute segment — 18 for the Gram half-tiles of an earlier tile, 48 for the update — read all their A
+        // operands (and the Gram B operands) from LDS.  Left to the compiler every ds_read sits right in front of its consumer (s_waitcnt
+        // lgkmcnt(0) before each MFMA group) and the LDS latency is exposed 11 times per tile and wave; here the reads of stage i+1 are issued
+        // before the MFMAs of stage i (stages: Gram unit 0, 1, 2, update k-step 0..7), pinned with sched_barrier.
         struct Opnd6 { bf16x8 a1, a2, a3, b1, b2, b3; };
         struct Opnd3 { bf16x8 a1, a2, a3; };
-        auto ldG = [&](int pa, int pb) {
-            const u32x4* oa = opnd + ((pa * 2 + kh) * 3) * 64 + lane;
-            const u32x4* ob_ = opnd + ((pb * 2 + kh) * 3) * 64 + lane;
+        auto ldG = [&](const u32x4* op, int pa, int pb) {
+            const u32x4* oa = op + ((pa * 2 + kh) * 3) * 64 + lane;
+            const u32x4* ob_ = op + ((pb * 2 + kh) * 3) * 64 + lane;
             Opnd6 r;
             r.a1 = __builtin_bit_cast(bf16x8, oa[0]); r.a2 = __builtin_bit_cast(bf16x8, oa[64]); r.a3 = __builtin_bit_cast(bf16x8, oa[128]);
             r.b1 = __builtin_bit_cast(bf16x8, ob_[0]); r.b2 = __builtin_bit_cast(bf16x8, ob_[64]); r.b3 = __builtin_bit_cast(bf16x8, ob_[128]);
@@ -545,43 +565,55 @@ __global__ __launch_bounds__(512, 1) void supgram_kernel(Sched sc, float* __rest
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.a1, r.b1, acc, 0, 0, 0);
             return acc;
         };
-        auto gram_tail = [&]() {  // after the last tile: nothing to overlap with
-            if (gon0) g0 = mmG(ldG(ga0, gb0), g0);
-            if (gon1) g1 = mmG(ldG(ga1, gb1), g1);
-            if (gon2) g2 = mmG(ldG(ga2, gb2), g2);
+        auto gram_of = [&](int t) {  // the three units of tile t, nothing to overlap with (tail)
+            if (r_begin + 32 * t >= m_pad) return;
+            const u32x4* op = opnd0 + (t & 1) * OPND_VECS;
+            if (gon0) g0 = mmG(ldG(op, ga0, gb0), g0);
+            if (gon1) g1 = mmG(ldG(op, ga1, gb1), g1);
+            if (gon2) g2 = mmG(ldG(op, ga2, gb2), g2);
         };
-        const int abl = sc.dbg_fill >> 8;  // tools/bench_supgram.py: timing-only ablations (results are wrong), always 0 in the product path
-        int cur = 0;
-        fetch(r_begin);
-        stash(aimg0);
+        const u32x4* img = aimg + (mypr * 8 * 3) * SG_BLK + h * SG_HB + c;
+        auto ldA = [&](int s) {
+            Opnd3 r;
+            r.a1 = __builtin_bit_cast(bf16x8, img[(3 * s + 0) * SG_BLK]);
+            r.a2 = __builtin_bit_cast(bf16x8, img[(3 * s + 1) * SG_BLK]);
+            r.a3 = __builtin_bit_cast(bf16x8, img[(3 * s + 2) * SG_BLK]);
+            return r;
+        };
+        const int glag = mypr ? 1 : 2;   // pair A accumulates the Gram units of tile t - 2 next to update t, pair B those of tile t - 1
+        float* __restrict__ Pst = Pw + (int64_t)r_begin * PB + (4 * h) * PB + c;   // this lane's first output element of tile 0
+
+        // ---- prologue: tile 0 staged, tile 1 in flight ----
+        fetch(0);
+        stash();
+        if (ntiles > 1) fetch(1);
         __syncthreads();
-        bool pending = false;  // Gram of the previous tile not yet accumulated (its operands are in opnd)
-        for (int r0 = r_begin; r0 < r_end; r0 += 32) {
-            const bool more = r0 + 32 < r_end;
-            if (more && !(abl & 8)) fetch(r0 + 32);
-            const u32x4* img = (cur ? aimg1 : aimg0) + (mypr * 8 * 3) * SG_BLK + h * SG_HB + c;
-            auto ldA = [&](int s) {
-                Opnd3 r;
-                r.a1 = __builtin_bit_cast(bf16x8, img[(3 * s + 0) * SG_BLK]);
-                r.a2 = __builtin_bit_cast(bf16x8, img[(3 * s + 1) * SG_BLK]);
-                r.a3 = __builtin_bit_cast(bf16x8, img[(3 * s + 2) * SG_BLK]);
-                return r;
-            };
+        if (mypr) __syncthreads();   // pair B runs one segment behind pair A
+#ifdef ASVD_SG_TIMING
+        const bool sg_ts_on = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && ob == 0 && lane == 0;
+#endif
+        for (int t = 0; t < ntiles; ++t) {
+            // ================= compute segment =================
+            SG_TS(0);
+            const int tg = t - glag;
+            const bool pending = tg >= 0 && r_begin + 32 * tg < m_pad;   // rows of the matrix proper only, not accumulated V rows
             Opnd3 ua;
-            if (pending) {  // reads opnd of the previous tile
-                Opnd6 x = ldG(ga0, gb0);
-                Opnd6 y = ldG(ga1, gb1);
+            if (pending) {
+                const u32x4* op = opnd0 + (tg & 1) * OPND_VECS;
+                Opnd6 x = ldG(op, ga0, gb0);
+                Opnd6 y = ldG(op, ga1, gb1);
                 __builtin_amdgcn_sched_barrier(0);
-                if (gon0 && !(abl & 4)) g0 = mmG(x, g0);
-                x = ldG(ga2, gb2);
+                if (gon0) g0 = mmG(x, g0);
+                x = ldG(op, ga2, gb2);
                 __builtin_amdgcn_sched_barrier(0);
-                if (gon1 && !(abl & 4)) g1 = mmG(y, g1);
+                if (gon1) g1 = mmG(y, g1);
                 ua = ldA(0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (gon2 && !(abl & 4)) g2 = mmG(x, g2);
+                if (gon2) g2 = mmG(x, g2);
             } else {
                 ua = ldA(0);
             }
+            SG_TS(1);
             f32x16 acc;
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[q] = 0.f;
@@ -591,27 +623,33 @@ __global__ __launch_bounds__(512, 1) void supgram_kernel(Sched sc, float* __rest
                 if (s + 1 < 8) un = ldA(s + 1);
                 __builtin_amdgcn_sched_barrier(0);
                 const bf16x8 B1 = __builtin_bit_cast(bf16x8, q1[s]), B2 = __builtin_bit_cast(bf16x8, q2[s]), B3 = __builtin_bit_cast(bf16x8, q3[s]);
-                if (s == 0 || !(abl & 2)) {
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.a3, B1, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.a1, B3, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.a2, B2, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.a2, B1, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.a1, B2, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.a1, B1, acc, 0, 0, 0);
-                }
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.a3, B1, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.a1, B3, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.a2, B2, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.a2, B1, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.a1, B2, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.a1, B1, acc, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 ua = un;
             }
-            if (mine && !(abl & 1)) {
+            SG_TS(2);
+            __syncthreads();   // own pair: done reading the incoming image; other pair: its memory segment ends
+            SG_TS(3);
+            // ================= memory segment =================
+            // order matters: vmcnt counts loads AND stores, and the panel stores are conditional (the compiler must assume none were issued), so a
+            // stash BEHIND this tile's stores would wait for them.  Stash first: it waits only for what the previous memory segment issued.
+            if (t + 1 < ntiles) stash();        // tile t + 1 (in registers since the previous memory segment) -> incoming image
+            SG_TS(6);
+            if (t + 2 < ntiles) fetch(t + 2);
+            SG_TS(7);
+            if (mine) {
+                float* __restrict__ po = Pst + (int64_t)t * (32 * PB);
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int i = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                    Pw[(int64_t)(r0 + i) * PB + c] = acc[reg];
-                }
+                for (int reg = 0; reg < 16; ++reg) po[((reg & 3) + 8 * (reg >> 2)) * PB] = acc[reg];
             }
-            __syncthreads();  // every wave is done with the previous tile's operands (and with tile[cur] as far as the stash below matters)
-            const bool gram_rows = r0 < m_pad;  // rows of the matrix proper only, not accumulated V rows
-            if (gram_rows && !(abl & 16)) {
+            SG_TS(8);
+            if (r_begin + 32 * t < m_pad) {
+                u32x4* ow = opnd0 + (t & 1) * OPND_VECS;
 #pragma unroll
                 for (int k2 = 0; k2 < 2; ++k2) {
                     u32x4 p1, p2, p3;
@@ -621,16 +659,18 @@ __global__ __launch_bounds__(512, 1) void supgram_kernel(Sched sc, float* __rest
                         split3(acc[8 * k2 + 2 * e2], acc[8 * k2 + 2 * e2 + 1], x, y, z);
                         p1[e2] = x; p2[e2] = y; p3[e2] = z;
                     }
-                    u32x4* o = opnd + ((otp * 2 + k2) * 3) * 64 + lane;
+                    u32x4* o = ow + ((otp * 2 + k2) * 3) * 64 + lane;
                     o[0] = p1; o[64] = p2; o[128] = p3;
                 }
             }
-            if (more && !(abl & 32)) stash(cur ? aimg0 : aimg1);
+            SG_TS(4);
             __syncthreads();
-            pending = gram_rows;
-            cur ^= 1;
+            SG_TS(5);
         }
-        if (pending) gram_tail();
+        if (!mypr) __syncthreads();   // pair A waits for pair B's last memory segment
+        // ---- tail: the Gram units not yet accumulated (pair A: the last two tiles, pair B: the last one) ----
+        if (ntiles - glag >= 0) gram_of(ntiles - glag);
+        if (glag == 2 && ntiles - 1 >= 0) gram_of(ntiles - 1);
     }
 
     // ---- the two k-steps of a tile sit in waves 2t and 2t+1 (j = 0), 2t-8 .. (j = 1), ...: sum through LDS, coalesced store ----

@@ -8,8 +8,8 @@ import torch
 
 def get_calib_data(name, tokenizer, model_id, nsamples, seqlen=2048, seed=3, use_bos=False, vocab_size=None):
     cache_file = f"cache/{name}_{model_id.replace('/','_')}_{nsamples}_{seqlen}_{seed}_bos{use_bos}.pt"
-    os.makedirs("cache", exist_ok=True)
-    if os.path.exists(cache_file):
+    from . import parallel
+    if parallel.cache_exists(cache_file):  # one answer for all ranks; the file is complete (written under a temporary name, then renamed)
         return torch.load(cache_file)
     if name != "synthetic":
         raise RuntimeError(f"calibration dataset '{name}' needs HF datasets + network, unavailable here; use --calib_dataset synthetic")
@@ -22,5 +22,5 @@ def get_calib_data(name, tokenizer, model_id, nsamples, seqlen=2048, seed=3, use
         if use_bos and getattr(tokenizer, "bos_token_id", None) is not None:
             inp[0, 0] = tokenizer.bos_token_id
         traindataset.append({"input_ids": inp, "attention_mask": torch.ones_like(inp)})
-    torch.save(traindataset, cache_file)
+    parallel.save_cache(traindataset, cache_file)  # the samples are a function of the seed: every rank built the same list, rank 0 writes it
     return traindataset

@@ -5,6 +5,7 @@ scaling, SVD, truncation and (layer, ratio) -> ppl evaluation is independent, so
 processing time first) assignment on the SVD flop estimate; the only exchange is ONE small all-gather of the per-layer
 sensitivities (<= 29 x 6 fp32 per rank for Llama-2-7B) before the — replicated, deterministic — binary search."""
 import math
+import os
 
 import torch
 import torch.distributed as dist
@@ -38,6 +39,36 @@ def lpt_assign(costs, world_size):
 def _comm_device():
     backend = dist.get_backend()
     return torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+
+
+def barrier():
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+
+
+def cache_exists(path):
+    """ONE answer for all ranks: rank 0 looks, every rank gets what it saw.  (With a shared working directory a rank that looks for itself
+    can see a file another rank created a moment ago and take the load branch while its peers take the compute branch — and the compute
+    branch may hold a collective.)"""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return os.path.exists(path)
+    flag = torch.tensor([1 if (dist.get_rank() == 0 and os.path.exists(path)) else 0], dtype=torch.int32, device=_comm_device())
+    dist.broadcast(flag, src=0)
+    return bool(int(flag.item()))
+
+
+def save_cache(obj, path):
+    """`.pt` cache files are written by rank 0 only, to a temporary name that is renamed into place (a reader sees the complete file or
+    none), and every rank waits until the file is there before it goes on."""
+    rank, _ = world()
+    if rank == 0:
+        d = os.path.dirname(path)
+        if d:
+            os.makedirs(d, exist_ok=True)
+        tmp = f"{path}.tmp.{os.getpid()}"
+        torch.save(obj, tmp)
+        os.replace(tmp, path)
+    barrier()
 
 
 def allgather_sensitivities(local, names, ratios, owner):

@@ -22,19 +22,24 @@ from .sweep_eval import PrefixCachedEvaluator
 
 
 def collect_linear_info(model):
-    """The reference's explicit stack walk (sensitivity.py:19-33 / binary_search.py:11-27): modules.pop() => reverse DFS."""
-    full_name_dict = {module: name for name, module in model.named_modules()}
-    linear_info = {}
-    modules = [model]
-    while len(modules) > 0:
-        submodule = modules.pop()
-        for name, raw_linear in submodule.named_children():
-            if isinstance(raw_linear, nn.Linear):
-                full_name = full_name_dict[raw_linear]
-                linear_info[raw_linear] = {"father": submodule, "name": name, "full_name": full_name}
+    """{nn.Linear: {"father", "name", "full_name"}} in the order the reference's sweep and search visit the layers (sensitivity.py:19-33,
+    binary_search.py:11-27): a module's own Linear children in registration order, then its other children LAST-FIRST, depth first —
+    lm_head, then the decoder layers from the last to the first, mlp before self_attn.  tests/golden/linear_order_hf.json pins it."""
+    qualified = {module: name for name, module in model.named_modules()}
+    found = {}
+
+    def visit(parent):
+        containers = []
+        for child_name, child in parent.named_children():
+            if isinstance(child, nn.Linear):
+                found[child] = {"father": parent, "name": child_name, "full_name": qualified[child]}
             else:
-                modules.append(raw_linear)
-    return linear_info
+                containers.append(child)
+        for child in reversed(containers):
+            visit(child)
+
+    visit(model)
+    return found
 
 
 def _multi_rank_module(raw_linear, ratios, args):
@@ -66,7 +71,7 @@ def _ppl_candidates(args):
 def calib_sensitivity_ppl(model, calib_loader, args, use_cache=True):
     model_id = model.config._name_or_path
     cache_file = f"cache/{model_id.replace('/','_')}_sensitivity_{args.scaling_method}_{args.alpha}_{args.n_calib_samples}_{args.calib_dataset}.pt"
-    if os.path.exists(cache_file) and use_cache:
+    if use_cache and parallel.cache_exists(cache_file):
         sensitivity_dict = torch.load(cache_file, map_location="cpu")
         return sensitivity_dict
     model.eval()
@@ -143,9 +148,7 @@ def calib_sensitivity_ppl(model, calib_loader, args, use_cache=True):
         if not keep_cache:
             SVDLinear.drop_factor_cache(raw_linear)
     sensitivity_dict = parallel.allgather_sensitivities(local, names, param_ratio_candidates, owner)
-    if rank == 0:
-        os.makedirs("cache", exist_ok=True)
-        torch.save(sensitivity_dict, cache_file)
+    parallel.save_cache(sensitivity_dict, cache_file)
     return sensitivity_dict
 
 
@@ -153,7 +156,7 @@ def calib_sensitivity_ppl(model, calib_loader, args, use_cache=True):
 def calib_sensitivity_stable_rank(model, calib_loader, args, use_cache=True):
     model_id = model.config._name_or_path
     cache_file = f"cache/{model_id.replace('/','_')}_sensitivity_stable_rank_{args.scaling_method}_{args.alpha}_{args.n_calib_samples}_{args.calib_dataset}.pt"
-    if os.path.exists(cache_file) and use_cache:
+    if use_cache and parallel.cache_exists(cache_file):
         sensitivity_dict = torch.load(cache_file, map_location="cpu")
         return sensitivity_dict
     model.eval()
@@ -204,7 +207,5 @@ def calib_sensitivity_stable_rank(model, calib_loader, args, use_cache=True):
         sensitivity_dict = {n: {r: torch.tensor(v) for r, v in d.items()} for n, d in full.items()}
     else:
         sensitivity_dict = {n: local[n] for n in names}
-    if rank == 0:
-        os.makedirs("cache", exist_ok=True)
-        torch.save(sensitivity_dict, cache_file)
+    parallel.save_cache(sensitivity_dict, cache_file)
     return sensitivity_dict

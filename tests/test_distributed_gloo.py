@@ -235,3 +235,65 @@ def test_bench_gpus2_dry_run_spawns_two_ranks():
     assert len(lines) == 1  # exactly one JSON line, from rank 0
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["dry_run"] is True and rec["scaling"] == "weak"
+
+
+def _cache_worker(rank, ws, port, q, tmpdir, shard):
+    """both ranks in ONE working directory: calibration data + hook pass with use_cache=True, twice (second pass = the load branch)"""
+    import contextlib, io, os as _os
+    _os.chdir(tmpdir)
+    _os.environ["MASTER_ADDR"] = "127.0.0.1"
+    _os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    try:
+        from asvd4llm_amd import act_aware_utils, datautils, ops
+        from tests.tiny_lm import TinyLM
+        # CPU stand-ins for the two hook kernels (the cache / collective plumbing is what is under test)
+        ops.absstat_partial = lambda x2, method: x2
+        def _fin(work, T, C, acc, method):
+            if "abs_max" in method:
+                torch.maximum(acc, work.abs().amax(0), out=acc)
+            else:
+                acc.add_(work.abs().mean(0))
+        ops.absstat_finalize = _fin
+        out = []
+        for it in range(2):
+            model = TinyLM()
+            model.config._name_or_path = "tiny/lm"
+            calib = datautils.get_calib_data("synthetic", None, "tiny/lm", 3, seqlen=16, seed=7, vocab_size=50)
+            with contextlib.redirect_stderr(io.StringIO()):
+                act_aware_utils.calib_input_distribution(model, calib, "abs_mean", use_cache=True, shard_samples=shard)
+            stats = {n: m.scaling_diag_matrix.clone() for n, m in model.named_modules() if isinstance(m, torch.nn.Linear)}
+            out.append((torch.cat([c["input_ids"] for c in calib]), stats))
+        files = sorted(_os.listdir("cache"))
+        q.put((rank, out, files))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(240)
+@pytest.mark.parametrize("shard", [False, True])
+def test_cache_files_are_written_once_and_read_complete_world2(tmp_path, shard):
+    """every rank used to torch.save the same cache files and load as soon as the name existed.  Now rank 0 writes (temporary
+    name + rename), the others wait; `cache_exists` gives every rank rank 0's answer.  With --shard_calib a rank that ran fewer samples than its
+    peer (3 samples over 2 ranks) still takes part in the all-reduce with a buffer of the same layout."""
+    ws = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_cache_worker, args=(r, ws, port, q, str(tmp_path), shard)) for r in range(ws)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=200) for _ in range(ws)], key=lambda r: r[0])
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    (_, out0, files0), (_, out1, files1) = res
+    assert files0 == files1 and len(files0) == 2 and not any(".tmp." in f for f in files0), files0
+    for (ids_a, st_a), (ids_b, st_b) in zip(out0, out1):   # rank 0 vs rank 1, both passes
+        assert torch.equal(ids_a, ids_b)
+        assert st_a.keys() == st_b.keys()
+        for n in st_a:
+            assert torch.equal(st_a[n], st_b[n]), n
+    for n in out0[0][1]:   # computed (first pass) vs loaded from the cache (second pass)
+        assert torch.equal(out0[0][1][n], out0[1][1][n])
+        assert out0[0][1][n].abs().sum() > 0

@@ -1,26 +1,59 @@
-"""Timing of ONE launch shape of the fused update + Gram kernel (supgram_kernel) in isolation, with timing-only ablations
-(ASVD_SG_ABLATE bits: 1 no panel stores, 2 one of eight update k-steps, 4 no Gram MFMAs, 8 no panel fetch, 16 no Gram operand split,
-32 no next-tile split).  The ablated results are wrong by construction; the numbers only say which resource the kernel waits for."""
-import ctypes, json, os, sys, subprocess
+"""Timing of ONE launch shape of the fused update + Gram kernel (supgram_kernel) in isolation.
 
-def one(abl, ns=64, R=4096, batch=32, D=1, E=2, reps=10):
+  python tools/bench_supgram.py [--near_identity] [--timing]
+
+--near_identity  Q = qr(I + 1e-3 N): the late-sweep regime (most of a real step); default is a random orthogonal Q (all three bf16
+                 parts of Q dense: the worst case for the matrix pipe's power draw)
+--timing         measurement build (-DASVD_SG_TIMING -> asvd4llm_amd/libasvd_hip_meas.so, built here beforehand with
+                 `python tools/bench_supgram.py --build_meas`): s_memtime stamps of one wave per pair of workgroup (0,0,0) —
+                 compute segment (Gram part | update part), barrier wait, memory segment, barrier wait, in shader cycles per tile."""
+import argparse, ctypes, json, os, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+MEAS = os.path.join(ROOT, "asvd4llm_amd", "libasvd_hip_meas.so")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--near_identity", action="store_true")
+    ap.add_argument("--timing", action="store_true")
+    ap.add_argument("--build_meas", action="store_true")
+    ap.add_argument("--ns", type=int, default=64)
+    ap.add_argument("--R", type=int, default=4096)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--reps", type=int, default=10)
+    a = ap.parse_args()
+    if a.build_meas:
+        from asvd4llm_amd import build as b
+        print(b.build(force=True, verbose=False, extra_flags=["-DASVD_SG_TIMING"], out=MEAS))
+        return
     import torch
-    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from asvd4llm_amd import _lib as L
-    os.environ["ASVD_SG_ABLATE"] = str(abl)
-    lib = L.load(True)
+    if a.timing:
+        lib = ctypes.CDLL(MEAS)
+        lib.asvd_test_supgram.restype = ctypes.c_int
+        lib.asvd_test_supgram.argtypes = L.SIGNATURES["asvd_test_supgram"][1]
+    else:
+        lib = L.load(True)
     gpu = torch.device("cuda:0")
+    ns, R, batch = a.ns, a.R, a.batch
     nb, npairs = 2 * ns, ns // 2
     X = torch.randn(batch, nb, R, 32, device=gpu) * 0.05
-    Q = torch.linalg.qr(torch.randn(npairs, 128, 128, device=gpu))[0].contiguous().unsqueeze(0).expand(batch, -1, -1, -1).contiguous()
+    if a.near_identity:
+        Q = torch.linalg.qr(torch.eye(128, device=gpu) + 1e-3 * torch.randn(npairs, 128, 128, device=gpu))[0]
+    else:
+        Q = torch.linalg.qr(torch.randn(npairs, 128, 128, device=gpu))[0]
+    Q = Q.contiguous().unsqueeze(0).expand(batch, -1, -1, -1).contiguous()
     flags = torch.ones(batch, npairs, 4, dtype=torch.int32, device=gpu)
     done = torch.zeros(batch, dtype=torch.int32, device=gpu)
     nupd = torch.zeros(batch, dtype=torch.int32, device=gpu)
     Gx = torch.zeros(batch, npairs, 1, 6, 1024, device=gpu)
     vp = ctypes.c_void_p
     st = torch.cuda.current_stream().cuda_stream
+
     def run():
-        rc = lib.asvd_test_supgram(vp(X.data_ptr()), R * 32, nb * R * 32, ns, D, E, R, R, R, vp(Q.data_ptr()), vp(flags.data_ptr()),
+        rc = lib.asvd_test_supgram(vp(X.data_ptr()), R * 32, nb * R * 32, ns, 1, 2, R, R, R, vp(Q.data_ptr()), vp(flags.data_ptr()),
                                    vp(Gx.data_ptr()), vp(done.data_ptr()), vp(nupd.data_ptr()), 1, npairs, batch, vp(st))
         assert rc == 0
     for _ in range(3):
@@ -28,17 +61,29 @@ def one(abl, ns=64, R=4096, batch=32, D=1, E=2, reps=10):
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(reps):
+    for _ in range(a.reps):
         run()
     e1.record()
     torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) * 1e3 / reps
+    us = e0.elapsed_time(e1) * 1e3 / a.reps
     gb = 2 * X.numel() * 4 / 1e9
-    print(json.dumps({"ablate": abl, "us_per_launch": round(us, 1), "us_per_tile": round(us / (2 * R / 32), 3), "TBps_rw": round(gb / us * 1e3 / 1e3, 3)}), flush=True)
+    tiles = (ns // 4) * batch * (R // 32) / 256.0   # 32-row tiles per CU
+    out = {"near_identity": a.near_identity, "us_per_launch": round(us, 1), "us_per_tile": round(us / tiles, 3), "TBps_rw": round(gb / us * 1e3 / 1e3, 3)}
+    if a.timing:
+        buf = (ctypes.c_ulonglong * (2 * 64 * 10))()
+        lib.asvd_test_sg_timing.restype = ctypes.c_int
+        assert lib.asvd_test_sg_timing(buf) == 0
+        ts = torch.tensor(list(buf), dtype=torch.int64).view(2, 64, 10)
+        for pr in range(2):
+            t = ts[pr, 8:56].double()   # steady state
+            seg = {"gram": (t[:, 1] - t[:, 0]).mean().item(), "update": (t[:, 2] - t[:, 1]).mean().item(), "bar_after_compute": (t[:, 3] - t[:, 2]).mean().item(),
+                   "memory": (t[:, 4] - t[:, 3]).mean().item(), "m_stash": (t[:, 6] - t[:, 3]).mean().item(), "m_fetch": (t[:, 7] - t[:, 6]).mean().item(),
+                   "m_stores": (t[:, 8] - t[:, 7]).mean().item(), "m_opnd": (t[:, 4] - t[:, 8]).mean().item(), "bar_after_memory": (t[:, 5] - t[:, 4]).mean().item(),
+                   "tile_period": (t[1:, 0] - t[:-1, 0]).mean().item()}
+            out[f"pair{pr}_cycles"] = {k: round(v) for k, v in seg.items()}
+        out["pair1_minus_pair0_start"] = round((ts[1, 8:56, 0] - ts[0, 8:56, 0]).double().mean().item())
+    print(json.dumps(out), flush=True)
+
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1:
-        one(int(sys.argv[1]))
-    else:
-        for abl in [0, 1, 2, 4, 8, 16, 32, 6, 7, 9, 15, 63, 54]:
-            subprocess.run([sys.executable, os.path.abspath(__file__), str(abl)], check=False)
+    main()
