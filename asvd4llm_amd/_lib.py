@@ -6,7 +6,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libasvd_hip.so")
+LIB_PATH = os.environ.get("ASVD_HIP_LIB") or os.path.join(_HERE, "libasvd_hip.so")   # ASVD_HIP_LIB: A/B runs of measurement builds (tools/)
 
 F32, F16, BF16 = 0, 1, 2
 FUSE = {"UV": 0, "U": 1, "V": 2}
@@ -46,10 +46,10 @@ SIGNATURES = {
     "asvd_lowrank_forward_f16": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
     "asvd_fro_worksize": (_i, [_i64, _i64, _c.POINTER(_sz)]),
     "asvd_fro_norm_sq": (_i, [_vp, _i, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
-    "asvd_reconstruct_worksize": (_i, [_i64, _i64, _c.POINTER(_sz)]),
+    "asvd_reconstruct_worksize": (_i, [_i64, _i64, _i64, _c.POINTER(_sz)]),
     "asvd_reconstruct_err": (_i, [_vp, _i, _i64, _vp, _vp, _i, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
-    "asvd_test_supdate": (_i, [_i, _vp, _i64, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
-    "asvd_test_supgram": (_i, [_vp, _i64, _i64, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "asvd_test_supdate": (_i, [_vp, _i64, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "asvd_test_supgram": (_i, [_vp, _i64, _i64, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "asvd_test_super_schedule": (_i, [_i, _i, _vp, _i, _c.POINTER(_i), _c.POINTER(_i)]),
     "asvd_test_evd_wave": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "asvd_svd_set_profiling": (None, [_i]),

@@ -2,6 +2,7 @@
 // column scaling (K3), truncate/un-scale/fuse/split (K5/K6), Frobenius norm (K8) and the reconstruction-error
 // evidence kernel (K9).  Reference lines are cited at each entry point in include/asvd_hip.h.
 #include "common.h"
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
@@ -338,6 +339,113 @@ __global__ __launch_bounds__(256) void recon_err_kernel(const void* __restrict__
         part[2 * bid + 1] = ((red[0][1] + red[1][1]) + red[2][1]) + red[3][1];
     }
 }
+// K9 for 16-bit factors (what SVDLinear holds): tiled NT GEMM on the fp16 / bf16 matrix pipe — products of 16-bit factors are exact there, the
+// accumulation is fp32 — fused with the squared-difference reduction against W.  Both operands are first brought to a K-contiguous, zero-padded
+// form in the workspace (Ap [m][rp], Bt [n][rp], rp = r rounded up to 64: rows 128-byte aligned, no tails), then a 256-thread workgroup owns a
+// 128 x 128 tile of A B (wave (wr, wc): 64 x 64 = 2 x 2 MFMA tiles, 64 accumulator registers) and reads its operands STRAIGHT from global memory
+// in MFMA operand order: lane (i, h) loads the 64 contiguous bytes k = 64 it + 32 h .. + 31 of its row and feeds 8-value chunk q to MFMA q (the
+// reduction index of an MFMA may be permuted as long as both operands agree), so every row is read as whole 128-byte lines; the loads of chunk
+// it + 1 are issued before the 16 MFMAs of chunk it.  The factors are re-read by the workgroups of a tile row / column through L2.
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 b16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void pad_rows16_kernel(const uint16_t* __restrict__ A, int64_t m, int64_t r, int64_t rp, uint16_t* __restrict__ Ap) {
+    const int64_t row = blockIdx.y;
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < rp; k += (int64_t)gridDim.x * 256) Ap[row * rp + k] = k < r ? A[row * r + k] : (uint16_t)0;
+}
+// Bt[j][k] = B[k][j] through 32 x 32 tiles (both sides coalesced), zero for k >= r.  grid (ceil(n/32), rp/32)
+__global__ __launch_bounds__(256) void transpose_pad16_kernel(const uint16_t* __restrict__ B, int64_t r, int64_t n, int64_t rp, uint16_t* __restrict__ Bt) {
+    __shared__ uint16_t tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int64_t j0 = (int64_t)blockIdx.x * 32, k0 = (int64_t)blockIdx.y * 32;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t k = k0 + ty + 8 * u, j = j0 + tx;
+        tile[ty + 8 * u][tx] = (k < r && j < n) ? B[k * n + j] : (uint16_t)0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t j = j0 + ty + 8 * u, k = k0 + tx;
+        if (j < n) Bt[j * rp + k] = tile[tx][ty + 8 * u];
+    }
+}
+
+template <int WT, int BF>   // BF: 1 bf16 factors, 0 fp16
+__global__ __launch_bounds__(256, 2) void recon_err16_kernel(const void* __restrict__ W, int64_t ldw, const uint16_t* __restrict__ Ap,
+                                                             const uint16_t* __restrict__ Bt, int64_t m, int64_t n, int64_t rp, double* __restrict__ part) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wr = w >> 1, wc = w & 1;
+    const int h = lane >> 5, c = lane & 31;
+    const int64_t r0 = (int64_t)blockIdx.y * 128 + wr * 64, c0 = (int64_t)blockIdx.x * 128 + wc * 64;
+    const uint16_t* pa[2];
+    const uint16_t* pb[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        pa[t] = Ap + min(r0 + 32 * t + c, m - 1) * rp + 32 * h;   // rows beyond the matrix re-read its last row: masked in the epilogue
+        pb[t] = Bt + min(c0 + 32 * t + c, n - 1) * rp + 32 * h;
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16){0};
+    u32x4 a[2][4], b[2][4], an[2][4], bn[2][4];
+    auto fetch = [&](int64_t it, u32x4 (&ra)[2][4], u32x4 (&rb)[2][4]) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                ra[t][q] = *(const u32x4*)(pa[t] + it * 64 + 8 * q);
+                rb[t][q] = *(const u32x4*)(pb[t] + it * 64 + 8 * q);
+            }
+    };
+    const int64_t nit = rp / 64;
+    fetch(0, a, b);
+    for (int64_t it = 0; it < nit; ++it) {
+        if (it + 1 < nit) fetch(it + 1, an, bn);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if constexpr (BF) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b16x8, a[i][q]), __builtin_bit_cast(b16x8, b[j][q]), acc[i][j], 0, 0, 0);
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a[i][q]), __builtin_bit_cast(h16x8, b[j][q]), acc[i][j], 0, 0, 0);
+                }
+        if (it + 1 < nit) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { a[t][q] = an[t][q]; b[t][q] = bn[t][q]; }
+        }
+    }
+    double e2 = 0.0, w2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int64_t row = r0 + 32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * h, col = c0 + 32 * j + c;
+                if (row < m && col < n) {
+                    const float wv = elem<WT>::ld(W, row * ldw + col);
+                    const double d = (double)wv - (double)acc[i][j][reg];
+                    e2 += d * d;
+                    w2 += (double)wv * (double)wv;
+                }
+            }
+    e2 = wave_reduce_sum_d(e2);
+    w2 = wave_reduce_sum_d(w2);
+    __shared__ double red[4][2];
+    if (lane == 0) { red[w][0] = e2; red[w][1] = w2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int64_t bid = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+        part[2 * bid + 0] = ((red[0][0] + red[1][0]) + red[2][0]) + red[3][0];
+        part[2 * bid + 1] = ((red[0][1] + red[1][1]) + red[2][1]) + red[3][1];
+    }
+}
 __global__ __launch_bounds__(256) void ordered_sum_d2_kernel(const double* __restrict__ part, int64_t np, double* __restrict__ out) {
     __shared__ double red[256][2];
     double a = 0.0, b = 0.0;
@@ -517,27 +625,43 @@ int asvd_fro_norm_sq(const void* w, int w_dtype, int64_t m, int64_t n, int64_t l
     return ASVD_OK;
 }
 
-int asvd_reconstruct_worksize(int64_t m, int64_t n, size_t* bytes) {
-    if (!bytes || m < 1 || n < 1) return ASVD_E_BADARG;
-    *bytes = (size_t)(ceil_div64(m, 64) * ceil_div64(n, 64)) * 2 * sizeof(double);
+static size_t recon_part_bytes(int64_t m, int64_t n) { return (((size_t)(ceil_div64(m, 64) * ceil_div64(n, 64)) * 2 * sizeof(double)) + 255) & ~(size_t)255; }
+
+int asvd_reconstruct_worksize(int64_t m, int64_t n, int64_t r, size_t* bytes) {
+    if (!bytes || m < 1 || n < 1 || r < 1) return ASVD_E_BADARG;
+    const int64_t rp = round_up64(r, 64);
+    *bytes = recon_part_bytes(m, n) + (size_t)(m + n) * rp * 2;   // partial sums + the K-contiguous padded copies of 16-bit factors
     return ASVD_OK;
 }
 
 int asvd_reconstruct_err(const void* W, int w_dtype, int64_t ldw, const void* A, const void* B, int ab_dtype, int64_t m, int64_t n,
                          int64_t r, double* out, void* work, size_t work_bytes, void* stream) {
     if (!W || !A || !B || !out || !work || m < 1 || n < 1 || r < 1 || ldw < n || !dtype_ok(w_dtype) || !dtype_ok(ab_dtype)) return ASVD_E_BADARG;
-    const int64_t gx = ceil_div64(n, 64), gy = ceil_div64(m, 64);
-    if (work_bytes < (size_t)(gx * gy) * 2 * sizeof(double)) return ASVD_E_WORKSPACE;
+    size_t need = 0;
+    (void)asvd_reconstruct_worksize(m, n, r, &need);
+    if (work_bytes < need) return ASVD_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
+    double* part = (double*)work;
+    if (ab_dtype == ASVD_F32) {  // fp32 factors (not what SVDLinear holds): one wave per 32 x 32 tile on the fp32 MFMA
+        const int64_t gx = ceil_div64(n, 64), gy = ceil_div64(m, 64);
+        dim3 grid((unsigned)gx, (unsigned)gy);
+        ASVD_DISPATCH_DTYPE(w_dtype, WT, { recon_err_kernel<WT, ASVD_F32><<<grid, 256, 0, st>>>(W, ldw, A, B, m, n, r, part); });
+        ordered_sum_d2_kernel<<<1, 256, 0, st>>>(part, gx * gy, out);
+        ASVD_HIP_CHECK(hipGetLastError());
+        return ASVD_OK;
+    }
+    const int64_t rp = round_up64(r, 64);
+    uint16_t* Ap = (uint16_t*)((char*)work + recon_part_bytes(m, n));
+    uint16_t* Bt = Ap + m * rp;
+    pad_rows16_kernel<<<dim3((unsigned)std::min<int64_t>(ceil_div64(rp, 256), 64), (unsigned)m), 256, 0, st>>>((const uint16_t*)A, m, r, rp, Ap);
+    transpose_pad16_kernel<<<dim3((unsigned)ceil_div64(n, 32), (unsigned)(rp / 32)), 256, 0, st>>>((const uint16_t*)B, r, n, rp, Bt);
+    const int64_t gx = ceil_div64(n, 128), gy = ceil_div64(m, 128);
     dim3 grid((unsigned)gx, (unsigned)gy);
     ASVD_DISPATCH_DTYPE(w_dtype, WT, {
-        switch (ab_dtype) {
-            case ASVD_F32: recon_err_kernel<WT, ASVD_F32><<<grid, 256, 0, st>>>(W, ldw, A, B, m, n, r, (double*)work); break;
-            case ASVD_F16: recon_err_kernel<WT, ASVD_F16><<<grid, 256, 0, st>>>(W, ldw, A, B, m, n, r, (double*)work); break;
-            default: recon_err_kernel<WT, ASVD_BF16><<<grid, 256, 0, st>>>(W, ldw, A, B, m, n, r, (double*)work); break;
-        }
+        if (ab_dtype == ASVD_BF16) recon_err16_kernel<WT, 1><<<grid, 256, 0, st>>>(W, ldw, Ap, Bt, m, n, rp, part);
+        else recon_err16_kernel<WT, 0><<<grid, 256, 0, st>>>(W, ldw, Ap, Bt, m, n, rp, part);
     });
-    ordered_sum_d2_kernel<<<1, 256, 0, st>>>((const double*)work, gx * gy, out);
+    ordered_sum_d2_kernel<<<1, 256, 0, st>>>(part, gx * gy, out);
     ASVD_HIP_CHECK(hipGetLastError());
     return ASVD_OK;
 }

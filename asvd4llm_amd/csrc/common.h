@@ -62,20 +62,12 @@ template <> struct elem<ASVD_BF16> {
 static inline size_t dtype_size(int dt) { return dt == ASVD_F32 ? 4 : 2; }
 static inline bool dtype_ok(int dt) { return dt == ASVD_F32 || dt == ASVD_F16 || dt == ASVD_BF16; }
 
-// ---- cache maintenance at kernel boundaries --------------------------------------------------------
-// The sweeps CAN run independent problem groups on several HIP streams at once (ASVD_GROUPS > 1; default 1 since round 2).
-// Measured on MI355X / ROCm 7.2: with kernels of OTHER streams in flight, data a kernel leaves in its XCD's L2 (small buffers that
-// are re-written every step: carried Gram blocks, 64x64 Q's, flags) was not reliably visible to the next kernel of the SAME stream
-// when that ran on another XCD — nondeterministic stale reads (the Jacobi iteration absorbs them as extra sweeps, which is how they
-// were found), never with a single stream.  With more than one stream group every kernel of the sweeps therefore starts with an
-// agent-scope acquire (invalidate this CU's L1) and ends with an agent-scope release (write back the XCD L2's dirty lines); either
-// fence alone was not enough.  The release costs a full L2 write-back per workgroup (the streaming kernels run 2x slower with
-// it), which is more than the 5-9 % the overlap of stream groups buys: one stream group, no fences, is the default.
-// The flag travels with every launch (Sched::fence, a kernel ARGUMENT): nothing the kernels read is process-global state, so concurrent
-// calls with different settings cannot disturb each other.
-// fence bits: 1 = acquire at kernel start, 2 = release at kernel end (ASVD_FENCE=1 means both; 2 / 3 = acquire / release only, experiments)
-#define ASVD_KERNEL_ACQUIRE(sc) do { if ((sc).fence & 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); } while (0)
-#define ASVD_KERNEL_RELEASE(sc) do { if ((sc).fence & 2) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); } while (0)
+// ---- one stream per call --------------------------------------------------------------------------
+// Every launch of a call goes to the caller's stream; kernel boundaries on that stream order everything.  (Rounds 1-2 drove independent problem
+// groups on several streams; what looked like missing cache maintenance between them was a race inside the LDS eigen-solver of the time — gone
+// with that solver in round 3 — and the overlap bought nothing once single launches filled the chip, so the stream groups, their agent-scope
+// fences and the solver are all gone: DESIGN.md 3.8.)  Concurrent CALLS on different streams with disjoint workspaces are supported and tested
+// (tests/test_gpu_concurrency.py): nothing the kernels read is process-global state, schedules travel by value in the Sched argument.
 
 // ---- small control words rewritten between launches (activity flags, done flags, pair lists) ----------------------------------
 // Read through the VECTOR path with an agent-scope load (global_load ... sc1: served by L2, never by the scalar data cache or this

@@ -465,7 +465,6 @@ __global__ __launch_bounds__(256, 2) void evdw0_kernel(Sched sc, const float* __
     const int lane = threadIdx.x & 63, wv_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wv = NW == 1 ? wv_ : 0, hw = NW == 1 ? 0 : wv_;
     const int pair = NW == 1 ? blockIdx.x * 4 + wv_ : blockIdx.x, b = blockIdx.y;
-    ASVD_KERNEL_ACQUIRE(sc);
     if (pair >= npairs || ld_flag(done + b)) return;   // NW = 1: no workgroup barrier below, the waves are independent
     const int64_t slot = (int64_t)b * npairs + pair;
     int* act_flag = active + slot;
@@ -518,6 +517,10 @@ __global__ __launch_bounds__(256, 2) void evdw0_kernel(Sched sc, const float* __
         atomicMax(&maxoff_bits[b], is_nan ? 0x7fc00000u : __float_as_uint(offt));
         *act_flag = rotate ? 1 : 0;
         if (rotate && offt >= tol) atomicAdd(&nrot[b], 1);
+        if (v3.hist && !is_nan) {  // debug: decade histogram of the pair measure (ASVD_DEBUG_HIST)
+            const int bk = (int)floorf(-log10f(fmaxf(off0, 1e-30f)));
+            atomicAdd(&v3.hist[bk < 0 ? 0 : (bk > 9 ? 9 : bk)], 1);
+        }
     }
     float* d0 = KEEPG ? v3.Gd32 + ((int64_t)b * v3.nbpan + I) * 1024 : nullptr;
     float* d1 = KEEPG ? v3.Gd32 + ((int64_t)b * v3.nbpan + J) * 1024 : nullptr;
@@ -534,13 +537,12 @@ __global__ __launch_bounds__(256, 2) void evdw0_kernel(Sched sc, const float* __
                 else d1[r * 32 + cc] = g[32 + r];
             }
         }
-        ASVD_KERNEL_RELEASE(sc);
         return;
     }
     if constexpr (NW == 1) {
         evdw_identity(q, lane);
         const int nsw = (off0 > 0.05f) ? inner_sweeps : min(1, inner_sweeps);
-        evdw_sweep(g, q, diag, bpiv, lane, nsw * sc.evd_pairs, csbuf[wv]);
+        evdw_sweep(g, q, diag, bpiv, lane, nsw * EVD_PHASE_PAIRS, csbuf[wv]);
     }
     float cs;
     int rnk;
@@ -549,7 +551,6 @@ __global__ __launch_bounds__(256, 2) void evdw0_kernel(Sched sc, const float* __
 #pragma unroll
     for (int r = 0; r < 64; ++r) qo[r * PW + rnk] = q[r] * cs;
     if (KEEPG && v3.Gd32) evdw_store_diag_blocks(g, diag, cs, rnk, lane, d0, d1);
-    ASVD_KERNEL_RELEASE(sc);
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -597,7 +598,6 @@ __global__ __launch_bounds__(128 * NW, NW == 1 ? 2 : 1) void evdw12_kernel(Sched
     const int hi = lane >> 5, cc = lane & 31;
     const int pair = blockIdx.x, b = blockIdx.y, npairs = gridDim.x;
     float* const LC = e12_smem + E12_SMEM_FLOATS + sp * Coop<NW == 1 ? 4 : NW>::FLOATS;   // cooperative-sweep block of this solve (NW > 1 only)
-    ASVD_KERNEL_ACQUIRE(sc);
     if (ld_flag(done + b)) return;              // uniform over the workgroup
     const int64_t slot = (int64_t)b * npairs + pair;
     int* const sub = v3.subact + slot * 4;      // [step 0: sub-pairs 0, 1 | step 1: sub-pairs 0, 1]
@@ -605,6 +605,13 @@ __global__ __launch_bounds__(128 * NW, NW == 1 ? 2 : 1) void evdw12_kernel(Sched
     super_pair(sc, v3.ns, step, pair, S, T);
     if (T >= v3.ns) {                           // padding super-pair
         if (lane == 0) { sub[sp] = 0; sub[2 + sp] = 0; }
+        // a present lower member still streams through the fused update + Gram kernel (its panels feed the next step's tiles): its column
+        // norms are the carried diagonals as they stand
+        if (v3.Din && hw == 0) {
+            float dv = 0.0f;
+            if (S < v3.ns && lane < 32) dv = v3.Gd32[((int64_t)b * v3.nbpan + 2 * S + sp) * 1024 + lane * 33];
+            v3.Din[slot * 128 + (lane < 32 ? 32 * sp + lane : 64 + 32 * sp + (lane - 32))] = dv;
+        }
         return;
     }
     const float* __restrict__ gx = v3.Gx6 + slot * v3.nsplit6 * (6 * 1024);
@@ -652,6 +659,7 @@ __global__ __launch_bounds__(128 * NW, NW == 1 ? 2 : 1) void evdw12_kernel(Sched
         }
         stamp();  // 1: image loaded
         evdw_init_state(g, lane, diag, bpiv);
+        if (v3.Din) v3.Din[slot * 128 + (lane < 32 ? 32 * sp + lane : 64 + 32 * sp + (lane - 32))] = diag;   // pre-rotation squared column norms, Q order
         evdw_measure(g, diag, lane, I < kb, J < kb, off0, offt);
         const bool is_nan = off0 != off0;
         const bool rotate = !(is_nan || off0 < tol);
@@ -659,12 +667,16 @@ __global__ __launch_bounds__(128 * NW, NW == 1 ? 2 : 1) void evdw12_kernel(Sched
             atomicMax(&maxoff_bits[b], is_nan ? 0x7fc00000u : __float_as_uint(offt));
             sub[sp] = rotate ? 1 : 0;
             if (rotate && offt >= tol) atomicAdd(&nrot[b], 1);
+            if (v3.hist && !is_nan) {  // debug: decade histogram of the pair measure (ASVD_DEBUG_HIST)
+                const int bk = (int)floorf(-log10f(fmaxf(off0, 1e-30f)));
+                atomicAdd(&v3.hist[bk < 0 ? 0 : (bk > 9 ? 9 : bk)], 1);
+            }
         }
         evdw_identity(q, lane);
         stamp();  // 2: measured
         asm volatile("" ::: "memory");
         if constexpr (NW > 1) coop_sweep<NW>(g, q, diag, bpiv, rotate, lane, 0, LC);
-        else if (rotate) evdw_sweep(g, q, diag, bpiv, lane, ((off0 > 0.05f) ? inner_sweeps : min(1, inner_sweeps)) * sc.evd_pairs, e12_smem + E12_CS + sp * 128);
+        else if (rotate) evdw_sweep(g, q, diag, bpiv, lane, ((off0 > 0.05f) ? inner_sweeps : min(1, inner_sweeps)) * EVD_PHASE_PAIRS, e12_smem + E12_CS + sp * 128);
         asm volatile("" ::: "memory");   // no load of a later stage is hoisted above the sweep (its registers would be spilled across it)
         stamp();  // 3: swept
         evdw_finish(q, diag, lane, rotate, cs, rnk);
@@ -784,10 +796,14 @@ __global__ __launch_bounds__(128 * NW, NW == 1 ? 2 : 1) void evdw12_kernel(Sched
             atomicMax(&maxoff_bits[b], is_nan ? 0x7fc00000u : __float_as_uint(offt));
             sub[2 + sp] = rotate ? 1 : 0;
             if (rotate && offt >= tol) atomicAdd(&nrot[b], 1);
+            if (v3.hist && !is_nan) {  // debug: decade histogram of the pair measure (ASVD_DEBUG_HIST)
+                const int bk = (int)floorf(-log10f(fmaxf(off0, 1e-30f)));
+                atomicAdd(&v3.hist[bk < 0 ? 0 : (bk > 9 ? 9 : bk)], 1);
+            }
         }
         evdw_identity(q, lane1);
         if constexpr (NW > 1) coop_sweep<NW>(g, q, diag, bpiv, rotate, lane1, 0, LC);
-        else if (rotate) evdw_sweep(g, q, diag, bpiv, lane1, ((off0 > 0.05f) ? inner_sweeps : min(1, inner_sweeps)) * sc.evd_pairs, e12_smem + E12_CS + sp * 128);
+        else if (rotate) evdw_sweep(g, q, diag, bpiv, lane1, ((off0 > 0.05f) ? inner_sweeps : min(1, inner_sweeps)) * EVD_PHASE_PAIRS, e12_smem + E12_CS + sp * 128);
         asm volatile("" ::: "memory");
         stamp();  // 10: swept
         evdw_finish(q, diag, lane1, rotate, cs, rnk);
@@ -853,7 +869,6 @@ __global__ __launch_bounds__(128 * NW, NW == 1 ? 2 : 1) void evdw12_kernel(Sched
         }
     }
     stamp();  // 12: Qfin written
-    ASVD_KERNEL_RELEASE(sc);
 }
 
 // Test hook kernel: one wave per 64x64 symmetric matrix (row-major), `sweeps` full inner sweeps, outputs the UNSORTED eigenvector
@@ -899,7 +914,7 @@ void launch_evdw0(bool keepg, int npairs, int batch, hipStream_t st, const Sched
                   unsigned* maxoff_bits, int* nrot, const int* done, float tol, int inner_sweeps, int nb, int step, int kb, const int* plist,
                   int list_stride, const EvdV3& v3) {
     // latency form (one pair per workgroup, four waves per solve; bit-identical) when the pairs of the launch would leave most SIMDs idle
-    const bool coop = inner_sweeps == 1 && sc.evd_pairs == 32 && (evdq_env() == 1 || (evdq_env() != 0 && (long long)npairs * batch <= 512));
+    const bool coop = inner_sweeps == 1 && (evdq_env() == 1 || (evdq_env() != 0 && (long long)npairs * batch <= 512));
     if (coop) {
         const dim3 grid((unsigned)npairs, (unsigned)batch);
         if (keepg)
@@ -933,7 +948,7 @@ void launch_evdw12(int npairs_s, int batch, hipStream_t st, const Sched& sc, uns
     }
     // latency form when the launch cannot even give every CU one workgroup: four waves per solve (bit-identical results).  It needs one
     // full inner sweep per visit (the default) and the standard 32 phase pairs.  ASVD_EVDQ=0 / 1 forces the choice.
-    const bool coop = inner_sweeps == 1 && sc.evd_pairs == 32 && (evdq_env() == 1 || (evdq_env() != 0 && (long long)npairs_s * batch <= 256));
+    const bool coop = inner_sweeps == 1 && (evdq_env() == 1 || (evdq_env() != 0 && (long long)npairs_s * batch <= 256));
     if (coop) {
         evdw12_kernel<EVDQ_NW><<<dim3((unsigned)npairs_s, (unsigned)batch), 128 * EVDQ_NW, evdq12_lds_bytes(), st>>>(sc, maxoff_bits, nrot, done, tol, inner_sweeps, nb,
                                                                                                               step, kb, v3, nullptr);

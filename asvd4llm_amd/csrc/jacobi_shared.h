@@ -9,6 +9,7 @@ namespace asvdk {
 
 constexpr int PB = 32;       // panel width
 constexpr int PW = 2 * PB;   // pair width
+constexpr int EVD_PHASE_PAIRS = PW / 2;   // (A, B) phase pairs of one inner sweep of the 64x64 eigen-solve: one full odd-even cycle, every column pair meets once
 
 // Pair ordering of one Jacobi sweep: nb (even) panels, nb-1 steps, pair k in [0, nb/2) of step `step`.
 //  * default: XOR ordering over the panel count padded to a power of two P — step d = step+1 (d = 1..P-1) pairs every panel i
@@ -20,12 +21,10 @@ constexpr int PW = 2 * PB;   // pair width
 // kept these in __constant__ symbols rewritten by every call, so two concurrent calls with different shapes (a grouped 13B schedule next
 // to an XOR one) overwrote each other's tables mid-flight.
 //   pair_order  1 XOR (default), 0 round-robin (ASVD_ORDER=rr)
-//   super_order 1 XOR, 0 round-robin tournament, 2 grouped (below);  gm / gpair: group pairs per round / {gA, gB} of the grouped schedule
-//   evd_pairs   phase pairs per inner sweep of the 64x64 eigen-solve: 32 = one full odd-even cycle (ASVD_EVD_PAIRS, experiments)
-//   fence       agent-scope acquire / release at kernel boundaries (stream groups, common.h)
+//   super_order 1 XOR, 2 grouped (below);  gm / gpair: group pairs per round / {gA, gB} of the grouped schedule
 struct Sched {
-    int pair_order, super_order, evd_pairs, fence, gm;
-    int dbg_fill;   // experiments on the LDS solver (tools/repro_lds_fill.py): bit r = pre-fill LDS region r with NaN at kernel entry
+    int pair_order, super_order, gm;
+    int meas;       // measurement builds only (-DASVD_SG_TIMING, tools/bench_supgram.py): timing-only ablation bits of the fused kernel; 0 in the product
     signed char gpair[8][4][2];
 };
 static Sched default_sched() {
@@ -33,7 +32,6 @@ static Sched default_sched() {
     std::memset(&sc, 0, sizeof(sc));
     sc.pair_order = 1;
     sc.super_order = 1;
-    sc.evd_pairs = 32;
     return sc;
 }
 
@@ -52,14 +50,15 @@ static __device__ __forceinline__ void rr_pair(const Sched& sc, int nb, int step
     J = a < b ? b : a;
 }
 
-// Pair ordering at the SUPER-PANEL level of the two-level sweeps (twolevel.h): XOR like the panel level when the super-panel count is a
-// power of two; otherwise (c_super_order = 0) the round-robin tournament over ns (+1 if odd) super-panels — a padded XOR schedule runs
-// P-1 super-steps with many empty slots (13B: 80 super-panels -> 127 steps, 37 % empty), the tournament ns-1 full ones.  Pairs with
-// T >= ns (padding / the bye) are skipped by the callers.  `step` counts from 0.
-// c_super_order = 2: GROUPED schedule for counts that are a multiple of 16 but not a power of two: XOR (d = 1..15) inside groups of 16
-// super-panels, then the group pairs of a round-robin tournament over the groups, each for the 16 offsets s (A_i <-> B_{i ^ s}): the
-// nearest-neighbour-first order of the XOR schedule inside a group and inside a group pair, and 15 + rounds * 16 super-steps with
-// (almost) every slot filled instead of a padded XOR schedule.  sc.gpair[round][m] = {gA, gB} (gA < gB), sc.gm = pairs per round.
+// Pair ordering at the SUPER-PANEL level of the two-level sweeps (twolevel.h).  `step` counts from 0; pairs with T >= ns (padding) are skipped
+// by the callers.
+//   super_order 1: XOR like the panel level, over the super-panel count padded to a power of two.  A padded schedule runs P-1 super-steps
+//     with many empty slots (13B: 80 super-panels -> 127 steps, 37 % empty).
+//   super_order 2: GROUPED schedule for counts that are a multiple of 16 but not a power of two: XOR (d = 1..15) inside groups of 16
+//     super-panels, then the group pairs of a round-robin tournament over the groups, each for the 16 offsets s (A_i <-> B_{i ^ s}): the
+//     nearest-neighbour-first order of the XOR schedule inside a group and inside a group pair, and 15 + rounds * 16 super-steps with
+//     (almost) every slot filled.  sc.gpair[round][m] = {gA, gB} (gA < gB), sc.gm = pairs per round.  (A plain round-robin tournament over
+//     the super-panels — ns-1 full steps — was measured in round 2: sweeps 7-9 -> 8-12, the nearest-neighbour-first order is worth more.)
 static __device__ __forceinline__ void super_pair(const Sched& sc, int ns, int step, int k, int& S, int& T) {
     if (sc.super_order == 1) {
         const int d = step + 1;
@@ -82,13 +81,7 @@ static __device__ __forceinline__ void super_pair(const Sched& sc, int ns, int s
         T = 16 * sc.gpair[r][m][1] + (i ^ sft);
         return;
     }
-    const int n = ns + (ns & 1);  // even player count; player n-1 is the bye when ns is odd
-    if (k >= n / 2) { S = ns; T = ns; return; }
-    const int a = (k == 0) ? 0 : 1 + (k - 1 + step) % (n - 1);
-    const int pb = n - 1 - k;
-    const int b = 1 + (pb - 1 + step) % (n - 1);
-    S = a < b ? a : b;
-    T = a < b ? b : a;
+    S = ns; T = ns;   // no other order exists
 }
 
 // Pair handled by a workgroup: from the schedule (plist == nullptr) or, in sparse sweeps, from an explicit per-problem list of
@@ -137,6 +130,9 @@ struct EvdV3 {
     float* D0;            // [slot][4][32*32]
     float* Qfin;          // [slot][128*128]
     int* subact;          // [slot][4]: step 0 sub-pairs 0,1; step 1 sub-pairs 0,1
+    int* hist;            // debug (ASVD_DEBUG_HIST): 10 counters, decade histogram of the pair measures of a sweep; nullptr otherwise
+    float* Din;           // [slot][128]: squared column norms of the super-pair BEFORE its rotation (carried diagonal), in Q order (blocks S0 S1 T0 T1):
+                          //              the power-of-two column scales of the split-fp16 update (twolevel.h, supgram_kernel) come from these
 };
 
 // ---- launchers of the wave-local eigen-solver (evd_wave.hip) -------------------------------------------------------------------

@@ -1,4 +1,4 @@
-// twolevel.h — kernels of the TWO-LEVEL dense sweep (included by svd_jacobi.hip inside its anonymous namespace, after evd_kernel).
+// twolevel.h — kernels of the TWO-LEVEL dense sweep (included by svd_jacobi.hip inside its anonymous namespace).
 //
 // Why: at panel width 32 a sweep moves (nb-1) x 3 panel passes through HBM and sits on the roofline ridge.  The
 // two-level sweep works on SUPER-PANELS of 64 columns (two adjacent 32-column panels, layout unchanged) under the same XOR
@@ -6,15 +6,20 @@
 //   sgram6   ONE pass over the four panels: the four cross tiles [0,2] [0,3] [1,2] [1,3] and the two within tiles [0,1] [2,3]
 //            (fp32 MFMA, row-split partials).  The 32x32 DIAGONAL blocks of the panels are CARRIED: every 64x64 eigen-solve leaves
 //            Q^T G Q behind, whose diagonal blocks are the Gram blocks of the two updated panels; they are refreshed from the data
-//            once per sweep (internal step, below).
-//   evd<1>   inner step 0: sub-pairs (0,2) and (1,3), assembled from the carried blocks and the summed cross tiles
-//   evd<2>   inner step 1: sub-pairs (0,3) and (1,2); their cross blocks are the tile G[{0,2},{1,3}] transformed by the two Q's of
-//            step 0 (two small fp32-MFMA products in the kernel's prologue); the epilogue emits the sub-pair's 128x64 column
-//            block of Qfin = Q^(0) Q^(1) and the new carried diagonal blocks.  No 128x128 Gram matrix is ever formed.
-//   supdate  ONE pass: [X_S X_T] <- [X_S X_T] Qfin   (128x128; split-bf16 or fp32 MFMA, K = 128)
+//            once per sweep (internal step, below).  Runs only in front of the first super-step of a sweep (and wherever the fused
+//            kernel below does not apply): supgram leaves the tiles of the next step behind.
+//   evdw12   (evd_wave.hip) both inner steps of every super-pair in one launch, one wave per 64x64 solve.  Inner step 0: sub-pairs
+//            (0,2) and (1,3), assembled from the carried blocks and the summed cross tiles; inner step 1: sub-pairs (0,3) and (1,2), whose
+//            cross blocks are the tile G[{0,2},{1,3}] transformed by the two Q's of step 0 (two small fp32-MFMA products); the epilogue emits
+//            the sub-pair's 128x64 column block of Qfin = Q^(0) Q^(1), the new carried diagonal blocks, and the squared column norms the
+//            pair had BEFORE its rotation (EvdV3::Din: the column scales of supgram's split-fp16 arithmetic).  No 128x128 Gram matrix is
+//            ever formed.
+//   supgram  ONE pass: [X_S X_T] <- [X_S X_T] Qfin (128x128, split-fp16 on the fp16 matrix pipe) AND the six tiles of the next step's pairs
+//   supdate_split   the update alone (split-bf16): last super-step of a sweep, padded schedules, and the fallback of a call that turned NaN
+//            on the split-fp16 path
 // The pairs INSIDE a super-panel (2S, 2S+1) are the d = 1 step of the single-level schedule: it runs first in every sweep with the
 // single-level kernels (full 3-block Gram from the data) and its eigen-solve emits the fresh carried blocks of both panels.
-// HBM passes per sweep: 3 (nb/2 - 1) + 3 instead of 3 (nb - 1); launches per step: 4; the number of 64x64 eigen-solves is
+// HBM passes per sweep: 2 (nb/2 - 1) + 4 instead of 3 (nb - 1); launches per super-step: 2; the number of 64x64 eigen-solves is
 // unchanged (every 32-panel pair still meets exactly once per sweep).  Each eigen-solve sorts its own 64 columns (larger half to
 // the lower panel); there is no global 128-column sort (CPU prototype tools/proto_two_level.py: same sweep count either way).
 
@@ -46,13 +51,11 @@ __device__ __forceinline__ void split3(float x0, float x1, unsigned& p1, unsigne
 // [0,1] [2,3], tile [x,y] = X_x[rows]^T X_y[rows].  Same streaming structure as gram_kernel (register prefetch of the next 16-row
 // chunk, wave-private LDS image, one ds_read_b32 per MFMA operand); four panels and six accumulators per wave.
 constexpr int SGRAM6_SMEM_FLOATS = 4 * 4 * 16 * PB;  // 32 KiB
-template <int GSPLIT>  // 1: split-bf16 arithmetic (six bf16 products per fp32 product), 0: fp32 MFMA
-__device__ __forceinline__ void sgram6_body(const Sched& sc, const BlockCtx& ctx, float* __restrict__ smem, const float* __restrict__ X, int64_t panel_stride,
-                                            int64_t batch_stride, int ns, int D, int m_pad, int rows_per_split, float* __restrict__ Gx,
-                                            const int* __restrict__ done) {
-    const int split = ctx.bx, pair = ctx.by, b = ctx.bz;
-    const int nsplit = ctx.gx, npairs = ctx.gy;
-    ASVD_KERNEL_ACQUIRE(sc);
+__global__ __launch_bounds__(256, 2) void sgram6_kernel(Sched sc, const float* __restrict__ X, int64_t panel_stride, int64_t batch_stride, int ns, int D,
+                                                        int m_pad, int rows_per_split, float* __restrict__ Gx, const int* __restrict__ done) {
+    __shared__ __attribute__((aligned(16))) float smem[SGRAM6_SMEM_FLOATS];
+    const int split = blockIdx.x, pair = blockIdx.y, b = blockIdx.z;
+    const int nsplit = gridDim.x, npairs = gridDim.y;
     if (ld_flag(done + b)) return;
     int S, T;
     super_pair(sc, ns, D - 1, pair, S, T);
@@ -94,34 +97,7 @@ __device__ __forceinline__ void sgram6_body(const Sched& sc, const BlockCtx& ctx
                 *(f32x4*)(s + 3 * (SCH * PB) + it * 256 + lane * 4) = p3[it];
             }
             if (ch + 4 < nchunks) fetch(ch + 4);
-            if constexpr (GSPLIT) {
-                // split-bf16: the 16 rows of the chunk are ONE k-step of v_mfma_f32_32x32x16_bf16; lane (column c, group h) holds rows
-                // 8 h + e, e = 0..7, of its column, each fp32 value as three bf16 (exact), six products per fp32 product
-                const int hh = lane >> 5, cc = lane & 31;
-                bf16x8 o1[4], o2[4], o3[4];
-#pragma unroll
-                for (int pnl = 0; pnl < 4; ++pnl) {
-                    const float* sp = s + pnl * (SCH * PB) + (8 * hh) * PB + cc;
-                    u32x4 p1, p2, p3;
-#pragma unroll
-                    for (int e2 = 0; e2 < 4; ++e2) {
-                        unsigned x, y, z;
-                        split3(sp[(2 * e2) * PB], sp[(2 * e2 + 1) * PB], x, y, z);
-                        p1[e2] = x; p2[e2] = y; p3[e2] = z;
-                    }
-                    o1[pnl] = __builtin_bit_cast(bf16x8, p1); o2[pnl] = __builtin_bit_cast(bf16x8, p2); o3[pnl] = __builtin_bit_cast(bf16x8, p3);
-                }
-                auto mm = [&](int a, int b, f32x16 acc) {
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o3[a], o1[b], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o1[a], o3[b], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o2[a], o2[b], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o2[a], o1[b], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o1[a], o2[b], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o1[a], o1[b], acc, 0, 0, 0);
-                    return acc;
-                };
-                a02 = mm(0, 2, a02); a03 = mm(0, 3, a03); a12 = mm(1, 2, a12); a13 = mm(1, 3, a13); a01 = mm(0, 1, a01); a23 = mm(2, 3, a23);
-            } else {
+            // fp32 MFMA (the split-bf16 form was measured in round 2: this pass is latency / HBM-, not matrix-pipe-bound, and it runs once per sweep)
 #pragma unroll
             for (int u = 0; u < SCH / 2; ++u) {
                 const float x0 = s[0 * (SCH * PB) + u * 64 + lane], x1 = s[1 * (SCH * PB) + u * 64 + lane];
@@ -132,7 +108,6 @@ __device__ __forceinline__ void sgram6_body(const Sched& sc, const BlockCtx& ctx
                 a13 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, y1, a13, 0, 0, 0);
                 a01 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, x1, a01, 0, 0, 0);
                 a23 = __builtin_amdgcn_mfma_f32_32x32x2f32(y0, y1, a23, 0, 0, 0);
-            }
             }
         }
     }
@@ -159,91 +134,9 @@ __device__ __forceinline__ void sgram6_body(const Sched& sc, const BlockCtx& ctx
             out[tile * 1024 + i * 32 + j] = v;
         }
     }
-    ASVD_KERNEL_RELEASE(sc);
 }
 
-template <int GSPLIT>
-__global__ __launch_bounds__(256, 2) void sgram6_kernel(Sched sc, const float* __restrict__ X, int64_t panel_stride, int64_t batch_stride, int ns, int D,
-                                                        int m_pad, int rows_per_split, float* __restrict__ Gx, const int* __restrict__ done) {
-    __shared__ __attribute__((aligned(16))) float smem[SGRAM6_SMEM_FLOATS];
-    const BlockCtx ctx{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, (int)gridDim.y, (int)gridDim.z};
-    sgram6_body<GSPLIT>(sc, ctx, smem, X, panel_stride, batch_stride, ns, D, m_pad, rows_per_split, Gx, done);
-}
-
-// --------------------------------------------------------------------------------------------------
-// supdate: [X_S X_T] <- [X_S X_T] * Qfin over the rows of this chunk.  The 32 x 128 tile is shared by the four waves through a
-// double-buffered padded LDS image (next tile prefetched into registers while the current one is in the matrix pipe, one barrier
-// per tile); wave w owns output panel w: its 128 x 32 slice of Qfin sits in 64 VGPRs, 64 MFMAs per tile.
 constexpr int ULD = SP + 4;  // LDS row stride in floats (528 B: conflict-free b128 row-per-lane reads)
-__global__ __launch_bounds__(256, 2) void supdate_kernel(Sched sc, float* __restrict__ X, int64_t panel_stride, int64_t batch_stride, int ns, int D,
-                                                         int R, int rows_per_wg, const float* __restrict__ Qfin,
-                                                         const int* __restrict__ subact, const int* __restrict__ done, int* __restrict__ nupd) {
-    const int chunk = blockIdx.x, pair = blockIdx.y, b = blockIdx.z, npairs = gridDim.y;
-    ASVD_KERNEL_ACQUIRE(sc);
-    if (ld_flag(done + b) || !pair_active(subact, (int64_t)b * npairs + pair)) return;
-    int S, T;
-    super_pair(sc, ns, D - 1, pair, S, T);
-    if (T >= ns) return;
-    if (chunk == 0 && threadIdx.x == 0) atomicAdd(&nupd[b], 1);  // instrumentation: super-pairs updated in this sweep
-    float* __restrict__ Xb = X + (int64_t)b * batch_stride;
-    float* __restrict__ P0 = Xb + (int64_t)(2 * S) * panel_stride;
-    float* __restrict__ P1 = Xb + (int64_t)(2 * S + 1) * panel_stride;
-    float* __restrict__ P2 = Xb + (int64_t)(2 * T) * panel_stride;
-    float* __restrict__ P3 = Xb + (int64_t)(2 * T + 1) * panel_stride;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, c = lane & 31;
-    const float* __restrict__ Qp = Qfin + ((int64_t)b * npairs + pair) * (SP * SP);
-    float q[64];
-#pragma unroll
-    for (int t = 0; t < 64; ++t) q[t] = Qp[(h * 64 + t) * SP + 32 * w + c];
-    float* __restrict__ Pw = (w == 0) ? P0 : (w == 1) ? P1 : (w == 2) ? P2 : P3;
-
-    __shared__ __attribute__((aligned(16))) float tile[2][32 * ULD];
-    const int r_begin = chunk * rows_per_wg;
-    const int r_end = min(r_begin + rows_per_wg, R);
-    if (r_begin >= r_end) return;
-    f32x4 pre0, pre1, pre2, pre3;
-    auto fetch = [&](int r0) {
-        const int64_t o = (int64_t)r0 * PB + tid * 4;
-        pre0 = *(const f32x4*)(P0 + o);
-        pre1 = *(const f32x4*)(P1 + o);
-        pre2 = *(const f32x4*)(P2 + o);
-        pre3 = *(const f32x4*)(P3 + o);
-    };
-    auto stash = [&](float* t) {
-        float* dst = t + (tid >> 3) * ULD + (tid & 7) * 4;
-        *(f32x4*)(dst + 0) = pre0;
-        *(f32x4*)(dst + 32) = pre1;
-        *(f32x4*)(dst + 64) = pre2;
-        *(f32x4*)(dst + 96) = pre3;
-    };
-    int cur = 0;
-    fetch(r_begin);
-    stash(tile[0]);
-    __syncthreads();
-    for (int r0 = r_begin; r0 < r_end; r0 += 32) {  // R and rows_per_wg are multiples of 32
-        const bool more = r0 + 32 < r_end;
-        if (more) fetch(r0 + 32);
-        const float* my = tile[cur] + c * ULD + h * 64;
-        f32x16 acc = {0};
-#pragma unroll
-        for (int t4 = 0; t4 < 16; ++t4) {
-            const f32x4 v = *(const f32x4*)(my + t4 * 4);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v[0], q[4 * t4 + 0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v[1], q[4 * t4 + 1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v[2], q[4 * t4 + 2], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v[3], q[4 * t4 + 3], acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int i = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-            Pw[(int64_t)(r0 + i) * PB + c] = acc[reg];
-        }
-        if (more) stash(tile[cur ^ 1]);
-        __syncthreads();
-        cur ^= 1;
-    }
-    ASVD_KERNEL_RELEASE(sc);
-}
 
 // --------------------------------------------------------------------------------------------------
 // supdate with split-bf16 arithmetic.  Every fp32 value is written EXACTLY as the sum of three bf16 numbers (truncation split:
@@ -253,11 +146,11 @@ __global__ __launch_bounds__(256, 2) void supdate_kernel(Sched sc, float* __rest
 // v_mfma_f32_32x32x2_f32 (64 cycles each): 2.7x less matrix-pipe time for the kernel that holds 4/5 of the sweep's flops.
 // Bitwise it is not the fp32 MFMA result (different summation tree), numerically it is equivalent (tests compare both with fp64).
 constexpr int SUPDATE_SMEM_FLOATS = 2 * 32 * ULD;  // 33 KiB
-__device__ __forceinline__ void supdate_split_body(const Sched& sc, const BlockCtx& ctx, float* __restrict__ smem, float* __restrict__ X, int64_t panel_stride,
-                                                   int64_t batch_stride, int ns, int D, int R, int rows_per_wg, const float* __restrict__ Qfin,
-                                                   const int* __restrict__ subact, const int* __restrict__ done, int* __restrict__ nupd) {
-    const int chunk = ctx.bx, pair = ctx.by, b = ctx.bz, npairs = ctx.gy;
-    ASVD_KERNEL_ACQUIRE(sc);
+__global__ __launch_bounds__(256, 2) void supdate_split_kernel(Sched sc, float* __restrict__ X, int64_t panel_stride, int64_t batch_stride, int ns,
+                                                               int D, int R, int rows_per_wg, const float* __restrict__ Qfin,
+                                                               const int* __restrict__ subact, const int* __restrict__ done, int* __restrict__ nupd) {
+    __shared__ __attribute__((aligned(16))) float smem[SUPDATE_SMEM_FLOATS];
+    const int chunk = blockIdx.x, pair = blockIdx.y, b = blockIdx.z, npairs = gridDim.y;
     if (ld_flag(done + b) || !pair_active(subact, (int64_t)b * npairs + pair)) return;
     int S, T;
     super_pair(sc, ns, D - 1, pair, S, T);
@@ -344,66 +237,96 @@ __device__ __forceinline__ void supdate_split_body(const Sched& sc, const BlockC
         __syncthreads();
         cur ^= 1;
     }
-    ASVD_KERNEL_RELEASE(sc);
-}
-
-__global__ __launch_bounds__(256, 2) void supdate_split_kernel(Sched sc, float* __restrict__ X, int64_t panel_stride, int64_t batch_stride, int ns,
-                                                               int D, int R, int rows_per_wg, const float* __restrict__ Qfin,
-                                                               const int* __restrict__ subact, const int* __restrict__ done, int* __restrict__ nupd) {
-    __shared__ __attribute__((aligned(16))) float smem[SUPDATE_SMEM_FLOATS];
-    const BlockCtx ctx{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, (int)gridDim.y, (int)gridDim.z};
-    supdate_split_body(sc, ctx, smem, X, panel_stride, batch_stride, ns, D, R, rows_per_wg, Qfin, subact, done, nupd);
 }
 
 // --------------------------------------------------------------------------------------------------
 // supgram: the update of super-step D fused with the Gram tiles of super-step E (the step that follows).  Under the XOR ordering the
 // four super-panels {a, a^D, a^E, a^D^E} (a QUAD) are closed under both steps: the pairs (a, a^D) and (a^E, a^D^E) rotate now, the
 // pairs (a, a^E) and (a^D, a^D^E) meet next.  One workgroup of EIGHT waves streams a row chunk of a quad ONCE, in 32-row tiles; wave w
-// owns output panel w (waves 0-3: first pair, 4-7: second pair; its 128x32 slice of Qfin sits pre-split in 96 VGPRs), writes it back,
-// and leaves it — already split into three bf16 parts, in MFMA operand order — in LDS.  The C layout of the update (lane = column,
-// registers = rows) IS the A/B operand layout of the Gram product over rows (the reduction index may be permuted freely as long as both
-// operands agree), so the twelve 32x32 tiles of the two next pairs are accumulated from those images without any transpose: 24
-// half-tiles (tile x 16-row k-step), three per wave, held in registers over the whole chunk.
-// HBM traffic of a super-step: one read + one write instead of read + (read + write); MFMA work per tile and wave: 48 (update) + 18
-// (Gram) v_mfma_f32_32x32x16_bf16.  Super-panels beyond ns (power-of-two padding of the schedule) read as absent: no loads, no stores.
+// owns output panel w (waves 0-3: first pair, 4-7: second pair; its 128x32 slice of Qfin sits pre-split in 64 VGPRs), writes it back,
+// and leaves it — already split, in MFMA operand order — in LDS.  The C layout of the update (lane = column, registers = rows) IS the
+// A/B operand layout of the Gram product over rows (the reduction index may be permuted freely as long as both operands agree), so the
+// twelve 32x32 tiles of the two next pairs are accumulated from those images without any transpose: 24 half-tiles (tile x 16-row
+// k-step), three per wave, held in registers over the whole chunk.  HBM traffic of a super-step: one read + one write instead of
+// read + (read + write).  Super-panels beyond ns (power-of-two padding of the schedule) read as absent: no loads, no stores.
 //
 // PING-PONG SCHEDULE (round 4).  Rounds 2-3 ran all eight waves through the same phases between two barriers per tile — fetch / split /
-// LDS stores, then 66 matrix instructions, then panel stores — so the matrix pipe, the VALU and the memory pipe took turns: the kernel
-// ran at the SUM of its HBM time and its MFMA time (48 % MFMA-busy, 0.44 of the HBM spec).  The two waves of a SIMD are w and w + 4, i.e.
-// one wave of each pair.  Now the pairs run HALF A TILE APART: between two barriers the waves of one pair are in their COMPUTE segment
-// (Gram MFMAs of an earlier tile + the 48 update MFMAs of this one, operands from LDS) while the waves of the other pair are in their
-// MEMORY segment (panel stores of the tile just computed, split of its accumulators into Gram operands, split + LDS stores of the next
-// incoming tile, global loads of the tile after that), then they swap.  Every SIMD therefore holds one wave that feeds the matrix pipe
-// and one that feeds VALU / LDS / HBM at any time.  What makes it fit: every pair stages only ITS OWN 32 x 128 incoming tile — written
-// in its memory segment, read in its compute segment — so the incoming image needs no double buffer (54 KiB instead of 108); the Gram
-// operand image is double buffered instead (2 x 48 KiB), because the tiles of the next step need the updated panels of BOTH pairs and
-// pair B's lag half a tile behind: pair A accumulates the Gram units of tile t - 2 next to the update of tile t, pair B those of tile
-// t - 1 (timeline in segments: A computes tile t in segment 2t and publishes its operands in 2t + 1, B computes in 2t + 1 and publishes
-// in 2t + 2; the operand buffer (t & 1) is complete after segment 2t + 2, read in 2t + 3 (B) and 2t + 4 (A), and rewritten from 2t + 5).
-// Two barriers per tile as before; global loads and stores stay in flight across them (s_barrier waits for lgkmcnt only).
+// LDS stores, then the matrix instructions, then panel stores — so the matrix pipe, the VALU and the memory pipe took turns: the kernel
+// ran at the SUM of its HBM time and its MFMA time.  The two waves of a SIMD are w and w + 4, i.e. one wave of each pair.  Now the pairs
+// run HALF A TILE APART: between two barriers the waves of one pair are in their COMPUTE segment (Gram MFMAs of an earlier tile + the
+// update MFMAs of this one, operands from LDS) while the waves of the other pair are in their MEMORY segment (split + LDS stores of the
+// next incoming tile, global loads of the tile after that, panel stores of the tile just computed, its accumulators as Gram operands),
+// then they swap: every SIMD holds one wave that feeds the matrix pipe and one that feeds VALU / LDS / HBM at any time.  Every pair
+// stages only ITS OWN 32 x 128 incoming tile — written in its memory segment, read in its compute segment — so the incoming image needs
+// no double buffer; the Gram operand image is double buffered instead, because the tiles of the next step need the updated panels of
+// BOTH pairs and pair B's lag half a tile behind: pair A accumulates the Gram units of tile t - 2 next to the update of tile t, pair B
+// those of tile t - 1 (timeline in segments: A computes tile t in segment 2t and publishes its operands in 2t + 1, B computes in 2t + 1
+// and publishes in 2t + 2; the operand buffer (t & 1) is complete after segment 2t + 2, read in 2t + 3 (B) and 2t + 4 (A), and rewritten
+// from 2t + 5).  Two barriers per tile; global loads and stores stay in flight across them (s_barrier waits for lgkmcnt only).
+//
+// SPLIT-FP16 ARITHMETIC WITH POWER-OF-TWO COLUMN SCALES (round 4).  Telemetry (tools/power_probe.py) shows this kernel pinned at the
+// 1400 W socket cap at 1.65 GHz with the matrix pipe half busy: its time is its ENERGY, and two thirds of that are the matrix
+// instructions.  Rounds 2-3 wrote every fp32 value as three bf16 numbers (8 + 8 + 8 bits) and every fp32 product as six bf16 products.
+// fp16 carries 11 bits: x = h1 + h2 to 22 bits and x q = h1 q1 + h1 q2 + h2 q1 to 2^-22 — THREE products, half the matrix work and two
+// thirds of the LDS traffic — but only where both parts stay inside fp16's range, 2^-24 .. 65504, which an unscaled column of a graded
+// matrix does not (the round-3 trial without scales stalled at 1e-3 orthogonality).  So every column is used at a power-of-two scale
+// (exact):   X Q = (X 2^-ein) (2^ein Q 2^-eout) 2^eout,
+//   ein[k]   from the column's squared norm before the rotation (v3.Din, written by the eigen-solve launch of this step): the scaled
+//            column has norm <= 2^9, so its entries are <= 2^9 and the accumulators stay below 2^12.5 — inside fp16 when they become the
+//            Gram operands, with 3 bits to spare if the carried norm is off; columns more than 2^20 below the largest column of their pair
+//            share its floor (noise columns of rank-deficient inputs: their carried norms mean nothing);
+//   eout[j]  from the largest TERM of output column j, max_k |Q[k][j]| 2^ein[k] (not from its norm: a column that cancels down to noise
+//            has terms far above its norm, and fp32 itself resolves it only relative to those terms): the scaled Q has entries <= 1.
+// Measured against fp64 (tools/emu, tests/test_gpu_twolevel.py): 3.0e-7 per column against 2.2e-7 for a plain fp32 product and 1.1e-7
+// for the six-product bf16 form.  The Gram tiles come out at the scale 2^(eout[i] + eout[j]) and are rescaled when they are stored.
+// A pair at rest (or one with an absent member) goes through the same arithmetic with Q = I and is not written back.
+// If a call ever produces a NaN through this path (a carried norm that is wrong by more than 2^7), the driver repeats it with the
+// separate passes (sgram6 in fp32, supdate_split in split-bf16), which need no scales.
 //
 // The incoming tile is split ONCE, by the thread that fetched it, and stored as the A operands of the update: image [pair][k-step][part]
-// [lane] of 16-byte operands.  A 32-lane half block is padded to 36 operands (one (k-step, part) block = 72): the stash writes of a
-// quarter wave — four rows x four (k-step, lane group) targets — then fall on distinct banks; the reads are lane-contiguous either way.
-constexpr int SG_HB = 36, SG_BLK = 2 * SG_HB;
-constexpr int SUPGRAM_AIMG_WORDS = 2 * 8 * 3 * SG_BLK * 4;         // one 32-row image of the eight panels, as bf16x3 A operands (54 KiB)
-constexpr int SUPGRAM_OPND_WORDS = 8 * 2 * 3 * 64 * 4;             // updated panels as Gram operands [panel][k-step][part][lane] x 16 B (48 KiB)
-constexpr int SUPGRAM_SMEM_FLOATS = SUPGRAM_AIMG_WORDS + 2 * SUPGRAM_OPND_WORDS;  // 153,600 B of the CU's 160 KiB
-static_assert(SUPGRAM_SMEM_FLOATS >= 24 * 1024, "the final reduction reuses the whole buffer");
+// [lane] of 16-byte operands.  A 32-lane half block is padded to 36 operands and a (k-step, part) block to 73: the stash writes of an
+// 8-lane group — two rows x four (k-step, lane group) targets — then fall on eight distinct 16-byte bank groups.
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+constexpr int SG_HB = 36, SG_BLK = 73;
+constexpr int SUPGRAM_AIMG_WORDS = 2 * 8 * 2 * SG_BLK * 4;         // one 32-row image of the eight panels, as fp16 x 2 A operands (36.5 KiB)
+constexpr int SUPGRAM_OPND_WORDS = 8 * 2 * 2 * 64 * 4;             // updated panels as Gram operands [panel][k-step][part][lane] x 16 B (32 KiB)
+constexpr int SUPGRAM_RED_FLOATS = 24 * 1024;                      // the final reduction reuses the front of the buffer
+constexpr int SUPGRAM_MAIN_FLOATS = SUPGRAM_AIMG_WORDS + 2 * SUPGRAM_OPND_WORDS > SUPGRAM_RED_FLOATS ? SUPGRAM_AIMG_WORDS + 2 * SUPGRAM_OPND_WORDS : SUPGRAM_RED_FLOATS;
+constexpr int SUPGRAM_SMEM_FLOATS = SUPGRAM_MAIN_FLOATS + 256;  // + exponent table: 103,936 B
+constexpr int SG_TARGET = 9;    // scaled columns have norm <= 2^SG_TARGET
+constexpr int SG_SPAN = 20;     // columns more than 2^SG_SPAN below the largest of their pair share its floor
 
-#ifdef ASVD_SG_TIMING   // tools/bench_supgram.py --timing: s_memtime stamps of one wave per pair of workgroup (0, 0, 0), 64 tiles x 6 stamps
-__device__ unsigned long long g_sg_ts[2][64][10];
-#define SG_TS(i) do { __builtin_amdgcn_sched_barrier(0); if (sg_ts_on && t < 64) g_sg_ts[mypr][t][i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+// exponent e with sqrt(d) <= 2^e (d a squared norm); d <= 0, denormal or NaN -> very small
+__device__ __forceinline__ int sg_half_exp(float d) {
+    const int bits = __float_as_int(d);
+    const int ex = (bits >> 23) & 255;
+    if (bits <= 0 || ex == 0 || ex == 255) return -200;
+    return (ex - 126 + 1) >> 1;   // d = f 2^p, f in [0.5, 1), p = ex - 126: ceil(p / 2)
+}
+// two fp32 -> (h1, h2) with x ~ h1 + h2 (22 bits)
+__device__ __forceinline__ void split2(float x0, float x1, unsigned& p1, unsigned& p2) {
+    const h16x2 a = {(_Float16)x0, (_Float16)x1};
+    const h16x2 r = {(_Float16)(x0 - (float)a[0]), (_Float16)(x1 - (float)a[1])};
+    p1 = __builtin_bit_cast(unsigned, a);
+    p2 = __builtin_bit_cast(unsigned, r);
+}
+
+#ifdef ASVD_SG_TIMING   // tools/bench_supgram.py --timing: shader cycles per stage of the tile loop, summed in scalar registers (no memory traffic in
+                        // the loop), one wave per pair of workgroup (0, 0, 0); stage k = from stamp k - 1 to stamp k in program order
+__device__ unsigned long long g_sg_ts[2][10];
+#define SG_TS(i) do { __builtin_amdgcn_sched_barrier(0); { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); sg_acc[i] += now_ - sg_last; sg_last = now_; } __builtin_amdgcn_sched_barrier(0); } while (0)
+#define SG_ABL(bit) (sc.meas & (bit))   // timing-only ablations (results wrong): 1 no panel stores, 2 no fetch, 4 no matrix instructions, 8 no LDS operand stores
 #else
 #define SG_TS(i) do { } while (0)
+#define SG_ABL(bit) 0
 #endif
 __global__ __launch_bounds__(512, 1) void supgram_kernel(Sched sc, float* __restrict__ X, int64_t panel_stride, int64_t batch_stride, int ns, int D,
                                                          int E, int R, int m_pad, int rows_per_wg, const float* __restrict__ Qfin,
-                                                         const int* __restrict__ subact, float* __restrict__ Gx, const int* __restrict__ done,
-                                                         int* __restrict__ nupd, int npairs) {
+                                                         const int* __restrict__ subact, const float* __restrict__ Din, float* __restrict__ Gx,
+                                                         const int* __restrict__ done, int* __restrict__ nupd, int npairs) {
     extern __shared__ __attribute__((aligned(16))) float sg_smem[];
     const int chunk = blockIdx.x, quad = blockIdx.y, b = blockIdx.z, nsplit = gridDim.x;
-    ASVD_KERNEL_ACQUIRE(sc);
     if (ld_flag(done + b)) return;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5, c = lane & 31;
     // ---- quad geometry (uniform) ----
@@ -455,22 +378,52 @@ __global__ __launch_bounds__(512, 1) void supgram_kernel(Sched sc, float* __rest
     const int otp = 2 * oslot + (ob & 1);
     const bool mine = mypr ? act1 : act0;
     float* __restrict__ Pw = Xb + (int64_t)(2 * min(Pof(oslot), ns - 1) + (ob & 1)) * panel_stride;
-    // B operand of k-step s: lane (j = c, group h) holds Q[16 s + 8 h + e][32 ob + c], e = 0..7, in three bf16 parts
-    // A pair at rest (or one with an absent member) goes through the same arithmetic with Q = I — exact in split-bf16 — and is not
-    // written back: its panels still feed the tiles of the next step.
-    u32x4 q1[8], q2[8], q3[8];
+
+    // ---- column scales of this wave's pair ----
+    // din[k], k in Q order (S0 S1 T0 T1); a member beyond ns holds nothing: its columns get the floor of the pair
+    const float* __restrict__ dinp = Din + ((int64_t)b * npairs + (mypr ? kcur1 : kcur0)) * 128;
+    const bool presS = Pof(mS) < ns, presT = Pof(mT) < ns;
+    auto ein_raw = [&](int k) { return ((k < 64) ? presS : presT) ? sg_half_exp(dinp[k]) : -200; };
+    int emax;
+    {
+        int e0 = max(ein_raw(lane), ein_raw(64 + lane));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) e0 = max(e0, __shfl_xor(e0, o, 64));
+        emax = e0 < -150 ? SG_TARGET : e0;   // nothing usable in the whole pair (all-zero columns): any scale does
+    }
+    auto ein_of = [&](int k) { return max(ein_raw(k), emax - SG_SPAN) - SG_TARGET; };
+
+    // B operand of k-step s: lane (j = c, group h) holds Qs[16 s + 8 h + e][32 ob + c], e = 0..7, Qs = 2^ein Q 2^-eout, in two fp16 parts
+    u32x4 q1[8], q2[8];
+    float oscale;   // 2^eout of this lane's output column
+    int eout;
     {
         const float* __restrict__ Qp = Qfin + ((int64_t)b * npairs + (mypr ? kcur1 : kcur0)) * (SP * SP);
+        float v[8][8];
+        float tmax = 0.0f;
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            float v[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = mine ? Qp[(16 * s + 8 * h + e) * SP + 32 * ob + c] : ((16 * s + 8 * h + e == 32 * ob + c) ? 1.0f : 0.0f);
+            for (int e = 0; e < 8; ++e) {
+                const int k = 16 * s + 8 * h + e;
+                const float qv = mine ? Qp[k * SP + 32 * ob + c] : ((k == 32 * ob + c) ? 1.0f : 0.0f);
+                v[s][e] = ldexpf(qv, ein_of(k));
+                tmax = fmaxf(tmax, fabsf(v[s][e]));
+            }
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));   // the other half of the k range sits in lane c of the other half-wave
+        {
+            const int bits = __float_as_int(tmax), ex = (bits >> 23) & 255;
+            eout = (tmax > 0.0f && ex != 0 && ex != 255) ? ex - 126 : 0;   // tmax = f 2^eout, f in [0.5, 1); NaN / Inf / 0: leave as is (NaN propagates)
+        }
+        oscale = ldexpf(1.0f, eout);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
 #pragma unroll
             for (int e2 = 0; e2 < 4; ++e2) {
-                unsigned x, y, z;
-                split3(v[2 * e2], v[2 * e2 + 1], x, y, z);
-                q1[s][e2] = x; q2[s][e2] = y; q3[s][e2] = z;
+                unsigned x, y;
+                split2(ldexpf(v[s][2 * e2], -eout), ldexpf(v[s][2 * e2 + 1], -eout), x, y);
+                q1[s][e2] = x; q2[s][e2] = y;
             }
         }
     }
@@ -478,11 +431,13 @@ __global__ __launch_bounds__(512, 1) void supgram_kernel(Sched sc, float* __rest
     u32x4* aimg = (u32x4*)sg_smem;
     u32x4* opnd0 = (u32x4*)(sg_smem + SUPGRAM_AIMG_WORDS);
     constexpr int OPND_VECS = SUPGRAM_OPND_WORDS / 4;  // 16-byte operands per buffer
+    int* egtab = (int*)(sg_smem + SUPGRAM_MAIN_FLOATS);   // eout of the 8 x 32 output columns (the scale of the Gram operands)
+    if (!h) egtab[otp * 32 + c] = eout;
 
     // ---- this wave's three Gram half-tiles: unit u = w + 8 j -> tile u >> 1 (0..5 pair C, 6..11 pair D'), k-step u & 1 ----
     // sgram6 tile order [0,2] [0,3] [1,2] [1,3] [0,1] [2,3] over the pair's panels (0,1 = lower super-panel, 2,3 = upper)
-    auto unit = [&](int j, int& pa, int& pb, bool& on) {
-        const int u = w + 8 * j, tt = u >> 1, np = tt >= 6 ? 1 : 0, t6 = tt - 6 * np;
+    auto tile_panels = [&](int tt, int& pa, int& pb, bool& on) {
+        const int np = tt >= 6 ? 1 : 0, t6 = tt - 6 * np;
         const int xa = t6 < 2 ? 0 : (t6 < 4 ? 1 : (t6 == 4 ? 0 : 2));
         const int xb = t6 == 0 ? 2 : (t6 == 1 ? 3 : (t6 == 2 ? 2 : (t6 == 3 ? 3 : (t6 == 4 ? 1 : 3))));
         const int sS = np ? nxtS1 : 0, sT = np ? nxtT1 : 2;
@@ -492,9 +447,9 @@ __global__ __launch_bounds__(512, 1) void supgram_kernel(Sched sc, float* __rest
     };
     int ga0, gb0, ga1, gb1, ga2, gb2;
     bool gon0, gon1, gon2;
-    unit(0, ga0, gb0, gon0);
-    unit(1, ga1, gb1, gon1);
-    unit(2, ga2, gb2, gon2);
+    tile_panels((w + 0) >> 1, ga0, gb0, gon0);
+    tile_panels((w + 8) >> 1, ga1, gb1, gon1);
+    tile_panels((w + 16) >> 1, ga2, gb2, gon2);
     const int kh = w & 1;
     f32x16 g0 = {0}, g1 = {0}, g2 = {0};
 
@@ -505,18 +460,21 @@ __global__ __launch_bounds__(512, 1) void supgram_kernel(Sched sc, float* __rest
         // a thread fetches two 8-column pieces (32 B) of ITS PAIR's 32 x 128 tile: piece q = (tid & 255) + 256 jj -> panel q >> 7 of the pair in Q
         // order (0, 1: lower super-panel S, 2, 3: upper super-panel T), row (q & 127) >> 2, columns 8 (q & 3) .. +7; as an A operand that is
         // k-step / lane group (k >> 4, (k >> 3) & 1), k = 32 (q >> 7) + 8 (q & 3) its column in Q order
-        f32x4 pre[2][2];
+        f32x4 preA[2][2];   // one tile in flight per pair and thread (two in flight — 64 KB of loads per CU — measured slower: 1008 vs 895 us per launch)
+        float mul[2][8];   // 2^-ein of the piece's eight columns
         int dst[2];
         const float* src[2];
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
             const int q = (tid & 255) + 256 * jj, lp = q >> 7, row = (q & 127) >> 2;
             const int k = 32 * lp + 8 * (q & 3);
-            dst[jj] = ((mypr * 8 + (k >> 4)) * 3) * SG_BLK + ((k >> 3) & 1) * SG_HB + row;
+            dst[jj] = ((mypr * 8 + (k >> 4)) * 2) * SG_BLK + ((k >> 3) & 1) * SG_HB + row;
             const int sp = Pof(jj ? mT : mS);   // jj = 0: pieces of S (lp = 0, 1), jj = 1: pieces of T (lp = 2, 3)
             src[jj] = sp < ns ? Xb + (int64_t)(2 * sp + (lp & 1)) * panel_stride + (int64_t)r_begin * PB + (q & 127) * 8 : nullptr;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) mul[jj][e] = ldexpf(1.0f, -ein_of(k + e));
         }
-        auto fetch = [&](int t) {
+        auto fetch = [&](int t, f32x4 (&pre)[2][2]) {
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
                 if (src[jj]) {
@@ -529,87 +487,83 @@ __global__ __launch_bounds__(512, 1) void supgram_kernel(Sched sc, float* __rest
                 }
             }
         };
-        auto stash = [&]() {
+        auto stash = [&](const f32x4 (&pre)[2][2]) {
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
-                u32x4 p1, p2, p3;
-                unsigned x, y, z;
-                split3(pre[jj][0][0], pre[jj][0][1], x, y, z); p1[0] = x; p2[0] = y; p3[0] = z;
-                split3(pre[jj][0][2], pre[jj][0][3], x, y, z); p1[1] = x; p2[1] = y; p3[1] = z;
-                split3(pre[jj][1][0], pre[jj][1][1], x, y, z); p1[2] = x; p2[2] = y; p3[2] = z;
-                split3(pre[jj][1][2], pre[jj][1][3], x, y, z); p1[3] = x; p2[3] = y; p3[3] = z;
+                u32x4 p1, p2;
+                unsigned x, y;
+                split2(pre[jj][0][0] * mul[jj][0], pre[jj][0][1] * mul[jj][1], x, y); p1[0] = x; p2[0] = y;
+                split2(pre[jj][0][2] * mul[jj][2], pre[jj][0][3] * mul[jj][3], x, y); p1[1] = x; p2[1] = y;
+                split2(pre[jj][1][0] * mul[jj][4], pre[jj][1][1] * mul[jj][5], x, y); p1[2] = x; p2[2] = y;
+                split2(pre[jj][1][2] * mul[jj][6], pre[jj][1][3] * mul[jj][7], x, y); p1[3] = x; p2[3] = y;
                 u32x4* o = aimg + dst[jj];
-                o[0] = p1; o[SG_BLK] = p2; o[2 * SG_BLK] = p3;
+                o[0] = p1; o[SG_BLK] = p2;
             }
         };
-        // The matrix instructions of a compute segment — 18 for the Gram half-tiles of an earlier tile, 48 for the update — read all their A
+        // The matrix instructions of a compute segment — 9 for the Gram half-tiles of an earlier tile, 24 for the update — read all their A
         // operands (and the Gram B operands) from LDS.  Left to the compiler every ds_read sits right in front of its consumer (s_waitcnt
-        // lgkmcnt(0) before each MFMA group) and the LDS latency is exposed 11 times per tile and wave; here the reads of stage i+1 are issued
-        // before the MFMAs of stage i (stages: Gram unit 0, 1, 2, update k-step 0..7), pinned with sched_barrier.
-        struct Opnd6 { bf16x8 a1, a2, a3, b1, b2, b3; };
-        struct Opnd3 { bf16x8 a1, a2, a3; };
+        // lgkmcnt(0) before each MFMA group) and the LDS latency is exposed; here the reads of stage i+1 are issued before the MFMAs of stage i,
+        // pinned with sched_barrier.  Consecutive matrix instructions never share an accumulator (a dependent pair costs an issue bubble):
+        // the Gram units take turns; the update keeps ONE accumulator (its compute segment is the shorter one, see the panel stores below).
+        struct Opnd4 { h16x8 a1, a2, b1, b2; };
+        struct Opnd2 { h16x8 a1, a2; };
         auto ldG = [&](const u32x4* op, int pa, int pb) {
-            const u32x4* oa = op + ((pa * 2 + kh) * 3) * 64 + lane;
-            const u32x4* ob_ = op + ((pb * 2 + kh) * 3) * 64 + lane;
-            Opnd6 r;
-            r.a1 = __builtin_bit_cast(bf16x8, oa[0]); r.a2 = __builtin_bit_cast(bf16x8, oa[64]); r.a3 = __builtin_bit_cast(bf16x8, oa[128]);
-            r.b1 = __builtin_bit_cast(bf16x8, ob_[0]); r.b2 = __builtin_bit_cast(bf16x8, ob_[64]); r.b3 = __builtin_bit_cast(bf16x8, ob_[128]);
+            const u32x4* oa = op + ((pa * 2 + kh) * 2) * 64 + lane;
+            const u32x4* ob_ = op + ((pb * 2 + kh) * 2) * 64 + lane;
+            Opnd4 r;
+            r.a1 = __builtin_bit_cast(h16x8, oa[0]); r.a2 = __builtin_bit_cast(h16x8, oa[64]);
+            r.b1 = __builtin_bit_cast(h16x8, ob_[0]); r.b2 = __builtin_bit_cast(h16x8, ob_[64]);
             return r;
         };
-        auto mmG = [&](const Opnd6& r, f32x16 acc) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.a3, r.b1, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.a1, r.b3, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.a2, r.b2, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.a2, r.b1, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.a1, r.b2, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.a1, r.b1, acc, 0, 0, 0);
-            return acc;
+        auto gram3 = [&](const Opnd4& x, const Opnd4& y, const Opnd4& z) {   // small terms first, units interleaved
+            if (gon0) g0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x.a2, x.b1, g0, 0, 0, 0);
+            if (gon1) g1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(y.a2, y.b1, g1, 0, 0, 0);
+            if (gon2) g2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(z.a2, z.b1, g2, 0, 0, 0);
+            if (gon0) g0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x.a1, x.b2, g0, 0, 0, 0);
+            if (gon1) g1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(y.a1, y.b2, g1, 0, 0, 0);
+            if (gon2) g2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(z.a1, z.b2, g2, 0, 0, 0);
+            if (gon0) g0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x.a1, x.b1, g0, 0, 0, 0);
+            if (gon1) g1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(y.a1, y.b1, g1, 0, 0, 0);
+            if (gon2) g2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(z.a1, z.b1, g2, 0, 0, 0);
         };
         auto gram_of = [&](int t) {  // the three units of tile t, nothing to overlap with (tail)
             if (r_begin + 32 * t >= m_pad) return;
             const u32x4* op = opnd0 + (t & 1) * OPND_VECS;
-            if (gon0) g0 = mmG(ldG(op, ga0, gb0), g0);
-            if (gon1) g1 = mmG(ldG(op, ga1, gb1), g1);
-            if (gon2) g2 = mmG(ldG(op, ga2, gb2), g2);
+            const Opnd4 x = ldG(op, ga0, gb0), y = ldG(op, ga1, gb1), z = ldG(op, ga2, gb2);
+            gram3(x, y, z);
         };
-        const u32x4* img = aimg + (mypr * 8 * 3) * SG_BLK + h * SG_HB + c;
+        const u32x4* img = aimg + (mypr * 8 * 2) * SG_BLK + h * SG_HB + c;
         auto ldA = [&](int s) {
-            Opnd3 r;
-            r.a1 = __builtin_bit_cast(bf16x8, img[(3 * s + 0) * SG_BLK]);
-            r.a2 = __builtin_bit_cast(bf16x8, img[(3 * s + 1) * SG_BLK]);
-            r.a3 = __builtin_bit_cast(bf16x8, img[(3 * s + 2) * SG_BLK]);
+            Opnd2 r;
+            r.a1 = __builtin_bit_cast(h16x8, img[(2 * s + 0) * SG_BLK]);
+            r.a2 = __builtin_bit_cast(h16x8, img[(2 * s + 1) * SG_BLK]);
             return r;
         };
         const int glag = mypr ? 1 : 2;   // pair A accumulates the Gram units of tile t - 2 next to update t, pair B those of tile t - 1
         float* __restrict__ Pst = Pw + (int64_t)r_begin * PB + (4 * h) * PB + c;   // this lane's first output element of tile 0
 
         // ---- prologue: tile 0 staged, tile 1 in flight ----
-        fetch(0);
-        stash();
-        if (ntiles > 1) fetch(1);
+        fetch(0, preA);
+        stash(preA);
+        if (ntiles > 1) fetch(1, preA);
         __syncthreads();
         if (mypr) __syncthreads();   // pair B runs one segment behind pair A
 #ifdef ASVD_SG_TIMING
-        const bool sg_ts_on = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && ob == 0 && lane == 0;
+        unsigned long long sg_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, sg_last = __builtin_amdgcn_s_memtime();
 #endif
-        for (int t = 0; t < ntiles; ++t) {
+        // one tile: compute segment, barrier, memory segment, barrier.  `pre` holds tile t + 1
+        auto tile_step = [&](const int t, f32x4 (&pre)[2][2]) __attribute__((always_inline)) {
             // ================= compute segment =================
             SG_TS(0);
             const int tg = t - glag;
             const bool pending = tg >= 0 && r_begin + 32 * tg < m_pad;   // rows of the matrix proper only, not accumulated V rows
-            Opnd3 ua;
+            Opnd2 ua;
             if (pending) {
                 const u32x4* op = opnd0 + (tg & 1) * OPND_VECS;
-                Opnd6 x = ldG(op, ga0, gb0);
-                Opnd6 y = ldG(op, ga1, gb1);
-                __builtin_amdgcn_sched_barrier(0);
-                if (gon0) g0 = mmG(x, g0);
-                x = ldG(op, ga2, gb2);
-                __builtin_amdgcn_sched_barrier(0);
-                if (gon1) g1 = mmG(y, g1);
+                const Opnd4 x = ldG(op, ga0, gb0), y = ldG(op, ga1, gb1), z = ldG(op, ga2, gb2);
                 ua = ldA(0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (gon2) g2 = mmG(x, g2);
+                if (!SG_ABL(4)) gram3(x, y, z);
             } else {
                 ua = ldA(0);
             }
@@ -619,16 +573,15 @@ __global__ __launch_bounds__(512, 1) void supgram_kernel(Sched sc, float* __rest
             for (int q = 0; q < 16; ++q) acc[q] = 0.f;
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
-                Opnd3 un = ua;
+                Opnd2 un = ua;
                 if (s + 1 < 8) un = ldA(s + 1);
                 __builtin_amdgcn_sched_barrier(0);
-                const bf16x8 B1 = __builtin_bit_cast(bf16x8, q1[s]), B2 = __builtin_bit_cast(bf16x8, q2[s]), B3 = __builtin_bit_cast(bf16x8, q3[s]);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.a3, B1, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.a1, B3, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.a2, B2, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.a2, B1, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.a1, B2, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.a1, B1, acc, 0, 0, 0);
+                const h16x8 B1 = __builtin_bit_cast(h16x8, q1[s]), B2 = __builtin_bit_cast(h16x8, q2[s]);
+                if (!SG_ABL(4)) {   // one accumulator, small terms first (two alternating accumulators + their sum: 892.5 vs 894.3 us per launch, nothing)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ua.a2, B1, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ua.a1, B2, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ua.a1, B1, acc, 0, 0, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 ua = un;
             }
@@ -638,42 +591,51 @@ __global__ __launch_bounds__(512, 1) void supgram_kernel(Sched sc, float* __rest
             // ================= memory segment =================
             // order matters: vmcnt counts loads AND stores, and the panel stores are conditional (the compiler must assume none were issued), so a
             // stash BEHIND this tile's stores would wait for them.  Stash first: it waits only for what the previous memory segment issued.
-            if (t + 1 < ntiles) stash();        // tile t + 1 (in registers since the previous memory segment) -> incoming image
-            SG_TS(6);
-            if (t + 2 < ntiles) fetch(t + 2);
-            SG_TS(7);
-            if (mine) {
+            if (t + 1 < ntiles && !SG_ABL(8)) stash(pre);     // tile t + 1 (in registers since the previous memory segment) -> incoming image
+            SG_TS(4);
+            if (t + 2 < ntiles && !SG_ABL(2)) fetch(t + 2, pre);   // into the registers the stash has just emptied
+            SG_TS(5);
+            if (mine && !SG_ABL(1)) {
+                // sixteen 4-byte stores per lane (two full 128-byte rows per instruction).  Measured and dropped: the tile through 4 KB of wave-private LDS
+                // (ds_write_b32 in the C layout, ds_read_b128 along the rows) and out as four 16-byte stores per lane — 1047 vs 893 us per launch.
                 float* __restrict__ po = Pst + (int64_t)t * (32 * PB);
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) po[((reg & 3) + 8 * (reg >> 2)) * PB] = acc[reg];
+                for (int reg = 0; reg < 16; ++reg) po[((reg & 3) + 8 * (reg >> 2)) * PB] = acc[reg] * oscale;
             }
-            SG_TS(8);
-            if (r_begin + 32 * t < m_pad) {
+            SG_TS(6);
+            if (r_begin + 32 * t < m_pad && !SG_ABL(8)) {
                 u32x4* ow = opnd0 + (t & 1) * OPND_VECS;
 #pragma unroll
                 for (int k2 = 0; k2 < 2; ++k2) {
-                    u32x4 p1, p2, p3;
+                    u32x4 p1, p2;
 #pragma unroll
                     for (int e2 = 0; e2 < 4; ++e2) {
-                        unsigned x, y, z;
-                        split3(acc[8 * k2 + 2 * e2], acc[8 * k2 + 2 * e2 + 1], x, y, z);
-                        p1[e2] = x; p2[e2] = y; p3[e2] = z;
+                        unsigned x, y;
+                        split2(acc[8 * k2 + 2 * e2], acc[8 * k2 + 2 * e2 + 1], x, y);
+                        p1[e2] = x; p2[e2] = y;
                     }
-                    u32x4* o = ow + ((otp * 2 + k2) * 3) * 64 + lane;
-                    o[0] = p1; o[64] = p2; o[128] = p3;
+                    u32x4* o = ow + ((otp * 2 + k2) * 2) * 64 + lane;
+                    o[0] = p1; o[64] = p2;
                 }
             }
-            SG_TS(4);
+            SG_TS(7);
             __syncthreads();
-            SG_TS(5);
+            SG_TS(8);
+        };
+        for (int t = 0; t < ntiles; ++t) tile_step(t, preA);
+#ifdef ASVD_SG_TIMING
+        if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && ob == 0 && lane == 0) {
+            for (int i = 0; i < 9; ++i) g_sg_ts[mypr][i] = sg_acc[i];
+            g_sg_ts[mypr][9] = (unsigned long long)ntiles;
         }
+#endif
         if (!mypr) __syncthreads();   // pair A waits for pair B's last memory segment
         // ---- tail: the Gram units not yet accumulated (pair A: the last two tiles, pair B: the last one) ----
         if (ntiles - glag >= 0) gram_of(ntiles - glag);
-        if (glag == 2 && ntiles - 1 >= 0) gram_of(ntiles - 1);
+        if (glag == 2) gram_of(ntiles - 1);
     }
 
-    // ---- the two k-steps of a tile sit in waves 2t and 2t+1 (j = 0), 2t-8 .. (j = 1), ...: sum through LDS, coalesced store ----
+    // ---- the two k-steps of a tile sit in waves 2t and 2t+1 (j = 0), 2t-8 .. (j = 1), ...: sum through LDS, rescale, coalesced store ----
     __syncthreads();
     float* red = sg_smem;  // [unit u = 0..23][16 x 64]
 #pragma unroll
@@ -686,62 +648,12 @@ __global__ __launch_bounds__(512, 1) void supgram_kernel(Sched sc, float* __rest
     for (int o = tid; o < 12 * 1024; o += 512) {
         const int tt = o >> 10, e = o & 1023, np = tt >= 6 ? 1 : 0;
         if (!(np ? have1 : have0)) continue;
-        const float v = red[(2 * tt) * 1024 + e] + red[(2 * tt + 1) * 1024 + e];
+        int pa, pb;
+        bool on;
+        tile_panels(tt, pa, pb, on);
         const int reg = e >> 6, ln = e & 63;
         const int i = (reg & 3) + 8 * (reg >> 2) + 4 * (ln >> 5), j = ln & 31;
+        const float v = ldexpf(red[(2 * tt) * 1024 + e] + red[(2 * tt + 1) * 1024 + e], egtab[pa * 32 + i] + egtab[pb * 32 + j]);
         Gx[((((int64_t)b * npairs + (np ? knxt1 : knxt0)) * nsplit + chunk) * 6 + (tt - 6 * np)) * 1024 + i * 32 + j] = v;
-    }
-    ASVD_KERNEL_RELEASE(sc);
-}
-
-// ==================================================================================================
-// Dual launches: software pipelining on ONE stream.  The phases of a super-step — Gram pass (G), eigen-solves of inner step 0 and 1
-// (E1, E2), update pass (U) — are bound by different resources: G and U stream panels through HBM and the matrix pipe, E1 and E2 are
-// chains of short VALU/LDS phases on a few hundred workgroups.  Run back to back on one stream each phase leaves the other resource
-// idle (and several streams are not an option, common.h).  The batch is therefore cut into two halves, and the Gram pass of one half
-// (in two launches, each over half of the super-pairs) carries the two solve launches of the other half:
-//     [Ga(h0) | E1(h1)]  [Gb(h0) | E2(h1)]  U(h1)   [Ga'(h1) | E1(h0)]  [Gb'(h1) | E2(h0)]  U(h0)   ...      (' = next step)
-// Blocks [0, nsolve) of a dual launch run the solve body (dispatched first: they are the long-latency ones), the rest the Gram body;
-// both are the bodies of the stand-alone kernels above.  Kernel boundaries on the single stream keep every dependency.
-// The update pass is NOT combined with solves: measured in round 2 (library self-test, since removed), eigen-solve workgroups that
-// share a CU with split-bf16 update workgroups of the same launch produce a different, wrong Q (most of the 64x64 matrix; never with
-// Gram workgroups, never when the two kernels run one after the other, independent of LDS size, priority and fences) — cause not
-// found.  And the pairing that is safe does not pay: the solve workgroups slow down next to the Gram workgroups (LDS / issue
-// contention on a 128-phase dependent chain) by more than the overlap saves — 77 vs 69 ms per dense sweep.  Opt-in: ASVD_PIPE=1.
-struct SolveArgs {
-    unsigned* maxoff;
-    int* nrot;
-    const int* done;
-    float tol;
-    int inner_sweeps, nb, step, kb;
-    int* hist;
-    EvdV3 v3;
-    int gx, gy;  // grid of the solve part: (2 * super-pair slots, problems of its half); gy = 0: no solve part
-};
-struct GramArgs {
-    const float* X;
-    int64_t panel_stride, batch_stride;
-    int ns, D, m_pad, rows_per_split;
-    float* Gx;
-    const int* done;
-    int gx, gy, gz;  // (row splits, super-pair slots of THIS launch, problems); gz = 0: no streaming part
-    int pair0, npairs;  // the launch covers pair slots [pair0, pair0 + gy) of npairs
-};
-constexpr int DUAL_SMEM_FLOATS = EVD_SMEM_FLOATS(1) > SUPDATE_SMEM_FLOATS ? EVD_SMEM_FLOATS(1) : SUPDATE_SMEM_FLOATS;
-static_assert(DUAL_SMEM_FLOATS >= SGRAM6_SMEM_FLOATS, "LDS of the dual kernels");
-
-template <int EMODE>
-__global__ __launch_bounds__(256, 3) void dual_gram_kernel(Sched sc, SolveArgs sa, GramArgs ga) {
-    __shared__ __attribute__((aligned(16))) float smem[DUAL_SMEM_FLOATS];
-    int id = blockIdx.x;
-    const int nsolve = sa.gx * sa.gy;
-    if (id < nsolve) {
-        const BlockCtx ctx{id % sa.gx, id / sa.gx, 0, sa.gx, sa.gy, 1};
-        evd_body<EMODE, 1>(sc, ctx, smem, nullptr, 0, nullptr, nullptr, sa.maxoff, sa.nrot, sa.done, sa.tol, sa.inner_sweeps, sa.nb, sa.step, sa.kb,
-                           sa.hist, nullptr, 0, sa.v3);
-    } else {
-        id -= nsolve;
-        const BlockCtx ctx{id % ga.gx, ga.pair0 + (id / ga.gx) % ga.gy, id / (ga.gx * ga.gy), ga.gx, ga.npairs, ga.gz};
-        sgram6_body<0>(sc, ctx, smem, ga.X, ga.panel_stride, ga.batch_stride, ga.ns, ga.D, ga.m_pad, ga.rows_per_split, ga.Gx, ga.done);
     }
 }

@@ -344,7 +344,7 @@ def reconstruct_err(W, A, B):
     r = A.shape[1]
     assert A.shape == (m, r) and B.shape == (r, n) and A.is_contiguous() and B.is_contiguous() and A.dtype == B.dtype
     nb = ctypes.c_size_t()
-    L.check(lib.asvd_reconstruct_worksize(m, n, ctypes.byref(nb)), "asvd_reconstruct_worksize")
+    L.check(lib.asvd_reconstruct_worksize(m, n, r, ctypes.byref(nb)), "asvd_reconstruct_worksize")
     work = _work(nb.value, W.device)
     out = torch.empty(2, dtype=torch.float64, device=W.device)
     with torch.cuda.device(W.device):

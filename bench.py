@@ -31,6 +31,115 @@ def synth(size_m, size_n, seed, n_calib=32):
     return W.float(), scal.to(torch.float16)
 
 
+MODEL_SHAPES = {  # (out, in) of the Linears of a decoder layer + lm_head, and the layer count (SURVEY 8: model configs[2]-[4])
+    "llama-2-7b": dict(layers=32, attn=(4096, 4096), up=(11008, 4096), down=(4096, 11008), head=(32000, 4096)),
+    "llama-2-13b": dict(layers=40, attn=(5120, 5120), up=(13824, 5120), down=(5120, 13824), head=(32000, 5120)),
+    "tiny": dict(layers=3, attn=(64, 64), up=(176, 64), down=(64, 176), head=(320, 64)),
+}
+
+
+def model_linears(name):
+    """[(full_name, out, in)] in the order the reference's sweep visits a Llama module tree (lm_head, then the layers from the last to the
+    first, mlp before self_attn: sensitivity.py:19-33 as pinned by tests/golden/linear_order_hf.json)"""
+    c = MODEL_SHAPES[name]
+    out = [("lm_head",) + c["head"]]
+    for l in range(c["layers"] - 1, -1, -1):
+        out += [(f"model.layers.{l}.mlp.gate_proj",) + c["up"], (f"model.layers.{l}.mlp.up_proj",) + c["up"], (f"model.layers.{l}.mlp.down_proj",) + c["down"]]
+        out += [(f"model.layers.{l}.self_attn.{p}_proj",) + c["attn"] for p in ("q", "k", "v", "o")]
+    return out
+
+
+def sharded_model_leg(name, rank, world, dev, ratio=0.9, dry=False):
+    """BASELINE configs[3]: the Linears of a Llama-2-7B-shaped model LPT-sharded over the ranks, every rank decomposes its own layers with the HIP
+    path, ONE all-gather of the per-layer sensitivities on the process group (RCCL when the bench runs on GPUs), then the replicated search.
+    Untimed extra of `bench.py --gpus N` (not part of `value`); returns the record rank 0 prints under "sharded_model".  dry: no kernels (gloo
+    plumbing test): the sensitivities are made up, everything else is the real code path."""
+    import hashlib
+    import zlib
+    import torch
+    import torch.distributed as dist
+    from asvd4llm_amd import parallel
+    from asvd4llm_amd.binary_search import _CutPlans, _bisect_cut, _plan_params
+    layers = model_linears(name)
+    names = [n for n, _, _ in layers]
+    costs = [parallel.svd_flops(o, i) for _, o, i in layers]
+    owner = parallel.lpt_assign(costs, world)
+    ratios = [0.4, 0.5, 0.6, 0.7, 0.8, 0.9]
+    load = [sum(c for c, o in zip(costs, owner) if o == r) for r in range(world)]
+    mine = [(n, o, i) for (n, o, i), ow in zip(layers, owner) if ow == rank]
+    local, t_dec, sweeps = {}, 0.0, []
+    if dry:
+        for n, o, i in mine:
+            local[n] = {r: 5.0 + (zlib.crc32(f"{n}:{r}".encode()) % 1000) / 1000.0 for r in ratios}
+    else:
+        import torch.nn as nn
+        from asvd4llm_amd.modules.svd_linear import SVDLinear
+        lins = []
+        for idx, (n, o, i) in enumerate(mine):
+            g = torch.Generator(device=dev).manual_seed(233 + 7919 * rank + idx)
+            lin = nn.Linear(i, o, bias=False, device="meta")
+            lin.weight = nn.Parameter((torch.randn(o, i, generator=g, device=dev) * 0.02).half(), requires_grad=False)
+            scal = 32 * torch.randn(i, generator=g, device=dev).abs()
+            scal[torch.randperm(i, generator=g, device=dev)[:max(1, i // 100)]] *= 30
+            lin.scaling_diag_matrix = scal.half()
+            lins.append(lin)
+        ranks = {l: SVDLinear.compute_rank(l, ratio) for l in lins}
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        SVDLinear.prefactorize(lins, act_aware=True, alpha=0.5, ranks=ranks, max_batch=32)
+        for (n, o, i), l in zip(mine, lins):
+            mod = SVDLinear.from_linear(l, ratio, act_aware=True, alpha=0.5, sigma_fuse="UV")
+            assert isinstance(mod, SVDLinear) and l._asvd_svd_info.status == 0, n
+            sweeps.append(l._asvd_svd_info.sweeps)
+            S = l._asvd_factor_cache[1][1].float()
+            # a sensitivity made of the layer's own spectrum (the real sweep would put calibration perplexities here): what matters is that real
+            # per-layer numbers computed on the owning rank cross the collective
+            local[n] = {r: float(1.0 + S[min(SVDLinear.compute_rank(l, r), S.numel()) - 1] / S[0]) for r in ratios}
+            SVDLinear.drop_factor_cache(l)
+        torch.cuda.synchronize()
+        t_dec = time.perf_counter() - t0
+    # ---- the one exchange step of the path: all-gather of the sensitivities ----
+    if world > 1:
+        dist.barrier()
+    if not dry:
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    full = parallel.allgather_sensitivities(local, names, ratios, owner)
+    if not dry:
+        torch.cuda.synchronize()
+    t_ag = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    full2 = parallel.allgather_sensitivities(local, names, ratios, owner)  # second call: without communicator set-up
+    if not dry:
+        torch.cuda.synchronize()
+    t_ag2 = time.perf_counter() - t0
+    assert full2 == full and list(full.keys()) == names
+    # ---- replicated search on the complete dict: every rank must arrive at the same plan ----
+    plans = _CutPlans(full, lambda r: r < 1, 1)
+    weights = {n: o * i for n, o, i in layers}
+    cut = _bisect_cut(plans.size, lambda lo, mid, hi: (lambda ct: ct[0] / ct[1] > ratio)(_plan_params(plans.plan(mid), weights)))
+    plan = plans.plan(cut)
+    digest = int(hashlib.sha256(json.dumps(sorted(plan.items())).encode()).hexdigest()[:15], 16)
+    comm_dev = dev if (world > 1 and dist.get_backend() == "nccl") else torch.device("cpu")
+    red = torch.tensor([float(digest), -float(digest), t_dec, t_ag, t_ag2], dtype=torch.float64, device=comm_dev)
+    if world > 1:
+        dist.all_reduce(red, op=dist.ReduceOp.MAX)
+    red = red.cpu()
+    comp, total = _plan_params(plan, weights)
+    return {"model": name, "config": "BASELINE configs[3] shape: every Linear of the model, ratio %.2f, alpha 0.5, synthetic weights / statistics" % ratio,
+            "linears": len(layers), "collective_world_size": dist.get_world_size() if (world > 1 or (dist.is_available() and dist.is_initialized())) else 1,
+            "collective_backend": (dist.get_backend() if (dist.is_available() and dist.is_initialized()) else "none (single process)") + (" = RCCL" if (dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl") else ""),
+            "layers_per_rank": [sum(1 for o in owner if o == r) for r in range(world)],
+            "load_flops_max_over_mean": max(load) / (sum(load) / world), "decompose_s_max_over_ranks": float(red[2]),
+            "svd_flops_total": sum(costs), "achieved_TFLOPs_whole_job": (sum(costs) / float(red[2]) / 1e12) if float(red[2]) > 0 else None,
+            "allgather_first_call_ms": 1e3 * float(red[3]), "allgather_ms": 1e3 * float(red[4]),
+            "allgather_payload_bytes_per_rank": 2 * 8 * max(1, max(sum(1 for o in owner if o == r) for r in range(world)) * len(ratios)),
+            "plan_identical_on_all_ranks": bool(float(red[0]) == -float(red[1])), "plan_param_ratio": comp / total,
+            "layers_factorised_by_plan": sum(1 for v in plan.values() if v < 1), "sweeps_min_max_rank0": [min(sweeps), max(sweeps)] if sweeps else None}
+
+
 def dry_run(args, rank, world):
     """CPU/gloo exercise of everything around the kernels: rank binding, rendezvous, barrier-bracketed timing, MAX over ranks, one
     JSON line on rank 0.  No SVD runs (the product path has no CPU fallback), so value is null."""
@@ -48,11 +157,14 @@ def dry_run(args, rank, world):
     t = torch.tensor([dt, float(rank)], dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    sharded = None
+    if args.sharded_model != "none":
+        sharded = sharded_model_leg("tiny" if args.sharded_model == "auto" else args.sharded_model, rank, world, torch.device("cpu"), dry=True)
     if rank == 0:
         assert world == 1 or int(t[1].item()) == world - 1
         print(json.dumps({"metric": "weight-matrix SVDs/sec (4096x4096 fp32)", "value": None, "unit": "SVD/s", "n_gpus": world, "steps": args.steps,
                           "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-                          "data": "synthetic", "dry_run": True,
+                          "data": "synthetic", "dry_run": True, "sharded_model": sharded,
                           "config": {"workload": "dry run: launch plumbing only", "batch_per_gpu": args.batch, "parallelism": f"independent matrices x{world}"}}))
     if world > 1:
         dist.destroy_process_group()
@@ -72,6 +184,8 @@ def main():
     ap.add_argument("--no_latency", action="store_true", help="skip the batch-1 latency leg (profiling runs: keeps per-kernel averages to the batch workload)")
     ap.add_argument("--cpu_reps", type=int, default=3, help="repetitions of the CPU oracle pipeline at the best thread count (>= 3; median reported)")
     ap.add_argument("--cpu_budget_s", type=float, default=90.0, help="soft bound on the CPU-baseline leg (warm-up + thread sweep + repetitions)")
+    ap.add_argument("--sharded_model", default="auto", help="untimed extra: LPT-sharded decomposition of a model's Linears + the sensitivity all-gather on the "
+                    "process group (BASELINE configs[3]); auto = llama-2-7b when --gpus > 1, none at one GPU; or llama-2-7b / llama-2-13b / tiny / none")
     ap.add_argument("--dry_run", action="store_true", help="launch plumbing only (CPU, gloo): spawn/bind ranks, barrier, max-reduce, JSON line; no kernels, value = null")
     args = ap.parse_args()
 
@@ -165,6 +279,12 @@ def main():
     ops.svd_profile(False)
     assert all(i.status == 0 for i in infos), [i.status for i in infos]  # every SVD of the batch converged
 
+    # ---- configs[3] in one line (untimed): LPT-sharded model decomposition + the real sensitivity all-gather on this process group ----
+    sharded = None
+    sm = args.sharded_model if args.sharded_model != "auto" else ("llama-2-7b" if world > 1 else "none")
+    if sm != "none":
+        sharded = sharded_model_leg(sm, rank, world, dev)
+
     # per-rank rates (N > 1): every rank's own SVDs/s over its own wall clock
     per_rank = None
     if world > 1:
@@ -253,6 +373,8 @@ def main():
         }
         if per_rank is not None:
             out["per_rank_svds_per_s"] = per_rank
+        if sharded is not None:
+            out["sharded_model"] = sharded
         # ---- batch-1 latency (BASELINE configs[1] says "single ... Linear"): one matrix alone, same path, median of 3 ----
         if world == 1 and not args.no_latency:
             lat = []
@@ -270,6 +392,25 @@ def main():
             # BASELINE configs[1] reads "single ... Linear": the literal one-matrix figure travels inside `config` with the workload it belongs to
             out["config"]["latency_batch1_ms"] = out["latency_batch1_ms"]
             out["config"]["svds_per_s_batch1"] = out["svds_per_s_batch1"]
+        # ---- K9 on the device (north_star "reconstructed W <= 1e-3 Frobenius"): |W - A B|_F / |W|_F of the emitted fp16 factors of one matrix of the
+        # batch, by the tiled fp16-MFMA kernel fused with the difference reduction (asvd_reconstruct_err), timed with HIP events on its stream ----
+        k9 = None
+        if world == 1:
+            A_g, B_g, _ = outs[0]
+            ops.reconstruct_err(mats[0], A_g, B_g)  # warm (workspace)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(5):
+                k9_out = ops.reconstruct_err(mats[0], A_g, B_g)
+            e1.record()
+            torch.cuda.synchronize()
+            k9_us = e0.elapsed_time(e1) * 1e3 / 5
+            e2w2 = k9_out.cpu()
+            k9 = {"recon_err_over_W_device": float((e2w2[0] / e2w2[1]).sqrt()), "us_per_call": k9_us, "flop": 2.0 * m * n * r,
+                  "TFLOPs": 2.0 * m * n * r / (k9_us * 1e-6) / 1e12, "frac_of_fp16_mfma_peak": 2.0 * m * n * r / (k9_us * 1e-6) / 2.5e15,
+                  "note": "pad + transpose of the factors, the GEMM + reduction kernel and the final sum: three launches per call, all inside the timed region"}
+            out["k9_reconstruct"] = k9
         # ---- parity + CPU baseline (rank 0, N=1 only): the oracle pipeline on the box's host cores, bounded sample ----
         if world == 1 and not args.no_cpu_baseline:
             from oracle import asvd_oracle as O
@@ -321,7 +462,12 @@ def main():
                                              f"{sorted(sweep)} (one run each), median of {len(reps)} runs at the best thread count",
                                    "seconds_per_svd": tcpu, "seconds_by_threads": {str(k): v for k, v in sorted(sweep.items())},
                                    "host_cpu_count": ncpu, "seconds_torch_svd_lowrank_q_rank": t_lowrank}
-            out["parity"] = {"sigma_rel_err_top_r": serr, "r": r9, "recon_fro_err_rank512_vs_oracle": rerr, "recon_fro_err_scaled_norm": rerr_scaled, "tolerance": {"sigma": 1e-4, "recon": 1e-3}}
+            # the same quantity for the ORACLE's factors, on the host in fp64: what an exact rank-r truncation leaves (the device figure above must not exceed it
+            # by more than the contract's 1e-3)
+            oracle_err = float(((W0.double() - Ao.double() @ Bo.double()).norm() / W0.double().norm()).item())
+            out["parity"] = {"sigma_rel_err_top_r": serr, "r": r9, "recon_fro_err_rank512_vs_oracle": rerr, "recon_fro_err_scaled_norm": rerr_scaled,
+                             "truncation_err_over_W_device_k9": k9["recon_err_over_W_device"] if k9 else None, "truncation_err_over_W_oracle_fp64": oracle_err,
+                             "tolerance": {"sigma": 1e-4, "recon": 1e-3}}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -197,10 +197,13 @@ int asvd_fro_norm_sq(const void* w, int w_dtype, int64_t m, int64_t n, int64_t l
                      void* work, size_t work_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
- * K9  parity evidence (new; no reference counterpart):  err2 = |W - A*B|_F^2 , w2 = |W|_F^2
- *   W [m, n] in w_dtype (ldw), A [m, r], B [r, n] contiguous in ab_dtype (F16/BF16/F32).
- *   out: device double[2] = {err2, w2}.  work: asvd_reconstruct_worksize bytes.  Asynchronous. */
-int asvd_reconstruct_worksize(int64_t m, int64_t n, size_t* bytes);
+ * K9  parity evidence (new; no reference counterpart — BASELINE.json north_star "reconstructed W <= 1e-3 Frobenius"):
+ *        err2 = |W - A*B|_F^2 , w2 = |W|_F^2      (A, B = ALinear.weight, BLinear.weight of an SVDLinear: svd_linear.py:8-24)
+ *   W [m, n] in w_dtype (ldw), A [m, r], B [r, n] contiguous in ab_dtype.  F16 / BF16 factors: tiled GEMM on the fp16 / bf16 matrix pipe
+ *   (products of 16-bit factors are exact there, fp32 accumulation) fused with the squared-difference reduction in fp64, 2 m n r flop;
+ *   F32 factors: fp32 MFMA, one wave per 32x32 tile.  out: device double[2] = {err2, w2}.  work: asvd_reconstruct_worksize(m, n, r)
+ *   bytes (partial sums + zero-padded K-contiguous copies of 16-bit factors).  Asynchronous. */
+int asvd_reconstruct_worksize(int64_t m, int64_t n, int64_t r, size_t* bytes);
 int asvd_reconstruct_err(const void* W, int w_dtype, int64_t ldw, const void* A, const void* B, int ab_dtype,
                          int64_t m, int64_t n, int64_t r, double* out, void* work, size_t work_bytes, void* stream);
 
@@ -247,15 +250,18 @@ void asvd_svd_set_profiling(int enabled);
 int asvd_svd_get_profile(float* ms_host, int* launches_host);
 /* Test hook: one launch of the two-level update kernel ([X_S X_T] <- [X_S X_T] Qfin for every super-pair of XOR step D) on
  * caller-built panels X [batch][nb][R][32]; Qfin [batch][npairs][128*128]; subact [batch][npairs][4] (pair updated when any flag is
- * set); done, nupd [batch] ints.  split != 0: split-bf16 arithmetic.  Used by tests/test_gpu_twolevel.py only. */
-int asvd_test_supdate(int split, float* X, int64_t panel_stride, int64_t batch_stride, int ns, int D, int R, int rows_per_wg,
+ * set); done, nupd [batch] ints.  Used by tests/test_gpu_twolevel.py only. */
+int asvd_test_supdate(float* X, int64_t panel_stride, int64_t batch_stride, int ns, int D, int R, int rows_per_wg,
                       const float* Qfin, const int* subact, const int* done, int* nupd, int nchunks, int npairs, int batch, void* stream);
 /* Test hook: one launch of the fused kernel of the two-level sweep (update of XOR super-step D + partial Gram tiles of super-step E,
  * E != D) on caller-built panels.  Gx [batch][npairs][nchunks][6][32*32]: tiles [0,2] [0,3] [1,2] [1,3] [0,1] [2,3] of E's super-pairs
- * over the first m_pad rows, one partial per row chunk.  Other arguments as asvd_test_supdate.  tests/test_gpu_twolevel.py only. */
+ * over the first m_pad rows, one partial per row chunk.  Din [batch][npairs][128]: squared norms of the 128 columns of every super-pair
+ * of step D BEFORE the update, in the pair's column order (panels 2S, 2S+1, 2T, 2T+1; zeros for an absent member) — the power-of-two
+ * column scales of the split-fp16 arithmetic come from them (in the library the eigen-solve launch of the step leaves them behind).
+ * Other arguments as asvd_test_supdate.  tests/test_gpu_twolevel.py only. */
 int asvd_test_supgram(float* X, int64_t panel_stride, int64_t batch_stride, int ns, int D, int E, int R, int m_pad, int rows_per_wg,
-                      const float* Qfin, const int* subact, float* Gx, const int* done, int* nupd, int nchunks, int npairs, int batch,
-                      void* stream);
+                      const float* Qfin, const int* subact, const float* Din, float* Gx, const int* done, int* nupd, int nchunks, int npairs,
+                      int batch, void* stream);
 /* Test hook: the super-panel pair schedule of the two-level sweeps for `ns` super-panels (grouped != 0: the grouped order where it applies,
  * else XOR).  out_dev: device int[out_capacity] >= nsteps * npairs; out[step * npairs + k] = (S << 16) | T or -1 (empty slot).
  * tests/test_gpu_twolevel.py only. */

@@ -39,6 +39,31 @@ def npy(t):
 
 
 # ---- F-rank ---------------------------------------------------------------------------------------------------
+def _reference_rank(out_f, in_f, ratio, align):
+    """rank the reference's SVDLinear.from_linear computes (svd_linear.py:39-44), obtained by CALLING it: the proxy Linear carries a weight that is a
+    1-element tensor expanded to [out, in] (numel and shape right, 4 bytes of storage; `.float()` of an fp32 tensor is the tensor itself), the
+    factorisation is replaced by a spy that records the rank it is asked for and fails, and the random nn.Linear the reference builds after a failed
+    factorisation is created on the meta device (moving it to the CPU raises: caught here, the rank is already known)."""
+    seen = {}
+
+    def spy(w, q=6, niter=2, M=None):
+        seen["q"] = q
+        raise RuntimeError("rank probe")
+
+    proxy = types.SimpleNamespace(weight=torch.zeros(1, 1).expand(out_f, in_f), in_features=in_f, out_features=out_f)
+    stock = torch.svd_lowrank
+    torch.svd_lowrank = spy
+    try:
+        with torch.device("meta"), contextlib.redirect_stdout(io.StringIO()):
+            try:
+                SVDLinear.from_linear(proxy, ratio, rank_align=align)
+            except NotImplementedError:  # "Cannot copy out of meta tensor": the fallback Linear's .to(cpu)
+                pass
+    finally:
+        torch.svd_lowrank = stock
+    return int(seen["q"])
+
+
 def gen_rank():
     shapes = [(768, 768), (3072, 768), (768, 3072), (50272, 768), (4096, 4096), (11008, 4096), (4096, 11008), (32000, 4096),
               (5120, 5120), (13824, 5120), (5120, 13824), (32000, 5120), (64, 64), (176, 64), (64, 176)]
@@ -47,16 +72,8 @@ def gen_rank():
     for (o, i) in shapes:
         for ratio in ratios:
             for align in (1, 128):
-                lin = types.SimpleNamespace()
-                # run the reference arithmetic through from_linear on a meta-free tiny proxy is too heavy for 50272x768;
-                # the rank lines (svd_linear.py:39-44) are reproduced by calling from_linear only on small shapes below and
-                # evaluated here with the identical expressions for the big ones (checked equal on the small ones).
-                n_params = o * i
-                compressed = int(n_params * ratio)
-                rank = compressed // (i + o)
-                rank = int(np.ceil(rank / align) * align)
-                rows.append([o, i, ratio, align, rank])
-    # cross-check the expressions against the reference object on small shapes
+                rows.append([o, i, ratio, align, _reference_rank(o, i, ratio, align)])
+    # and the real thing on small shapes: the rank of the module from_linear returns
     for (o, i) in [(64, 64), (176, 64), (64, 176)]:
         for ratio in ratios:
             lin = nn.Linear(i, o)
@@ -320,6 +337,122 @@ def gen_search():
     np.savez_compressed(os.path.join(OUT, "tiny_lm_state.npz"), **tiny_state(TinyLM()), **{"scal::" + k: v for k, v in scal.items()})
 
 
+def gen_search_extra():
+    """tests/golden/search_extra.json (round 4): (1) the reference's ppl-TARGET search (binary_search.py:64-87) on the tiny LM, with the
+    factorisation patched to the exact oracle for determinism, sensitivities and scaling vectors of the existing tiny fixture; (2) its ratio-target
+    search on a Llama-2-7B-SHAPED module tree (225 Linears x 6 ratios = 1350 candidates with many ties): proxy Linears whose weights are
+    1-element tensors expanded to the real shapes (numel right, no memory), from_linear replaced by a recorder — what is pinned is the search:
+    stable sort with ties, bisection trace, the plan of the LAST PROBED cut."""
+    out = {}
+    tiny = json.load(open(os.path.join(OUT, "tiny_lm.json")))
+    st = np.load(os.path.join(OUT, "tiny_lm_state.npz"))
+    sens = {k: {float(r): v for r, v in d.items()} for k, d in tiny["sensitivity_ppl"].items()}
+    calib = [{"input_ids": torch.tensor(ids)} for ids in tiny["calib_ids"]]
+    ids = torch.cat([c["input_ids"] for c in calib], 0)
+    stock = torch.svd_lowrank
+    cwd = os.getcwd()
+    res = {}
+    for tag, target in (("ppl54.1", 54.1), ("ppl54.3", 54.3), ("ppl60", 60.0)):
+        model = TinyLM()
+        model.load_state_dict({k: torch.from_numpy(st[k]) for k in st.files if not k.startswith("scal::")})
+        for n, mod in model.named_modules():
+            if isinstance(mod, nn.Linear):
+                mod.scaling_diag_matrix = torch.from_numpy(st["scal::" + n])
+        args = types.SimpleNamespace(scaling_method="abs_mean", alpha=0.5, n_calib_samples=3, calib_dataset="wikitext2", compress_kv_cache=False,
+                                     rank_align=1, act_aware=True, sigma_fuse="UV", ppl_target=target, param_ratio_target=-1, kv_cache_ratio_target=-1)
+        torch.svd_lowrank = exact_lowrank
+        buf = io.StringIO()
+        try:
+            with tempfile.TemporaryDirectory() as td:
+                os.chdir(td)
+                with contextlib.redirect_stdout(buf), contextlib.redirect_stderr(io.StringIO()):
+                    ref_binary_search.binary_search_truncation_rank(model, sens, calib, args)
+        finally:
+            torch.svd_lowrank = stock
+            os.chdir(cwd)
+        trace = [l for l in buf.getvalue().splitlines() if l.startswith("low=") or l.startswith("===")]
+        ranks = {n: (int(mod.truncation_rank) if isinstance(mod, SVDLinear) else -1) for n, mod in model.named_modules()
+                 if isinstance(mod, (SVDLinear,)) or (isinstance(mod, nn.Linear) and not n.endswith("ALinear") and not n.endswith("BLinear"))}
+        res[tag] = {"ppl_target": target, "trace": trace, "ranks": ranks, "ppl_after": ref_eval.evaluate_perplexity(model, ids, 3)}
+    out["tiny_ppl_target"] = res
+    print("ppl-target traces:", {k: (len(v["trace"]), v["ppl_after"]) for k, v in res.items()})
+
+    # ---- (2) Llama-2-7B-shaped search
+    def proxy_linear(out_f, in_f):
+        lin = nn.Linear(1, 1, bias=False)
+        lin.in_features, lin.out_features = in_f, out_f
+        lin.weight = nn.Parameter(torch.zeros(1, 1).expand(out_f, in_f), requires_grad=False)
+        return lin
+
+    class Blk(nn.Module):
+        def __init__(self, h, f):
+            super().__init__()
+            self.self_attn = nn.Module()
+            for n in ("q_proj", "k_proj", "v_proj", "o_proj"):
+                setattr(self.self_attn, n, proxy_linear(h, h))
+            self.mlp = nn.Module()
+            self.mlp.gate_proj, self.mlp.up_proj, self.mlp.down_proj = proxy_linear(f, h), proxy_linear(f, h), proxy_linear(h, f)
+
+    class Shaped(nn.Module):
+        def __init__(self, h=4096, f=11008, layers=32, vocab=32000):
+            super().__init__()
+            self.model = nn.Module()
+            self.model.layers = nn.ModuleList([Blk(h, f) for _ in range(layers)])
+            self.lm_head = proxy_linear(vocab, h)
+
+    def walk_order(model):  # the order the reference's sweep leaves in its dict: its own stack discipline (sensitivity.py:19-33) on this tree
+        full = {m: n for n, m in model.named_modules()}
+        order, modules = [], [model]
+        while modules:
+            sub = modules.pop()
+            for name, child in sub.named_children():
+                if isinstance(child, nn.Linear):
+                    order.append(full[child])
+                else:
+                    modules.append(child)
+        return order
+
+    rng = np.random.RandomState(233)
+    names = walk_order(Shaped())
+    assert len(names) == 225
+    sens7 = {}
+    for li, n in enumerate(names):
+        base = 5.5 + 0.9 * rng.rand()
+        # two decimals: plenty of exact ties across layers and ratios (the stable sort keeps the traversal order among them)
+        sens7[n] = {r: float(np.round(base + (0.9 - r) * (0.3 + 2.0 * rng.rand()) ** 2, 2)) for r in (0.4, 0.5, 0.6, 0.7, 0.8, 0.9)}
+    vals = [v for d in sens7.values() for v in d.values()]
+    assert len(vals) == 1350 and len(set(vals)) < 700, len(set(vals))
+    runs = {}
+    stock_from_linear = SVDLinear.from_linear
+    for tag, target in (("ratio0.9", 0.9), ("ratio0.95", 0.95), ("ratio0.8", 0.8)):
+        model = Shaped()
+        picked = {}
+
+        def recorder(linear, param_ratio, act_aware=False, ic_split=1, oc_split=1, alpha=1, sigma_fuse="UV", rank_align=1):
+            m = nn.Identity()
+            m.param_ratio = param_ratio
+            return m
+
+        SVDLinear.from_linear = staticmethod(recorder)
+        args = types.SimpleNamespace(scaling_method="abs_mean", alpha=0.5, n_calib_samples=1, calib_dataset="wikitext2", compress_kv_cache=False,
+                                     rank_align=1, act_aware=True, sigma_fuse="UV", ppl_target=-1, param_ratio_target=target, kv_cache_ratio_target=-1)
+        buf = io.StringIO()
+        try:
+            with contextlib.redirect_stdout(buf), contextlib.redirect_stderr(io.StringIO()):
+                ref_binary_search.binary_search_truncation_rank(model, sens7, [{"input_ids": torch.zeros(1, 4, dtype=torch.long)}], args)
+        finally:
+            SVDLinear.from_linear = stock_from_linear
+        for n, mod in model.named_modules():
+            if hasattr(mod, "param_ratio"):
+                picked[n] = mod.param_ratio
+        trace = [l for l in buf.getvalue().splitlines() if l.startswith("low=") or l.startswith("===")]
+        runs[tag] = {"param_ratio_target": target, "trace": trace, "plan": picked}
+    out["llama7b_shaped"] = {"shape": {"hidden": 4096, "inter": 11008, "layers": 32, "vocab": 32000}, "order": names,
+                             "sens": {k: {str(r): v for r, v in d.items()} for k, d in sens7.items()}, "runs": runs}
+    print("7B-shaped search:", {k: (len(v["trace"]), len(v["plan"])) for k, v in runs.items()})
+    json.dump(out, open(os.path.join(OUT, "search_extra.json"), "w"), indent=0)
+
+
 def gen_order_hf():
     """reverse-DFS Linear order of real HF module trees (tiny random Llama / OPT)"""
     from transformers import LlamaConfig, LlamaForCausalLM, OPTConfig, OPTForCausalLM
@@ -436,11 +569,18 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "hf_export":  # only the exported-repo fixture
         gen_hf_export()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "search_extra":  # ppl-target + model-scale search fixtures (needs tiny_lm.json / tiny_lm_state.npz)
+        gen_search_extra()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "rank":
+        gen_rank()
+        sys.exit(0)
     gen_rank()
     gen_hook()
     gen_svd()
     gen_svd_mid()
     gen_search()
+    gen_search_extra()
     gen_order_hf()
     gen_fisher()
     gen_hf_export()

@@ -235,6 +235,18 @@ def test_bench_gpus2_dry_run_spawns_two_ranks():
     assert len(lines) == 1  # exactly one JSON line, from rank 0
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["dry_run"] is True and rec["scaling"] == "weak"
+    # the configs[3] leg: LPT shard of a model's Linears, ONE all-gather of the sensitivities on the process group, replicated search
+    sm = rec["sharded_model"]
+    assert sm["collective_world_size"] == 2 and sm["collective_backend"] == "gloo" and sm["plan_identical_on_all_ranks"] is True
+    assert sum(sm["layers_per_rank"]) == sm["linears"] == 22 and min(sm["layers_per_rank"]) >= 1 and sm["load_flops_max_over_mean"] < 1.1
+    assert sm["allgather_ms"] > 0 and 0.85 < sm["plan_param_ratio"] <= 1.0
+
+
+def test_bench_model_linears_order_matches_reference_walk(golden):
+    """bench.py's shape list of a Llama model is in the order the reference's sweep visits the module tree"""
+    import bench
+    names = [n for n, _, _ in bench.model_linears("llama-2-7b")]
+    assert names == golden.json("search_extra.json")["llama7b_shaped"]["order"] and len(names) == 225
 
 
 def _cache_worker(rank, ws, port, q, tmpdir, shard):
@@ -262,8 +274,8 @@ def _cache_worker(rank, ws, port, q, tmpdir, shard):
             calib = datautils.get_calib_data("synthetic", None, "tiny/lm", 3, seqlen=16, seed=7, vocab_size=50)
             with contextlib.redirect_stderr(io.StringIO()):
                 act_aware_utils.calib_input_distribution(model, calib, "abs_mean", use_cache=True, shard_samples=shard)
-            stats = {n: m.scaling_diag_matrix.clone() for n, m in model.named_modules() if isinstance(m, torch.nn.Linear)}
-            out.append((torch.cat([c["input_ids"] for c in calib]), stats))
+            stats = {n: m.scaling_diag_matrix.numpy().copy() for n, m in model.named_modules() if isinstance(m, torch.nn.Linear)}
+            out.append((torch.cat([c["input_ids"] for c in calib]).numpy().copy(), stats))  # numpy: tensors would travel as file descriptors
         files = sorted(_os.listdir("cache"))
         q.put((rank, out, files))
     finally:
@@ -290,10 +302,10 @@ def test_cache_files_are_written_once_and_read_complete_world2(tmp_path, shard):
     (_, out0, files0), (_, out1, files1) = res
     assert files0 == files1 and len(files0) == 2 and not any(".tmp." in f for f in files0), files0
     for (ids_a, st_a), (ids_b, st_b) in zip(out0, out1):   # rank 0 vs rank 1, both passes
-        assert torch.equal(ids_a, ids_b)
+        assert (ids_a == ids_b).all()
         assert st_a.keys() == st_b.keys()
         for n in st_a:
-            assert torch.equal(st_a[n], st_b[n]), n
+            assert (st_a[n] == st_b[n]).all(), n
     for n in out0[0][1]:   # computed (first pass) vs loaded from the cache (second pass)
-        assert torch.equal(out0[0][1][n], out0[1][1][n])
-        assert out0[0][1][n].abs().sum() > 0
+        assert (out0[0][1][n] == out0[1][1][n]).all()
+        assert abs(out0[0][1][n]).sum() > 0

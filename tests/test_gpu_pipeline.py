@@ -166,6 +166,39 @@ def test_full_pipeline_vs_reference_run(gpu, golden, tmp_path, monkeypatch):
     assert any(k.endswith("ALinear.weight") for k in sd) and any(k.endswith("BLinear.weight") for k in sd)
 
 
+@pytest.mark.parametrize("tag", ["ppl54.1", "ppl54.3"])
+def test_ppl_target_search_vs_reference_run(gpu, golden, tag):
+    """--ppl_target with the HIP path: every probe factorises the whole toy LM (from the cached exact SVD of each layer) and measures its
+    perplexity; bisection steps, perplexities (2e-4) and final ranks are the reference's run on the same weights (binary_search.py:64-87)."""
+    from asvd4llm_amd.binary_search import binary_search_truncation_rank
+    from asvd4llm_amd.evaluate_utils import evaluate_perplexity
+    from asvd4llm_amd.modules.svd_linear import SVDLinear
+    from tests.tiny_lm import parse_search_trace
+    t = golden.json("tiny_lm.json")
+    rec = golden.json("search_extra.json")["tiny_ppl_target"][tag]
+    model, scal = load_golden_tiny(golden)
+    model = model.to(gpu)
+    for n, m in model.named_modules():
+        if isinstance(m, nn.Linear):
+            m.scaling_diag_matrix = scal[n].to(gpu)
+    calib = [{"input_ids": torch.tensor(ids)} for ids in t["calib_ids"]]
+    sens = {k: {float(r): v for r, v in d.items()} for k, d in t["sensitivity_ppl"].items()}
+    args = default_args(ppl_target=rec["ppl_target"], param_ratio_target=-1)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf), contextlib.redirect_stderr(io.StringIO()):
+        binary_search_truncation_rank(model, sens, calib, args)
+    lines = [l for l in buf.getvalue().splitlines() if l.startswith("low=") or l.startswith("===")]
+    got, want = parse_search_trace(lines), parse_search_trace(rec["trace"])
+    assert len(got) == len(want) >= 6
+    for g, w in zip(got, want):
+        assert g[:3] == w[:3] and abs(g[3] - w[3]) <= 2e-4 * w[3] and g[4] == w[4], (g, w)
+    ranks = {n: (m.truncation_rank if isinstance(m, SVDLinear) else -1) for n, m in model.named_modules()
+             if isinstance(m, SVDLinear) or (isinstance(m, nn.Linear) and not n.endswith("ALinear") and not n.endswith("BLinear"))}
+    assert ranks == rec["ranks"]
+    ids = torch.cat([c["input_ids"] for c in calib], 0)
+    assert abs(evaluate_perplexity(model, ids, 3) - rec["ppl_after"]) <= 2e-4 * rec["ppl_after"]
+
+
 def test_prefactorize_batches_same_shape_layers(gpu):
     """model-level batching: same-shape Linears are factorised concurrently and land in the cache from_linear uses"""
     from asvd4llm_amd import ops

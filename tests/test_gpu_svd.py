@@ -177,32 +177,24 @@ def test_reduction_matches_direct_path(gpu):
     assert ((R1 - R2).norm() / R2.norm()).item() <= 1e-4
 
 
-def test_fused_update_gram_path_matches_default(gpu):
-    """ASVD_FUSED=1: update of step d fused with the Gram blocks of step d+1 (upgram_kernel, power-of-two panel counts).
-    Same arithmetic in a different summation order: singular values agree to fp32 noise, parity bars hold."""
-    import os
+def test_fused_and_separate_passes_agree(gpu, monkeypatch):
+    """The dense sweeps run the fused update + next-step Gram kernel (split-fp16 arithmetic with power-of-two column scales); ASVD_SUPGRAM=0
+    runs the separate passes (fp32 Gram pass, split-bf16 update pass) — also what a call falls back to when the split-fp16 path turns a problem
+    NaN.  Different arithmetic, same contract: same sweep count (+-1), singular values equal to fp32 noise, parity bars hold for both."""
     from asvd4llm_amd import ops
     W, s = llm_like(1024, 1024, seed=77)
     Wd, sd = W.to(gpu), s.to(gpu)
     U0, S0, V0, i0 = ops.svd(Wd, sd)
-    os.environ["ASVD_FUSED"] = "1"
-    try:
-        U1, S1, V1, i1 = ops.svd(Wd, sd)
-        mats = [llm_like(512, 512, seed=90 + b)[0].to(gpu) for b in range(3)]
-        _, Sb, _, ib = ops.svd_batched(mats)
-    finally:
-        del os.environ["ASVD_FUSED"]
-    assert i1.status == 0 and abs(i1.sweeps - i0.sweeps) <= 1
+    monkeypatch.setenv("ASVD_SUPGRAM", "0")
+    U1, S1, V1, i1 = ops.svd(Wd, sd)
+    monkeypatch.delenv("ASVD_SUPGRAM")
+    assert i0.status == 0 and i1.status == 0 and abs(i1.sweeps - i0.sweeps) <= 1
     assert ((S1 - S0).abs().max() / S0[0]).item() <= 2e-6
     So = O.exact_svd(O.scaled_weight(W, s))[1]
-    assert O.sigma_rel_err(S1.cpu(), So, 460) <= SIG_TOL
+    assert O.sigma_rel_err(S0.cpu(), So, 460) <= SIG_TOL and O.sigma_rel_err(S1.cpu(), So, 460) <= SIG_TOL
     R1 = (U1[:, :460] * S1[:460]) @ V1[:, :460].T
     R0 = (U0[:, :460] * S0[:460]) @ V0[:, :460].T
     assert ((R1 - R0).norm() / R0.norm()).item() <= 1e-4
-    for b, m in enumerate(mats):
-        assert ib[b].status == 0
-        ref = torch.linalg.svdvals(m.cpu().double())
-        assert ((Sb[b].cpu().double() - ref).abs().max() / ref[0]).item() <= 1e-5
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -255,19 +247,19 @@ def test_svd_llama13b_shapes(gpu, shape):
 
 @pytest.mark.timeout(900)
 def test_grouped_schedule_fused_and_separate_passes_agree(gpu, monkeypatch):
-    """13B column counts (80 super-panels) run the grouped super-panel schedule; round 3 fuses the update of a super-step with the Gram
-    tiles of the next one there too (inside the groups AND between the offsets of a group pair).  Both forms of the sweep must meet parity
-    with the same sweep count, and agree with each other to rounding."""
+    """13B column counts (80 super-panels) run the grouped super-panel schedule; the update of a super-step is fused with the Gram tiles of the
+    next one there too (inside the groups AND between the offsets of a group pair).  Fused (split-fp16) and separate passes (ASVD_SUPGRAM=0)
+    must meet parity with the same sweep count, and agree with each other to rounding."""
     from asvd4llm_amd import ops
     W, s = llm_like(5120, 5120, seed=29)
     Wd, sd = W.to(gpu), s.to(gpu)
     res = {}
     for flag in ("1", "0"):
-        monkeypatch.setenv("ASVD_SUPGRAM_GROUPED", flag)
+        monkeypatch.setenv("ASVD_SUPGRAM", flag)
         U, S, V, info = ops.svd(Wd, sd)
         assert info.status == 0
         res[flag] = (S.cpu(), info.sweeps)
-    monkeypatch.delenv("ASVD_SUPGRAM_GROUPED")
+    monkeypatch.delenv("ASVD_SUPGRAM")
     So = torch.linalg.svdvals(O.scaled_weight(W, s).double())
     r = O.rank_from_ratio(5120, 5120, 0.9)
     for flag in ("1", "0"):

@@ -3,6 +3,7 @@ import contextlib
 import io
 import types
 
+import pytest
 import torch
 import torch.nn as nn
 
@@ -81,6 +82,75 @@ def test_binary_search_ratio_target_2(golden, monkeypatch):
 
 def test_binary_search_kv_mode(golden, monkeypatch):
     _run_search(golden, "kv0.5", monkeypatch, compress_kv_cache=True, kv_cache_ratio_target=0.5)
+
+
+@pytest.mark.parametrize("tag", ["ppl54.1", "ppl54.3", "ppl60"])
+def test_binary_search_ppl_target_vs_reference(golden, monkeypatch, tag):
+    """--ppl_target (binary_search.py:64-87): every probe compresses the WHOLE model to the plan of the cut and measures its perplexity.
+    Fixture: the reference's own run on the tiny LM (factorisation patched to the exact one).  Here the factors come from the CPU oracle
+    (tests only), so the bisection must walk the same (low, mid, high), see the same perplexities (to 1e-4) and end on the same ranks."""
+    from asvd4llm_amd import binary_search as bs
+    from tests.tiny_lm import oracle_from_linear, parse_search_trace
+    t = golden.json("tiny_lm.json")
+    rec = golden.json("search_extra.json")["tiny_ppl_target"][tag]
+    model, scal = load_golden_tiny(golden)
+    for n, m in model.named_modules():
+        if isinstance(m, nn.Linear):
+            m.scaling_diag_matrix = scal[n]
+    monkeypatch.setattr(SVDLinear, "from_linear", staticmethod(oracle_from_linear))
+    monkeypatch.setattr(SVDLinear, "drop_factor_cache", staticmethod(lambda l: None))
+    sens = {k: {float(r): v for r, v in d.items()} for k, d in t["sensitivity_ppl"].items()}
+    calib = [{"input_ids": torch.tensor(ids)} for ids in t["calib_ids"]]
+    args = default_args(offload_raw_to_cpu=False, ppl_target=rec["ppl_target"], param_ratio_target=-1)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf), contextlib.redirect_stderr(io.StringIO()):
+        bs.binary_search_truncation_rank(model, sens, calib, args)
+    lines = [l for l in buf.getvalue().splitlines() if l.startswith("low=") or l.startswith("===")]
+    assert [l for l in lines if l.startswith("===")] == [l for l in rec["trace"] if l.startswith("===")]
+    got, want = parse_search_trace(lines), parse_search_trace(rec["trace"])
+    assert len(got) == len(want) >= 6
+    for g, w in zip(got, want):
+        assert g[:3] == w[:3] and abs(g[3] - w[3]) <= 1e-4 * w[3] and g[4] == w[4], (g, w)
+    ranks = {}
+    for n, m in model.named_modules():
+        if hasattr(m, "truncation_rank"):
+            ranks[n] = m.truncation_rank
+        elif isinstance(m, nn.Linear):
+            ranks[n] = -1
+    assert ranks == rec["ranks"]
+    from asvd4llm_amd.evaluate_utils import evaluate_perplexity
+    ids = torch.cat([c["input_ids"] for c in calib], 0)
+    assert abs(evaluate_perplexity(model, ids, 3) - rec["ppl_after"]) <= 1e-4 * rec["ppl_after"]
+
+
+@pytest.mark.parametrize("tag", ["ratio0.9", "ratio0.95", "ratio0.8"])
+def test_binary_search_at_model_scale_vs_reference(golden, monkeypatch, tag):
+    """The search over the 1350 candidates of a Llama-2-7B-shaped model (225 Linears x 6 ratios, many exact ties in the sensitivities): the
+    trace lines — float sums included — and the plan of the last probed cut must be the reference's, character for character."""
+    from asvd4llm_amd import binary_search as bs
+    from tests.tiny_lm import ShapedLlama
+    fx = golden.json("search_extra.json")["llama7b_shaped"]
+    rec = fx["runs"][tag]
+    model = ShapedLlama(**{k: fx["shape"][k] for k in ("hidden", "inter", "layers", "vocab")})
+    from asvd4llm_amd.sensitivity import collect_linear_info
+    assert [i["full_name"] for i in collect_linear_info(model).values()] == fx["order"]
+
+    def recorder(linear, param_ratio, act_aware=False, ic_split=1, oc_split=1, alpha=1, sigma_fuse="UV", rank_align=1):
+        m = nn.Identity()
+        m.param_ratio = param_ratio
+        return m
+
+    monkeypatch.setattr(SVDLinear, "from_linear", staticmethod(recorder))
+    monkeypatch.setattr(SVDLinear, "drop_factor_cache", staticmethod(lambda l: None))
+    sens = {k: {float(r): v for r, v in d.items()} for k, d in fx["sens"].items()}
+    args = default_args(offload_raw_to_cpu=False, param_ratio_target=rec["param_ratio_target"])
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf), contextlib.redirect_stderr(io.StringIO()):
+        bs.binary_search_truncation_rank(model, sens, [{"input_ids": torch.zeros(1, 4, dtype=torch.long)}], args)
+    lines = [l for l in buf.getvalue().splitlines() if l.startswith("low=") or l.startswith("===")]
+    assert lines == rec["trace"]
+    plan = {n: m.param_ratio for n, m in model.named_modules() if hasattr(m, "param_ratio")}
+    assert plan == rec["plan"]
 
 
 def test_lpt_assign_balanced_and_deterministic():

@@ -108,3 +108,60 @@ class WideLM(nn.Module):
         if labels is not None:
             return (nn.functional.cross_entropy(logits.view(-1, logits.size(-1)), labels.reshape(-1)), logits)
         return (logits,)
+
+
+# ---- stand-ins shared by the host-logic tests ------------------------------------------------------------------------
+class OracleTwoLinear(nn.Module):
+    """what SVDLinear is to a forward pass, built from the CPU oracle's factors (tests only: the product has no CPU path)"""
+
+    def __init__(self, A, B, rank):
+        super().__init__()
+        self.A, self.B, self.truncation_rank = A, B, rank
+
+    def forward(self, x):
+        return torch.nn.functional.linear(torch.nn.functional.linear(x, self.B), self.A)
+
+
+def oracle_from_linear(linear, param_ratio, act_aware=False, ic_split=1, oc_split=1, alpha=1, sigma_fuse="UV", rank_align=1):
+    from oracle import asvd_oracle as O
+    o = O.from_linear_oracle(linear.weight.data, getattr(linear, "scaling_diag_matrix", None), param_ratio, alpha=alpha, act_aware=act_aware,
+                             sigma_fuse=sigma_fuse, rank_align=rank_align)
+    return OracleTwoLinear(o["A"], o["B"], o["rank"])
+
+
+def parse_search_trace(lines):
+    """[(low, mid, high, value, ratio)] of the `low=.. mid=.., high=.., ppl=.., param_ratio=..` / `now_ratio=.., params=..` lines"""
+    import re
+    out = []
+    for l in lines:
+        m = re.match(r"low=(\d+) mid=(\d+), high=(\d+), (?:ppl|now_ratio)=([^,]+), (?:param_ratio=(.+)|params=\((.+)\))$", l)
+        if m:
+            out.append((int(m.group(1)), int(m.group(2)), int(m.group(3)), float(m.group(4)), m.group(5) or m.group(6)))
+    return out
+
+
+def proxy_linear(out_f, in_f):
+    """an nn.Linear of the given shape whose weight is ONE float expanded to [out, in]: numel / shape as the real layer, 4 bytes of storage"""
+    lin = nn.Linear(1, 1, bias=False)
+    lin.in_features, lin.out_features = in_f, out_f
+    lin.weight = nn.Parameter(torch.zeros(1, 1).expand(out_f, in_f), requires_grad=False)
+    return lin
+
+
+class ShapedLlama(nn.Module):
+    """the module tree (names, order, weight shapes) of a Llama checkpoint without its memory: search / sharding logic at model scale"""
+
+    def __init__(self, hidden=4096, inter=11008, layers=32, vocab=32000):
+        super().__init__()
+        self.model = nn.Module()
+        blocks = []
+        for _ in range(layers):
+            blk = nn.Module()
+            blk.self_attn = nn.Module()
+            for n in ("q_proj", "k_proj", "v_proj", "o_proj"):
+                setattr(blk.self_attn, n, proxy_linear(hidden, hidden))
+            blk.mlp = nn.Module()
+            blk.mlp.gate_proj, blk.mlp.up_proj, blk.mlp.down_proj = proxy_linear(inter, hidden), proxy_linear(inter, hidden), proxy_linear(hidden, inter)
+            blocks.append(blk)
+        self.model.layers = nn.ModuleList(blocks)
+        self.lm_head = proxy_linear(vocab, hidden)

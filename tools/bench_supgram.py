@@ -22,7 +22,9 @@ def main():
     ap.add_argument("--ns", type=int, default=64)
     ap.add_argument("--R", type=int, default=4096)
     ap.add_argument("--batch", type=int, default=32)
-    ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--reps", type=int, default=200)
+    ap.add_argument("--warm_s", type=float, default=1.5)
+    ap.add_argument("--ablate", type=int, default=0, help="measurement build only (timing-only, results wrong): 1 no panel stores, 2 no fetch, 4 no matrix instructions, 8 no LDS operand stores")
     a = ap.parse_args()
     if a.build_meas:
         from asvd4llm_amd import build as b
@@ -30,6 +32,8 @@ def main():
         return
     import torch
     from asvd4llm_amd import _lib as L
+    if a.ablate:
+        os.environ["ASVD_SG_ABLATE"] = str(a.ablate)
     if a.timing:
         lib = ctypes.CDLL(MEAS)
         lib.asvd_test_supgram.restype = ctypes.c_int
@@ -49,16 +53,21 @@ def main():
     done = torch.zeros(batch, dtype=torch.int32, device=gpu)
     nupd = torch.zeros(batch, dtype=torch.int32, device=gpu)
     Gx = torch.zeros(batch, npairs, 1, 6, 1024, device=gpu)
+    nrm2 = (X.double() ** 2).sum(dim=2)   # squared column norms, [batch, nb, 32]; step D = 1 pairs super-panels (2k, 2k + 1): columns 128 k .. + 127
+    Din = nrm2.reshape(batch, npairs, 128).float().contiguous()
     vp = ctypes.c_void_p
     st = torch.cuda.current_stream().cuda_stream
 
     def run():
         rc = lib.asvd_test_supgram(vp(X.data_ptr()), R * 32, nb * R * 32, ns, 1, 2, R, R, R, vp(Q.data_ptr()), vp(flags.data_ptr()),
-                                   vp(Gx.data_ptr()), vp(done.data_ptr()), vp(nupd.data_ptr()), 1, npairs, batch, vp(st))
+                                   vp(Din.data_ptr()), vp(Gx.data_ptr()), vp(done.data_ptr()), vp(nupd.data_ptr()), 1, npairs, batch, vp(st))
         assert rc == 0
-    for _ in range(3):
-        run()
-    torch.cuda.synchronize()
+    import time
+    t_w = time.time()
+    while time.time() - t_w < a.warm_s:   # DVFS settles over hundreds of milliseconds: a 10-launch measurement from idle reads the clock ramp, not the kernel
+        for _ in range(20):
+            run()
+        torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(a.reps):
@@ -68,20 +77,17 @@ def main():
     us = e0.elapsed_time(e1) * 1e3 / a.reps
     gb = 2 * X.numel() * 4 / 1e9
     tiles = (ns // 4) * batch * (R // 32) / 256.0   # 32-row tiles per CU
-    out = {"near_identity": a.near_identity, "us_per_launch": round(us, 1), "us_per_tile": round(us / tiles, 3), "TBps_rw": round(gb / us * 1e3 / 1e3, 3)}
+    out = {"near_identity": a.near_identity, "ablate": a.ablate, "us_per_launch": round(us, 1), "us_per_tile": round(us / tiles, 3), "TBps_rw": round(gb / us * 1e3 / 1e3, 3)}
     if a.timing:
-        buf = (ctypes.c_ulonglong * (2 * 64 * 10))()
+        buf = (ctypes.c_ulonglong * 20)()
         lib.asvd_test_sg_timing.restype = ctypes.c_int
         assert lib.asvd_test_sg_timing(buf) == 0
-        ts = torch.tensor(list(buf), dtype=torch.int64).view(2, 64, 10)
+        names = ["loop", "gram", "update", "barrier_1", "stash", "fetch", "stores", "opnd_split", "barrier_2"]
         for pr in range(2):
-            t = ts[pr, 8:56].double()   # steady state
-            seg = {"gram": (t[:, 1] - t[:, 0]).mean().item(), "update": (t[:, 2] - t[:, 1]).mean().item(), "bar_after_compute": (t[:, 3] - t[:, 2]).mean().item(),
-                   "memory": (t[:, 4] - t[:, 3]).mean().item(), "m_stash": (t[:, 6] - t[:, 3]).mean().item(), "m_fetch": (t[:, 7] - t[:, 6]).mean().item(),
-                   "m_stores": (t[:, 8] - t[:, 7]).mean().item(), "m_opnd": (t[:, 4] - t[:, 8]).mean().item(), "bar_after_memory": (t[:, 5] - t[:, 4]).mean().item(),
-                   "tile_period": (t[1:, 0] - t[:-1, 0]).mean().item()}
-            out[f"pair{pr}_cycles"] = {k: round(v) for k, v in seg.items()}
-        out["pair1_minus_pair0_start"] = round((ts[1, 8:56, 0] - ts[0, 8:56, 0]).double().mean().item())
+            n = max(1, int(buf[pr * 10 + 9]))
+            out[f"pair{pr}_cycles_per_tile"] = {names[i]: round(buf[pr * 10 + i] / n) for i in range(9)}
+            out[f"pair{pr}_cycles_per_tile"]["total"] = round(sum(buf[pr * 10 + i] for i in range(9)) / n)
+        out["shader_clock_GHz"] = round(out["pair0_cycles_per_tile"]["total"] / (us / tiles) / 1e3, 3)
     print(json.dumps(out), flush=True)
 
 

@@ -86,13 +86,14 @@ def main():
         done = torch.zeros(batch, dtype=torch.int32, device=gpu)
         nupd = torch.zeros(batch, dtype=torch.int32, device=gpu)
         Gx = torch.zeros(batch, npairs, 1, 6, 1024, device=gpu)
+        Din = (X.double() ** 2).sum(dim=2).reshape(batch, npairs, 128).float().contiguous()   # step D = 1 pairs super-panels (2k, 2k + 1)
         vp = ctypes.c_void_p
         st = torch.cuda.current_stream().cuda_stream
 
         def work():
             for _ in range(20):
                 lib.asvd_test_supgram(vp(X.data_ptr()), R * 32, nb * R * 32, ns, 1, 2, R, R, R, vp(Q.data_ptr()), vp(flags.data_ptr()),
-                                      vp(Gx.data_ptr()), vp(done.data_ptr()), vp(nupd.data_ptr()), 1, npairs, batch, vp(st))
+                                      vp(Din.data_ptr()), vp(Gx.data_ptr()), vp(done.data_ptr()), vp(nupd.data_ptr()), 1, npairs, batch, vp(st))
             torch.cuda.synchronize()
             return 20
     elif a.workload == "mfma":
