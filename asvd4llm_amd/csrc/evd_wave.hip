@@ -652,6 +652,11 @@ __global__ __launch_bounds__(128 * NW, NW == 1 ? 2 : 1) void evdw12_kernel(Sched
 #pragma unroll
             for (int r = 0; r < 32; ++r) tr[cc * 33 + r] = g[r];       // C[r][cc] -> tr[cc][r]
         }
+        // lanes 32..63 wrote, lanes 0..31 read: one wave, so program order is the only order there is — pinned for the compiler (no motion of
+        // the reads into the first `!hi` region above) and for the LDS queue
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (!hi) {
             const float* tr = R16 + sp * (32 * 33);
 #pragma unroll
@@ -940,11 +945,14 @@ static int evdq12_lds_bytes() { return (int)((E12_SMEM_FLOATS + 2 * Coop<EVDQ_NW
 
 void launch_evdw12(int npairs_s, int batch, hipStream_t st, const Sched& sc, unsigned* maxoff_bits, int* nrot, const int* done, float tol,
                    int inner_sweeps, int nb, int step, int kb, const EvdV3& v3) {
-    static bool attr_done = false;   // idempotent; a race only repeats the calls
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)evdw12_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, evdw12_lds_bytes());
-        (void)hipFuncSetAttribute((const void*)evdw12_kernel<EVDQ_NW>, hipFuncAttributeMaxDynamicSharedMemorySize, evdq12_lds_bytes());
-        attr_done = true;
+    // the > 64 KB dynamic-LDS opt-in is per device: one flag per device the process drives (idempotent; a race only repeats the calls)
+    static bool attr_done[64] = {};
+    int devid = 0;
+    (void)hipGetDevice(&devid);
+    if (devid < 0 || devid >= 64 || !attr_done[devid]) {
+        const hipError_t e1 = hipFuncSetAttribute((const void*)evdw12_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, evdw12_lds_bytes());
+        const hipError_t e2 = hipFuncSetAttribute((const void*)evdw12_kernel<EVDQ_NW>, hipFuncAttributeMaxDynamicSharedMemorySize, evdq12_lds_bytes());
+        if (e1 == hipSuccess && e2 == hipSuccess && devid >= 0 && devid < 64) attr_done[devid] = true;
     }
     // latency form when the launch cannot even give every CU one workgroup: four waves per solve (bit-identical results).  It needs one
     // full inner sweep per visit (the default) and the standard 32 phase pairs.  ASVD_EVDQ=0 / 1 forces the choice.

@@ -284,22 +284,28 @@ __global__ __launch_bounds__(256) void fullcheck_kernel(Sched sc, const float* _
     f32x16 acc[4];
 #pragma unroll
     for (int a = 0; a < 4; ++a) acc[a] = (f32x16){0};
+    const float* __restrict__ dnb = dn + (int64_t)b * n_pad;
+    // power-of-two column scale from the column's own squared norm (just measured by panel_sumsq_kernel): scaled columns have norm <= 2^SG_TARGET
+    auto col_exp = [&](float d) { return min(max(sg_half_exp(d), -60), 60) - SG_TARGET; };
     {
-        // split-bf16 (twolevel.h): each fp32 operand = three bf16 exactly, six products per fp32 product on the bf16 matrix pipe (2.7x less
-        // pipe time; the dropped terms are at fp32 rounding level, which a coupling test against tol = 1e-6 needs).  The operand of k-step
-        // ks of a panel is: lane (column cc, group hh) holds rows 16 ks + 8 hh + e, e = 0..7.  Every operand of a 32-row chunk is built
-        // ONCE per workgroup: thread t owns the slots (panel (t >> 7) + 2 j, k-step (t >> 6) & 1, lane t & 63), j = 0..3, loads its eight
-        // values straight from global memory (a wave-load covers two 128-byte row segments), splits them and stores the three parts as
-        // ready operands; the waves then only read 16-byte operands.  (Before: every wave split the four A panels and its own B panel
-        // itself from an fp32 LDS image — 40 splits and 80 scalar LDS reads per wave and chunk against 48 MFMAs.)
-        __shared__ u32x4 oimg[8 * 2 * 3 * 64];
+        // split-fp16 with power-of-two column scales (twolevel.h, round 4): each fp32 operand = two fp16 numbers (22 bits), three products per fp32
+        // product on the fp16 matrix pipe — a cosine is resolved to 2^-22 of the norm product, what a coupling test against tol = 1e-6 needs, at
+        // half the matrix work of the six-product bf16 form of rounds 2-3.  The operand of k-step ks of a panel is: lane (column cc, group hh) holds
+        // rows 16 ks + 8 hh + e, e = 0..7.  Every operand of a 32-row chunk is built ONCE per workgroup: thread t owns the slots (panel
+        // (t >> 7) + 2 j, k-step (t >> 6) & 1, lane t & 63), j = 0..3, loads its eight values — one column, so ONE scale — straight from global
+        // memory (a wave-load covers two 128-byte row segments), splits them and stores the two parts as ready operands; the waves then only
+        // read 16-byte operands.
+        __shared__ u32x4 oimg[8 * 2 * 2 * 64];
         const int sks = (tid >> 6) & 1, sl = tid & 63;
         const float* src[4];
+        float mulc[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int q = (tid >> 7) + 2 * j;
             const int pnl = (q < 4) ? ig * 4 + q : jg * 4 + q - 4;
-            src[j] = Xb + (int64_t)(pnl < nb ? pnl : nb - 1) * panel_stride + (int64_t)(16 * sks + 8 * (sl >> 5)) * PB + (sl & 31);
+            const int pc = pnl < nb ? pnl : nb - 1;
+            src[j] = Xb + (int64_t)pc * panel_stride + (int64_t)(16 * sks + 8 * (sl >> 5)) * PB + (sl & 31);
+            mulc[j] = ldexpf(1.0f, -col_exp(dnb[pc * PB + (sl & 31)]));
         }
         float pre[4][8];
         auto fetch = [&](int r0) {
@@ -313,52 +319,48 @@ __global__ __launch_bounds__(256) void fullcheck_kernel(Sched sc, const float* _
             __syncthreads();  // previous chunk's operands fully consumed
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                u32x4 p1, p2, p3;
+                u32x4 p1, p2;
 #pragma unroll
                 for (int e2 = 0; e2 < 4; ++e2) {
-                    unsigned x, y, z;
-                    split3(pre[j][2 * e2], pre[j][2 * e2 + 1], x, y, z);
-                    p1[e2] = x; p2[e2] = y; p3[e2] = z;
+                    unsigned x, y;
+                    split2(pre[j][2 * e2] * mulc[j], pre[j][2 * e2 + 1] * mulc[j], x, y);
+                    p1[e2] = x; p2[e2] = y;
                 }
-                u32x4* o = oimg + ((((tid >> 7) + 2 * j) * 2 + sks) * 3) * 64 + sl;
-                o[0] = p1; o[64] = p2; o[128] = p3;
+                u32x4* o = oimg + ((((tid >> 7) + 2 * j) * 2 + sks) * 2) * 64 + sl;
+                o[0] = p1; o[64] = p2;
             }
             __syncthreads();
             if (r0 + 32 < m_pad) fetch(r0 + 32);
-            // eight stages (k-step, A panel) of six MFMAs; the operands of stage i + 1 are read from LDS before the MFMAs of stage i are
+            // eight stages (k-step, A panel) of three MFMAs; the operands of stage i + 1 are read from LDS before the MFMAs of stage i are
             // issued (left to the compiler each ds_read sat in front of its consumer: 51 % of the wave cycles waiting to issue)
-            struct Op3 { bf16x8 p1, p2, p3; };
-            auto ld3 = [&](int slot, int ks) {
-                const u32x4* o = oimg + ((slot * 2 + ks) * 3) * 64 + lane;
-                Op3 r;
-                r.p1 = __builtin_bit_cast(bf16x8, o[0]); r.p2 = __builtin_bit_cast(bf16x8, o[64]); r.p3 = __builtin_bit_cast(bf16x8, o[128]);
+            struct Op2 { h16x8 p1, p2; };
+            auto ld2 = [&](int slot, int ks) {
+                const u32x4* o = oimg + ((slot * 2 + ks) * 2) * 64 + lane;
+                Op2 r;
+                r.p1 = __builtin_bit_cast(h16x8, o[0]); r.p2 = __builtin_bit_cast(h16x8, o[64]);
                 return r;
             };
-            Op3 Bc = ld3(4 + w, 0), Ac = ld3(0, 0);
+            Op2 Bc = ld2(4 + w, 0), Ac = ld2(0, 0);
 #pragma unroll
             for (int st = 0; st < 8; ++st) {
-                const int ks = st >> 2, a = st & 3;
-                Op3 An = Ac, Bn = Bc;
-                if (st + 1 < 8) An = ld3((st + 1) & 3, (st + 1) >> 2);
-                if (st == 3) Bn = ld3(4 + w, 1);
+                const int a = st & 3;
+                Op2 An = Ac, Bn = Bc;
+                if (st + 1 < 8) An = ld2((st + 1) & 3, (st + 1) >> 2);
+                if (st == 3) Bn = ld2(4 + w, 1);
                 __builtin_amdgcn_sched_barrier(0);
-                acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ac.p3, Bc.p1, acc[a], 0, 0, 0);
-                acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ac.p1, Bc.p3, acc[a], 0, 0, 0);
-                acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ac.p2, Bc.p2, acc[a], 0, 0, 0);
-                acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ac.p2, Bc.p1, acc[a], 0, 0, 0);
-                acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ac.p1, Bc.p2, acc[a], 0, 0, 0);
-                acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ac.p1, Bc.p1, acc[a], 0, 0, 0);
+                acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ac.p2, Bc.p1, acc[a], 0, 0, 0);
+                acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ac.p1, Bc.p2, acc[a], 0, 0, 0);
+                acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ac.p1, Bc.p1, acc[a], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 Ac = An;
                 if (st == 3) Bc = Bn;
-                (void)ks;
             }
         }
     }
     if (J >= nb) return;
     const int h = lane >> 5, c = lane & 31;
-    const float* __restrict__ dnb = dn + (int64_t)b * n_pad;
     const float dj = dnb[J * PB + c];
+    const int ej = col_exp(dj);
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
         if (!ok[a]) continue;
@@ -369,7 +371,7 @@ __global__ __launch_bounds__(256) void fullcheck_kernel(Sched sc, const float* _
             const int i = (reg & 3) + 8 * (reg >> 2) + 4 * h;
             if (I == J && i == c) continue;
             const float di = dnb[I * PB + i];
-            const float g = acc[a][reg];
+            const float g = ldexpf(acc[a][reg], col_exp(di) + ej);   // back to the scale of the data
             const float dd = di * dj;
             float x = (dd > 0.0f) ? fabsf(g) * rsqrtf(dd) : 0.0f;
             if (g != g || dd != dd) x = __builtin_nanf("");

@@ -42,8 +42,10 @@ __device__ __forceinline__ void grid_barrier(unsigned* bar, unsigned nwg) {
     // reusable.  The generation is read BEFORE this workgroup arrives: both words sit in one 128-byte line (one L2 channel serves its
     // requests in issue order) and the compiler barrier keeps the program order.  The spin is BOUNDED: the launch is not cooperative, so
     // co-residency of the <= #CUs workgroups is an assumption (another stream's persistent kernel could hold CUs); after ~2^22 polls a
-    // waiter sets bar[2] and leaves instead of hanging the GPU — the output of that launch is then incomplete and the flag says so
-    // (asvd_lowrank_forward_f16's `work`, word 2; the Python module checks it when ASVD_DEBUG is set).
+    // waiter sets bar[2] and leaves instead of hanging the GPU.  What it computes next comes from an incomplete z, so the failure is made
+    // VISIBLE: every workgroup ends with poison_if_gave_up(), which overwrites its slice of y with NaN when the flag is set.  (A waiter gives
+    // up only while the barrier is incomplete, so every workgroup that passes normally does so AFTER the flag was set and sees it at its end.)
+    // ops.lowrank_forward additionally reads and clears the word under ASVD_STRICT / ASVD_DEBUG and raises.
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's z stores have been acknowledged (s_waitcnt vmcnt(0)); no L2 write-back
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -66,6 +68,12 @@ __device__ __forceinline__ void grid_barrier(unsigned* bar, unsigned nwg) {
         }
     }
     __syncthreads();
+}
+
+// last statement of both kernels: a launch in which some workgroup left the barrier without its peers has no valid output
+__device__ __forceinline__ void poison_if_gave_up(const unsigned* bar, uint16_t* __restrict__ y, int64_t count) {
+    if (__hip_atomic_load(&bar[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (int64_t)gridDim.x * blockDim.x) y[e] = 0x7e00;  // fp16 NaN
 }
 
 // One 32 x 32 output tile  C[i][j] = sum_k P[prow0+i][k] * Q[qrow0+j][k]  over k in [0, 64*nk), fp32, all four waves.
@@ -160,6 +168,7 @@ __global__ __launch_bounds__(256, 1) void lowrank_forward_kernel(const uint16_t*
         }
         __syncthreads();
     }
+    poison_if_gave_up(bar, y, (int64_t)T * N);
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -248,6 +257,8 @@ __global__ __launch_bounds__(512, 1) void lowrank_gemv_kernel(const uint16_t* __
     for (int e = tid; e < TT * r8; e += 512) gv_smem[e] = z_load16((const uint4*)z + e);
     __syncthreads();
     gemv_rows<TT, false>(wv, (const uint4*)Ap, r8, N, r8, gv_smem, gw, nw, lane, y, N, bias, T);
+    __syncthreads();
+    poison_if_gave_up(bar, y, (int64_t)T * N);
 }
 
 }  // namespace

@@ -463,7 +463,7 @@ __global__ __launch_bounds__(512, 1) void supgram_kernel(Sched sc, float* __rest
         f32x4 preA[2][2];   // one tile in flight per pair and thread (two in flight — 64 KB of loads per CU — measured slower: 1008 vs 895 us per launch)
         float mul[2][8];   // 2^-ein of the piece's eight columns
         int dst[2];
-        const float* src[2];
+        const float* src[2];   // per-lane pointers of the two pieces in tile 0
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
             const int q = (tid & 255) + 256 * jj, lp = q >> 7, row = (q & 127) >> 2;
@@ -540,7 +540,6 @@ __global__ __launch_bounds__(512, 1) void supgram_kernel(Sched sc, float* __rest
             return r;
         };
         const int glag = mypr ? 1 : 2;   // pair A accumulates the Gram units of tile t - 2 next to update t, pair B those of tile t - 1
-        float* __restrict__ Pst = Pw + (int64_t)r_begin * PB + (4 * h) * PB + c;   // this lane's first output element of tile 0
 
         // ---- prologue: tile 0 staged, tile 1 in flight ----
         fetch(0, preA);
@@ -595,13 +594,6 @@ __global__ __launch_bounds__(512, 1) void supgram_kernel(Sched sc, float* __rest
             SG_TS(4);
             if (t + 2 < ntiles && !SG_ABL(2)) fetch(t + 2, pre);   // into the registers the stash has just emptied
             SG_TS(5);
-            if (mine && !SG_ABL(1)) {
-                // sixteen 4-byte stores per lane (two full 128-byte rows per instruction).  Measured and dropped: the tile through 4 KB of wave-private LDS
-                // (ds_write_b32 in the C layout, ds_read_b128 along the rows) and out as four 16-byte stores per lane — 1047 vs 893 us per launch.
-                float* __restrict__ po = Pst + (int64_t)t * (32 * PB);
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) po[((reg & 3) + 8 * (reg >> 2)) * PB] = acc[reg] * oscale;
-            }
             SG_TS(6);
             if (r_begin + 32 * t < m_pad && !SG_ABL(8)) {
                 u32x4* ow = opnd0 + (t & 1) * OPND_VECS;
@@ -617,6 +609,17 @@ __global__ __launch_bounds__(512, 1) void supgram_kernel(Sched sc, float* __rest
                     u32x4* o = ow + ((otp * 2 + k2) * 2) * 64 + lane;
                     o[0] = p1; o[64] = p2;
                 }
+            }
+            if (mine && !SG_ABL(1)) {
+                // Panel stores, LAST in the segment and with the address formed per tile: sixteen 4-byte stores per lane (two full 128-byte rows per
+                // instruction).  This kernel waits for its vector-memory pipe (no stores: 769 instead of 1011 us per launch), and what was measured there
+                // does not follow a model: the same sixteen stores right behind the fetch cost 995 us per launch when their per-lane address is kept in a
+                // register pair across the loop, 893 when it is recomputed in front of them (four more VALU instructions), 884 when they are issued after
+                // the operand split — reproduced binary by binary on one box (profiles/r4_supgram_variants.txt).  Measured and dropped: the tile through
+                // 4 KB of wave-private LDS and out as four 16-byte row stores per lane (1047 us); two tiles of loads in flight (1008 us).
+                float* __restrict__ po = Pw + (int64_t)(r_begin + 32 * t + 4 * h) * PB + c;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) po[((reg & 3) + 8 * (reg >> 2)) * PB] = acc[reg] * oscale;
             }
             SG_TS(7);
             __syncthreads();

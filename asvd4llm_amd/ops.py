@@ -318,6 +318,14 @@ def lowrank_forward(x2d, Ap, Bp, bias, work):
     with _on(x2d.device):
         L.check(lib.asvd_lowrank_forward_f16(_ptr(x2d), T, _ptr(Bp), _ptr(Ap), _ptr(bias), N, K, rp, _ptr(y), _ptr(work), work.numel(),
                                              _stream(x2d)), "asvd_lowrank_forward_f16")
+    if os.environ.get("ASVD_STRICT") == "1" or os.environ.get("ASVD_DEBUG"):
+        # word 2 of the barrier state: some workgroup left the in-kernel grid barrier without its peers (the workgroups of the launch were not all
+        # resident); the kernel has poisoned y with NaN in that case — here the condition is reported and the word cleared for the next launch
+        flags = work[:16].view(torch.int32)
+        if int(flags[2].item()) != 0:
+            flags[2] = 0
+            raise L.AsvdHipError("asvd_lowrank_forward_f16: a workgroup gave up at the in-kernel grid barrier (the launch was not fully resident); "
+                                 "output poisoned with NaN.  Use the two nn.Linear GEMMs (fused_forward = False) next to persistent kernels of other streams.")
     return y
 
 

@@ -82,7 +82,7 @@ def main():
         buf = (ctypes.c_ulonglong * 20)()
         lib.asvd_test_sg_timing.restype = ctypes.c_int
         assert lib.asvd_test_sg_timing(buf) == 0
-        names = ["loop", "gram", "update", "barrier_1", "stash", "fetch", "stores", "opnd_split", "barrier_2"]
+        names = ["loop", "gram", "update", "barrier_1", "stash", "fetch", "-", "opnd_split+stores", "barrier_2"]
         for pr in range(2):
             n = max(1, int(buf[pr * 10 + 9]))
             out[f"pair{pr}_cycles_per_tile"] = {names[i]: round(buf[pr * 10 + i] / n) for i in range(9)}
