@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256) void fullcheck_kernel(Sched sc, const float* _
 #pragma unroll
                 for (int e2 = 0; e2 < 4; ++e2) {
                     unsigned x, y;
-                    split2(pre[j][2 * e2] * mulc[j], pre[j][2 * e2 + 1] * mulc[j], x, y);
+                    split2s(pre[j][2 * e2], pre[j][2 * e2 + 1], mulc[j], mulc[j], x, y);
                     p1[e2] = x; p2[e2] = y;
                 }
                 u32x4* o = oimg + ((((tid >> 7) + 2 * j) * 2 + sks) * 2) * 64 + sl;

@@ -304,12 +304,26 @@ __device__ __forceinline__ int sg_half_exp(float d) {
     if (bits <= 0 || ex == 0 || ex == 255) return -200;
     return (ex - 126 + 1) >> 1;   // d = f 2^p, f in [0.5, 1), p = ex - 126: ceil(p / 2)
 }
-// two fp32 -> (h1, h2) with x ~ h1 + h2 (22 bits)
+// two fp32 -> packed (h1, h2) fp16 pairs with x ~ h1 + h2 (22 bits).  Written out as the instructions they should be: left to the compiler a pair
+// cost 7 VALU instructions (it rounds h1 twice: once packed with v_cvt_pk_f16_f32 behind two v_mul, once per half with v_fma_mixlo_f16 to feed the
+// residual); here 4 with a scale (3 without): v_fma_mix{lo,hi}_f16 evaluate fma(x, m, -h1) in fp32 from mixed fp32 / fp16 sources and round once.
+//   split2s: h1 = fp16(x m), h2 = fp16(x m - h1), m a power of two (x m exact)          split2: the same with m = 1
+__device__ __forceinline__ void split2s(float x0, float x1, float m0, float m1, unsigned& p1, unsigned& p2) {
+    unsigned h1, h2;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h1) : "v"(x0), "v"(m0));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h1) : "v"(x1), "v"(m1));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(h2) : "v"(x0), "v"(m0), "v"(h1));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(h2) : "v"(x1), "v"(m1), "v"(h1));
+    p1 = h1;
+    p2 = h2;
+}
 __device__ __forceinline__ void split2(float x0, float x1, unsigned& p1, unsigned& p2) {
-    const h16x2 a = {(_Float16)x0, (_Float16)x1};
-    const h16x2 r = {(_Float16)(x0 - (float)a[0]), (_Float16)(x1 - (float)a[1])};
-    p1 = __builtin_bit_cast(unsigned, a);
-    p2 = __builtin_bit_cast(unsigned, r);
+    unsigned h1, h2;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h1) : "v"(x0), "v"(x1));
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(h2) : "v"(x0), "v"(h1));
+    asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(h2) : "v"(x1), "v"(h1));
+    p1 = h1;
+    p2 = h2;
 }
 
 #ifdef ASVD_SG_TIMING   // tools/bench_supgram.py --timing: shader cycles per stage of the tile loop, summed in scalar registers (no memory traffic in
@@ -492,10 +506,10 @@ __global__ __launch_bounds__(512, 1) void supgram_kernel(Sched sc, float* __rest
             for (int jj = 0; jj < 2; ++jj) {
                 u32x4 p1, p2;
                 unsigned x, y;
-                split2(pre[jj][0][0] * mul[jj][0], pre[jj][0][1] * mul[jj][1], x, y); p1[0] = x; p2[0] = y;
-                split2(pre[jj][0][2] * mul[jj][2], pre[jj][0][3] * mul[jj][3], x, y); p1[1] = x; p2[1] = y;
-                split2(pre[jj][1][0] * mul[jj][4], pre[jj][1][1] * mul[jj][5], x, y); p1[2] = x; p2[2] = y;
-                split2(pre[jj][1][2] * mul[jj][6], pre[jj][1][3] * mul[jj][7], x, y); p1[3] = x; p2[3] = y;
+                split2s(pre[jj][0][0], pre[jj][0][1], mul[jj][0], mul[jj][1], x, y); p1[0] = x; p2[0] = y;
+                split2s(pre[jj][0][2], pre[jj][0][3], mul[jj][2], mul[jj][3], x, y); p1[1] = x; p2[1] = y;
+                split2s(pre[jj][1][0], pre[jj][1][1], mul[jj][4], mul[jj][5], x, y); p1[2] = x; p2[2] = y;
+                split2s(pre[jj][1][2], pre[jj][1][3], mul[jj][6], mul[jj][7], x, y); p1[3] = x; p2[3] = y;
                 u32x4* o = aimg + dst[jj];
                 o[0] = p1; o[SG_BLK] = p2;
             }
@@ -616,7 +630,8 @@ __global__ __launch_bounds__(512, 1) void supgram_kernel(Sched sc, float* __rest
                 // does not follow a model: the same sixteen stores right behind the fetch cost 995 us per launch when their per-lane address is kept in a
                 // register pair across the loop, 893 when it is recomputed in front of them (four more VALU instructions), 884 when they are issued after
                 // the operand split — reproduced binary by binary on one box (profiles/r4_supgram_variants.txt).  Measured and dropped: the tile through
-                // 4 KB of wave-private LDS and out as four 16-byte row stores per lane (1047 us); two tiles of loads in flight (1008 us).
+                // 4 KB of wave-private LDS and out as four 16-byte row stores per lane (1047 us); 4 x 4 transposes inside the lane quads (DPP quad_perm, 64
+                // VALU per tile) and four 16-byte stores per lane (889 vs 884: the store COUNT is not what it waits for); two tiles of loads in flight (1008 us).
                 float* __restrict__ po = Pw + (int64_t)(r_begin + 32 * t + 4 * h) * PB + c;
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) po[((reg & 3) + 8 * (reg >> 2)) * PB] = acc[reg] * oscale;

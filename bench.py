@@ -325,7 +325,7 @@ def main():
         # HBM traffic of the dominant kernel comes from PMC counters, which need their own rocprofv3 passes (tools/prof_final.sh): the
         # stored figure is only quoted when it was collected from THIS build of the library (sha256 of libasvd_hip.so recorded with it)
         # on this workload — a kernel change since then prints null instead of a stale "measured" number
-        traffic, traffic_src = None, None
+        traffic, traffic_src, mfma_busy, pmc_clock = None, None, None, None
         try:
             import hashlib
             lib_sha = hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()
@@ -333,16 +333,22 @@ def main():
             if dom in pmc.get("kernels", {}) and (m, n, B) == (4096, 4096, pmc.get("batch")):
                 if pmc.get("lib_sha256") == lib_sha:
                     traffic = pmc["kernels"][dom]["hbm_bytes_per_launch"]
-                    traffic_src = "stored: " + pmc.get("source", "profiles/pmc_traffic.json") + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, same libasvd_hip.so)"
+                    mfma_busy = pmc["kernels"][dom].get("mfma_busy_frac")
+                    pmc_clock = pmc["kernels"][dom].get("shader_clock_GHz_under_pmc")
+                    traffic_src = "stored: " + pmc.get("source", "profiles/pmc_traffic.json") + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / MFMA-busy / GRBM passes of this command, same libasvd_hip.so)"
                 else:
-                    traffic_src = "not quoted: profiles/pmc_traffic.json was collected from a different build of libasvd_hip.so (re-run tools/prof_final.sh)"
+                    traffic_src = "not quoted: profiles/pmc_traffic.json was collected from a different build of libasvd_hip.so (re-run tools/reproduce_evidence.sh prof)"
         except Exception:
             pass
         if dom in alg:
             ach = alg[dom] / (classes[dom]["avg_us"] * 1e-6) / 1e9
             roofline = {"bound": "hbm", "kernel": {"supdate": "supdate_split_kernel", "sgram": "sgram6_kernel", "supgram": "supgram_kernel"}[dom], "achieved": ach, "peak": 8000.0,
                         "unit": "GB/s", "frac": ach / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
+                        "frac_of_measured_copy_rate_6290GBps": ach / 6290.0, "matrix_pipe_busy_frac": mfma_busy, "shader_clock_GHz_under_pmc": pmc_clock,
                         "algorithmic_bytes_per_launch": alg[dom], "avg_launch_us": classes[dom]["avg_us"],
+                        "bound_evidence": "the kernel sits on the 1400 W socket cap (profiles/r4_power.jsonl: amdsmi samples next to back-to-back launches), which holds the shader "
+                                          "clock at 1.6-1.9 GHz, and at that clock on the memory path of the CUs (~10 B/clk/CU): removing the panel stores is the only ablation "
+                                          "that shortens it (DESIGN.md 3.10); the fp16 matrix pipe is about a third busy (33 MFMAs per wave and tile)",
                         "note": "dominant streaming kernel by total time; bytes from the library's own counters of the profiled step, duration = HIP "
                                 "events around every launch on the launch stream, averaged over ALL its launches (one stream: nothing else runs beside it)"}
         else:
@@ -351,7 +357,7 @@ def main():
         achieved = f_svd * (value / world) / 1e12  # algorithmic TFLOP/s per GPU of the whole SVD job, from the timed region's wall clock
         roofline["svd_level"] = {"bound": "mfma", "unit_of_work": "one economy SVD, F = 14 m n^2 + 8 n^3", "achieved": achieved, "peak": 157.3,
                                  "unit": "TFLOP/s", "frac": achieved / 157.3,
-                                 "note": "fp32-MFMA peak as the yardstick (SURVEY 8d); the update pass itself runs split-bf16 on the bf16 matrix pipe"}
+                                 "note": "fp32-MFMA peak as the yardstick (SURVEY 8d); the streaming products run split-fp16 / split-bf16 on the 16-bit matrix pipes (3 / 6 products per fp32 product), so this fraction does not bound what executes"}
         if two_level:
             roofline["streaming_kernels"] = {k: {"GBps": alg[k] / (classes[k]["avg_us"] * 1e-6) / 1e9, "frac_of_8TBps": alg[k] / (classes[k]["avg_us"] * 1e-6) / 8e12,
                                                  "avg_launch_us": classes[k]["avg_us"], "algorithmic_bytes_per_launch": alg[k]}

@@ -20,6 +20,8 @@ res = {"batch": int(os.environ.get("PMC_BATCH", "16")), "lib_sha256": hashlib.sh
        "note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes of `python bench.py --no_cpu_baseline --no_latency --steps 1 --warmup 0 --prewarm_s 0` "
                "(" + os.environ.get("PMC_BATCH", "16") + " x 4096x4096 fp32, one stream); mean per dispatch over all launches of the run; FETCH doubled (gfx950 half-count), WRITE as reported",
        "kernels": {}}
+busy = table(os.path.join(d, "pmc_SQ_VALU_MFMA_BUSY_CYCLES_SQ_BUSY_CYCLES_SQ_W.txt"))
+grbm = table(os.path.join(d, "pmc_GRBM_GUI_ACTIVE_GRBM_COUNT.txt"))
 for key, kn in names.items():
     f = [v for (n, c), v in fetch.items() if kn in n and c == "FETCH_SIZE"]
     w = [v for (n, c), v in write.items() if kn in n and c == "WRITE_SIZE"]
@@ -29,4 +31,14 @@ for key, kn in names.items():
     wk = sum(x["avg"] * x["calls"] for x in w) / max(1, sum(x["calls"] for x in w)) if w else 0.0
     res["kernels"][key] = {"fetch_kib_raw": fk, "write_kib": wk, "hbm_bytes_per_launch": int(2 * fk * 1024 + wk * 1024),
                            "launches": sum(x["calls"] for x in f) if f else sum(x["calls"] for x in w)}
+    # matrix-pipe occupancy and shader clock of the same kernel (their own passes): SQ_VALU_MFMA_BUSY_CYCLES is summed over the SIMDs of a shader
+    # engine and averaged over the 32 engines by the summary (32 x 32 = 1024 SIMDs); GRBM_GUI_ACTIVE = shader cycles the dispatch was active
+    mb = [v for (n, c), v in busy.items() if kn in n and c == "SQ_VALU_MFMA_BUSY_CYCLES"]
+    ga = [v for (n, c), v in grbm.items() if kn in n and c == "GRBM_GUI_ACTIVE"]
+    if mb and ga:
+        mbusy = sum(x["avg"] * x["calls"] for x in mb) / max(1, sum(x["calls"] for x in mb))
+        gact = sum(x["avg"] * x["calls"] for x in ga) / max(1, sum(x["calls"] for x in ga))
+        gdur = sum(x["avg_dur_us"] * x["calls"] for x in ga) / max(1, sum(x["calls"] for x in ga))
+        res["kernels"][key].update({"mfma_busy_cycles_avg": mbusy, "gui_active_cycles": gact, "mfma_busy_frac": (mbusy * 32 / 1024) / gact if gact else None,
+                                    "shader_clock_GHz_under_pmc": gact / gdur / 1e3 if gdur else None})
 print(json.dumps(res, indent=1))

@@ -1,16 +1,21 @@
 #!/bin/bash
-# Reproduces the round's evidence on one MI355X (about 45 minutes).  Round 3 used tools/r3_final.sh (same steps, PMC passes first so that the
-# bench line carries roofline.traffic of the same library binary).  Outputs under gpurun_out/; copy what should be kept to profiles/.
-#   bash tools/reproduce_evidence.sh            # everything
-#   bash tools/reproduce_evidence.sh quick      # tests + smoke + bench only (about 10 minutes)
+# Reproduces the round's evidence on one MI355X.  Outputs under gpurun_out/; copy what should be kept to profiles/ (named r<round>_*).
+#   bash tools/reproduce_evidence.sh            # everything (about 60 minutes)
+#   bash tools/reproduce_evidence.sh quick      # tests + smoke + bench only (about 20 minutes)
+#   bash tools/reproduce_evidence.sh prof       # rocprofv3 kernel stats + PMC passes + power telemetry + bench (about 12 minutes): run this one
+#                                               # FIRST after a library change: it writes profiles/pmc_traffic.json's source, which bench.py quotes
+#                                               # as roofline.traffic only when it was collected from the SAME libasvd_hip.so (sha256)
 set -u
 mkdir -p gpurun_out
 export ASVD_STRICT=1
 python -c "import __graft_entry__ as g; g.build(); g.smoke()" 2>&1 | tail -1
-python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed" | tail -2
-python bench.py > gpurun_out/bench.json 2> gpurun_out/bench.err && tail -c 600 gpurun_out/bench.json
+[ "${1:-all}" = prof ] || python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed" | tail -2
+[ "${1:-all}" = prof ] || { python bench.py > gpurun_out/bench.json 2> gpurun_out/bench.err && tail -c 600 gpurun_out/bench.json; }
 [ "${1:-all}" = quick ] && exit 0
 PMC_BATCH=32 bash tools/prof_final.sh repro > gpurun_out/prof_repro.log 2>&1   # rocprofv3 kernel stats + FETCH/WRITE/MFMA counter passes
+for w in idle mfma supgram supgram_ni bench; do python tools/power_probe.py --workload $w --seconds 6 --out gpurun_out/power.jsonl > /dev/null 2>&1; done   # socket power / clock / cap
+python tools/bench_supgram.py > gpurun_out/supgram_micro.jsonl 2> /dev/null
+[ "${1:-all}" = prof ] && exit 0
 python tools/full_model_bench.py --model llama-2-7b 2>/dev/null | tail -1 > gpurun_out/full_7b.json
 python tools/full_model_bench.py --model llama-2-13b 2>/dev/null | tail -1 > gpurun_out/full_13b.json
 python tools/cpu_baseline_full.py --out gpurun_out/cpu_full_model.json > /dev/null 2>&1
