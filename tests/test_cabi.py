@@ -55,7 +55,9 @@ def test_host_side_queries(built_lib):
     assert lib.asvd_svd_worksize(1, 4, 4, 1, None) == -1
     assert lib.asvd_absstat_worksize(2048, 4096, ctypes.byref(nb)) == 0 and nb.value > 0
     assert lib.asvd_absstat_worksize(0, 4096, ctypes.byref(nb)) == -1
-    assert lib.asvd_reconstruct_worksize(4096, 4096, ctypes.byref(nb)) == 0 and nb.value == 64 * 64 * 16
+    # partial sums (64 x 64 tiles x 2 doubles) + zero-padded K-contiguous copies of the 16-bit factors ((m + n) x rp x 2 bytes)
+    assert lib.asvd_reconstruct_worksize(4096, 4096, 512, ctypes.byref(nb)) == 0 and nb.value == 64 * 64 * 16 + (4096 + 4096) * 512 * 2
+    assert lib.asvd_reconstruct_worksize(4096, 4096, 0, ctypes.byref(nb)) == -1
     assert lib.asvd_fro_worksize(4096, 4096, ctypes.byref(nb)) == 0
 
 
