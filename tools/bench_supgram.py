@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--reps", type=int, default=200)
     ap.add_argument("--warm_s", type=float, default=1.5)
+    ap.add_argument("--pad_rows", type=int, default=0, help="extra rows per panel in the allocation: panel stride (R + pad_rows) * 128 B instead of a power of two")
     ap.add_argument("--ablate", type=int, default=0, help="measurement build only (timing-only, results wrong): 1 no panel stores, 2 no fetch, 4 no matrix instructions, 8 no LDS operand stores")
     a = ap.parse_args()
     if a.build_meas:
@@ -43,7 +44,9 @@ def main():
     gpu = torch.device("cuda:0")
     ns, R, batch = a.ns, a.R, a.batch
     nb, npairs = 2 * ns, ns // 2
-    X = torch.randn(batch, nb, R, 32, device=gpu) * 0.05
+    Rs = R + a.pad_rows   # rows allocated per panel
+    Xfull = torch.randn(batch, nb, Rs, 32, device=gpu) * 0.05
+    X = Xfull[:, :, :R]
     if a.near_identity:
         Q = torch.linalg.qr(torch.eye(128, device=gpu) + 1e-3 * torch.randn(npairs, 128, 128, device=gpu))[0]
     else:
@@ -59,7 +62,7 @@ def main():
     st = torch.cuda.current_stream().cuda_stream
 
     def run():
-        rc = lib.asvd_test_supgram(vp(X.data_ptr()), R * 32, nb * R * 32, ns, 1, 2, R, R, R, vp(Q.data_ptr()), vp(flags.data_ptr()),
+        rc = lib.asvd_test_supgram(vp(Xfull.data_ptr()), Rs * 32, nb * Rs * 32, ns, 1, 2, R, R, R, vp(Q.data_ptr()), vp(flags.data_ptr()),
                                    vp(Din.data_ptr()), vp(Gx.data_ptr()), vp(done.data_ptr()), vp(nupd.data_ptr()), 1, npairs, batch, vp(st))
         assert rc == 0
     import time
@@ -77,7 +80,7 @@ def main():
     us = e0.elapsed_time(e1) * 1e3 / a.reps
     gb = 2 * X.numel() * 4 / 1e9
     tiles = (ns // 4) * batch * (R // 32) / 256.0   # 32-row tiles per CU
-    out = {"near_identity": a.near_identity, "ablate": a.ablate, "us_per_launch": round(us, 1), "us_per_tile": round(us / tiles, 3), "TBps_rw": round(gb / us * 1e3 / 1e3, 3)}
+    out = {"near_identity": a.near_identity, "pad_rows": a.pad_rows, "lib": os.path.basename(os.environ.get("ASVD_HIP_LIB", "default")), "ablate": a.ablate, "us_per_launch": round(us, 1), "us_per_tile": round(us / tiles, 3), "TBps_rw": round(gb / us * 1e3 / 1e3, 3)}
     if a.timing:
         buf = (ctypes.c_ulonglong * 20)()
         lib.asvd_test_sg_timing.restype = ctypes.c_int

@@ -20,8 +20,12 @@ res = {"batch": int(os.environ.get("PMC_BATCH", "16")), "lib_sha256": hashlib.sh
        "note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes of `python bench.py --no_cpu_baseline --no_latency --steps 1 --warmup 0 --prewarm_s 0` "
                "(" + os.environ.get("PMC_BATCH", "16") + " x 4096x4096 fp32, one stream); mean per dispatch over all launches of the run; FETCH doubled (gfx950 half-count), WRITE as reported",
        "kernels": {}}
-busy = table(os.path.join(d, "pmc_SQ_VALU_MFMA_BUSY_CYCLES_SQ_BUSY_CYCLES_SQ_W.txt"))
-grbm = table(os.path.join(d, "pmc_GRBM_GUI_ACTIVE_GRBM_COUNT.txt"))
+import glob
+def first(pattern):
+    m = sorted(glob.glob(os.path.join(d, pattern)))
+    return m[0] if m else os.path.join(d, "missing")
+busy = table(first("pmc_SQ_VALU_MFMA_BUSY*.txt"))
+grbm = table(first("pmc_GRBM_GUI_ACTIVE*.txt"))
 for key, kn in names.items():
     f = [v for (n, c), v in fetch.items() if kn in n and c == "FETCH_SIZE"]
     w = [v for (n, c), v in write.items() if kn in n and c == "WRITE_SIZE"]
