@@ -484,38 +484,10 @@ __global__ __launch_bounds__(512, 1) void supgram_kernel(Sched sc, float* __rest
             const int k = 32 * lp + 8 * (q & 3);
             dst[jj] = ((mypr * 8 + (k >> 4)) * 2) * SG_BLK + ((k >> 3) & 1) * SG_HB + row;
             const int sp = Pof(jj ? mT : mS);   // jj = 0: pieces of S (lp = 0, 1), jj = 1: pieces of T (lp = 2, 3)
-#ifdef ASVD_SG_PF2
-            src[jj] = Xb + (int64_t)(2 * (sp < ns ? sp : 0) + (lp & 1)) * panel_stride + (int64_t)r_begin * PB + (q & 127) * 8;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) mul[jj][e] = sp < ns ? ldexpf(1.0f, -ein_of(k + e)) : 0.0f;
-#else
             src[jj] = sp < ns ? Xb + (int64_t)(2 * sp + (lp & 1)) * panel_stride + (int64_t)r_begin * PB + (q & 127) * 8 : nullptr;
 #pragma unroll
             for (int e = 0; e < 8; ++e) mul[jj][e] = ldexpf(1.0f, -ein_of(k + e));
-#endif
         }
-#ifdef ASVD_SG_PF2
-        f32x4 preB[2][2];
-        // loads the compiler does not see (it would wait for ALL of them — vmcnt(0) — in front of the first use of a loop-carried pair of register
-        // sets); always four per thread and tile, so that the counts in wait_tile below are exact: an absent super-panel reads panel 0 and is
-        // multiplied by 0
-        auto fetch = [&](int t, f32x4 (&pre)[2][2]) {
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                const float* s_ = src[jj] + (int64_t)t * (32 * PB);
-                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(pre[jj][0]) : "v"(s_) : "memory");
-                asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(pre[jj][1]) : "v"(s_) : "memory");
-            }
-        };
-#define SG_WAIT(N, pre) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(pre[0][0]), "+v"(pre[0][1]), "+v"(pre[1][0]), "+v"(pre[1][1]) : : "memory")
-        // in front of the stash of tile t + 1 (memory segment t).  Issued behind its four loads (memory segment t - 2): the 16 panel stores of that
-        // segment, the four loads and 16 stores of segment t - 1
-        auto wait_tile = [&](int t, f32x4 (&pre)[2][2]) {
-            if (t + 3 >= ntiles) SG_WAIT(0, pre);
-            else if (t < 2 || !mine) SG_WAIT(4, pre);
-            else SG_WAIT(36, pre);
-        };
-#else
         auto fetch = [&](int t, f32x4 (&pre)[2][2]) {
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
@@ -529,7 +501,6 @@ __global__ __launch_bounds__(512, 1) void supgram_kernel(Sched sc, float* __rest
                 }
             }
         };
-#endif
         auto stash = [&](const f32x4 (&pre)[2][2]) {
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
@@ -585,17 +556,9 @@ __global__ __launch_bounds__(512, 1) void supgram_kernel(Sched sc, float* __rest
         const int glag = mypr ? 1 : 2;   // pair A accumulates the Gram units of tile t - 2 next to update t, pair B those of tile t - 1
 
         // ---- prologue: tile 0 staged, tile 1 in flight ----
-#ifdef ASVD_SG_PF2
-        fetch(0, preA);
-        SG_WAIT(0, preA);
-        stash(preA);
-        if (ntiles > 1) fetch(1, preB);
-        if (ntiles > 2) fetch(2, preA);
-#else
         fetch(0, preA);
         stash(preA);
         if (ntiles > 1) fetch(1, preA);
-#endif
         __syncthreads();
         if (mypr) __syncthreads();   // pair B runs one segment behind pair A
 #ifdef ASVD_SG_TIMING
@@ -641,15 +604,9 @@ __global__ __launch_bounds__(512, 1) void supgram_kernel(Sched sc, float* __rest
             // ================= memory segment =================
             // order matters: vmcnt counts loads AND stores, and the panel stores are conditional (the compiler must assume none were issued), so a
             // stash BEHIND this tile's stores would wait for them.  Stash first: it waits only for what the previous memory segment issued.
-#ifdef ASVD_SG_PF2
-            if (t + 1 < ntiles) { wait_tile(t, pre); stash(pre); }
-            SG_TS(4);
-            if (t + 3 < ntiles) fetch(t + 3, pre);
-#else
             if (t + 1 < ntiles && !SG_ABL(8)) stash(pre);     // tile t + 1 (in registers since the previous memory segment) -> incoming image
             SG_TS(4);
             if (t + 2 < ntiles && !SG_ABL(2)) fetch(t + 2, pre);   // into the registers the stash has just emptied
-#endif
             SG_TS(5);
             SG_TS(6);
             if (r_begin + 32 * t < m_pad && !SG_ABL(8)) {
@@ -674,7 +631,9 @@ __global__ __launch_bounds__(512, 1) void supgram_kernel(Sched sc, float* __rest
                 // register pair across the loop, 893 when it is recomputed in front of them (four more VALU instructions), 884 when they are issued after
                 // the operand split — reproduced binary by binary on one box (profiles/r4_supgram_variants.txt).  Measured and dropped: the tile through
                 // 4 KB of wave-private LDS and out as four 16-byte row stores per lane (1047 us); 4 x 4 transposes inside the lane quads (DPP quad_perm, 64
-                // VALU per tile) and four 16-byte stores per lane (889 vs 884: the store COUNT is not what it waits for); two tiles of loads in flight (1008 us).
+                // VALU per tile) and four 16-byte stores per lane (889 vs 884: the store COUNT is not what it waits for); two tiles of loads in flight — left to the
+                // compiler 1008 us (it waits for ALL loads, vmcnt(0)), with hand-issued loads and exact s_waitcnt vmcnt(36) counts 948 vs 957 on the same box:
+                // more bytes in flight buy nothing (profiles/r4_supgram_variants.txt); a panel stride that is not a power of two (+24 rows): 937 vs 957.
                 float* __restrict__ po = Pw + (int64_t)(r_begin + 32 * t + 4 * h) * PB + c;
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) po[((reg & 3) + 8 * (reg >> 2)) * PB] = acc[reg] * oscale;
@@ -683,15 +642,7 @@ __global__ __launch_bounds__(512, 1) void supgram_kernel(Sched sc, float* __rest
             __syncthreads();
             SG_TS(8);
         };
-#ifdef ASVD_SG_PF2
-        {
-            int t = 0;
-            for (; t + 1 < ntiles; t += 2) { tile_step(t, preB); tile_step(t + 1, preA); }
-            if (t < ntiles) tile_step(t, preB);
-        }
-#else
         for (int t = 0; t < ntiles; ++t) tile_step(t, preA);
-#endif
 #ifdef ASVD_SG_TIMING
         if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && ob == 0 && lane == 0) {
             for (int i = 0; i < 9; ++i) g_sg_ts[mypr][i] = sg_acc[i];
