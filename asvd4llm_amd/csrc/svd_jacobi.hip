@@ -883,22 +883,31 @@ static int svd_tall(int batch, const void* const* a_host, int a_dtype, int64_t m
     if (rc < 0) return rc;
     if (want_vectors) {
         ProfScope ps(4, st);
-        // per-problem epilogues (un-permute, long-side GEMM, sigma refinement) on the call's stream: their launches pipeline (three side
-        // streams bought nothing once every launch filled the chip)
-        for (int b = 0; b < batch; ++b) {
-            row_unpermute_kernel<<<dim3((unsigned)ceil_div64(k, 256), p.cols), 256, 0, st>>>(vperm[b], cperm + (int64_t)b * p.n_pad, p.cols, (int)k, vr[b]);
-            float* long_out = p.transposed ? (V_host ? V_host[b] : nullptr) : (U_host ? U_host[b] : nullptr);
-            if (!long_out) continue;
-            nn_gemm_split_kernel<<<dim3((unsigned)ceil_div64(k, 128), (unsigned)ceil_div64(p.rows, 128)), 256, 0, st>>>(
-                Xp + (int64_t)b * p.batch_stride, p.panel_stride, p.nb, p.rows, p.cols, vr[b], k, nullptr, (int)k, long_out, k);
+        // epilogues (un-permute, long-side product, sigma refinement), up to TALL_ZB problems per launch
+        const int nsp = (int)std::min<int64_t>(64, ceil_div64(p.rows, 256));
+        const int rps = (int)ceil_div64(p.rows, nsp);
+        for (int b0 = 0; b0 < batch; b0 += TALL_ZB) {
+            const int zb = std::min(TALL_ZB, batch - b0);
+            TallBatch tb{};
+            bool any_long = false;
+            for (int z = 0; z < zb; ++z) {
+                const int b = b0 + z;
+                tb.vperm[z] = vperm[b];
+                tb.vr[z] = vr[b];
+                tb.lng[z] = p.transposed ? (V_host ? V_host[b] : nullptr) : (U_host ? U_host[b] : nullptr);
+                tb.S[z] = S_host[b];
+                any_long = any_long || tb.lng[z];
+            }
+            row_unpermute_kernel<<<dim3((unsigned)ceil_div64(k, 256), p.cols, zb), 256, 0, st>>>(tb, cperm + (int64_t)b0 * p.n_pad, p.n_pad, p.cols, (int)k);
+            if (!any_long) continue;
+            nn_gemm_split_kernel<<<dim3((unsigned)ceil_div64(k, 128), (unsigned)ceil_div64(p.rows, 128), zb), 256, 0, st>>>(
+                tb, Xp + (int64_t)b0 * p.batch_stride, p.panel_stride, p.batch_stride, p.nb, p.rows, p.cols, k, (int)k, k);
             // sigma_j = |X v_j| and unit left vectors
-            const int nsp = (int)std::min<int64_t>(64, ceil_div64(p.rows, 256));
-            const int rps = (int)ceil_div64(p.rows, nsp);
-            double* part = (double*)(wb + t.off_part) + (size_t)b * 64 * k;
-            float* invs = (float*)(wb + t.off_inv) + (size_t)b * k;
-            colsumsq_kernel<<<dim3((unsigned)ceil_div64(k, 64), nsp), 256, 0, st>>>(long_out, k, p.rows, (int)k, rps, part);
-            colfinish_kernel<<<1, 256, 0, st>>>(part, nsp, (int)k, S_host[b], invs);
-            colscale_kernel<<<dim3((unsigned)ceil_div64(k, 256), (unsigned)ceil_div64(p.rows, 32)), 256, 0, st>>>(long_out, k, p.rows, (int)k, invs);
+            double* part = (double*)(wb + t.off_part) + (size_t)b0 * 64 * k;
+            float* invs = (float*)(wb + t.off_inv) + (size_t)b0 * k;
+            colsumsq_kernel<<<dim3((unsigned)ceil_div64(k, 64), nsp, zb), 256, 0, st>>>(tb, k, p.rows, (int)k, rps, part, (int64_t)64 * k);
+            colfinish_kernel<<<zb, 256, 0, st>>>(tb, part, (int64_t)64 * k, nsp, (int)k, invs);
+            colscale_kernel<<<dim3((unsigned)ceil_div64(k, 256), (unsigned)ceil_div64(p.rows, 32), zb), 256, 0, st>>>(tb, k, p.rows, (int)k, invs);
         }
         ASVD_HIP_CHECK(hipStreamSynchronize(st));
         ASVD_HIP_CHECK(hipGetLastError());

@@ -84,11 +84,21 @@ __global__ void g_permute_scale_kernel(const double* __restrict__ G, int64_t ldg
     else v = (di > 0.0 && dj > 0.0) ? G[(int64_t)b * g_batch_stride + (int64_t)lo * ldg + hi] / (di * dj) : 0.0;
     Gs[(int64_t)b * g_batch_stride + (int64_t)i * ldg + j] = v;
 }
+// The epilogue kernels of the tall path take up to 32 problems per launch (blockIdx.z): the caller's outputs are separate allocations, so the
+// pointers travel by value.  (One launch per problem — 128 workgroups of the long-side product on 256 CUs, 160 launches per batch of 32 — was
+// 33 ms of a 571 ms bench step.)
+constexpr int TALL_ZB = 32;
+struct TallBatch {
+    const float* vperm[TALL_ZB];   // right vectors in sorted-column order
+    float* vr[TALL_ZB];            // ... in the original order
+    float* lng[TALL_ZB];           // long-side vectors (nullptr: not wanted)
+    float* S[TALL_ZB];
+};
 // out[perm[i]][:] = in[i][:]   (rows of the right vectors back to the original column order)
-__global__ void row_unpermute_kernel(const float* __restrict__ in, const int* __restrict__ perm, int rows, int k, float* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+__global__ void row_unpermute_kernel(TallBatch tb, const int* __restrict__ perm, int64_t perm_stride, int rows, int k) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y, z = blockIdx.z;
     if (c >= k || i >= rows) return;
-    out[(int64_t)perm[i] * k + c] = in[(int64_t)i * k + c];
+    tb.vr[z][(int64_t)perm[z * perm_stride + i] * k + c] = tb.vperm[z][(int64_t)i * k + c];
 }
 
 constexpr int CB = 64;        // Cholesky block size
@@ -270,11 +280,15 @@ __global__ __launch_bounds__(256) void r_to_f32_t_kernel(const double* __restric
 // 36-operand half blocks so the scattered A writes fall on distinct banks); a wave then issues 48 bf16 MFMAs per 32-column panel
 // against 30 ds_read_b128, no VALU in the inner loop.  Same tiling (128 x 128 per workgroup, wave w = rows 32 w ..), same epilogue.
 constexpr int NG_HB = 36, NG_BLK = 2 * NG_HB;
-__global__ __launch_bounds__(256, 2) void nn_gemm_split_kernel(const float* __restrict__ X, int64_t panel_stride, int nb, int rows, int cols,
-                                                               const float* __restrict__ Vr, int64_t ldv, const float* __restrict__ S, int k,
-                                                               float* __restrict__ out, int64_t ldo) {
+__global__ __launch_bounds__(256, 2) void nn_gemm_split_kernel(TallBatch tb, const float* __restrict__ Xall, int64_t panel_stride, int64_t batch_stride, int nb,
+                                                               int rows, int cols, int64_t ldv, int k, int64_t ldo) {
     __shared__ u32x4 Aimg[4 * 2 * 3 * NG_BLK];
     __shared__ u32x4 Bimg[4 * 2 * 3 * NG_BLK];
+    float* __restrict__ out = tb.lng[blockIdx.z];
+    if (!out) return;
+    const float* __restrict__ X = Xall + (int64_t)blockIdx.z * batch_stride;
+    const float* __restrict__ Vr = tb.vr[blockIdx.z];
+    const float* S = nullptr;   // unscaled product: sigma and the unit vectors follow from its column norms (colsumsq / colfinish / colscale)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, tid = threadIdx.x;
     const int h = lane >> 5, c = lane & 31;
     const int r0 = blockIdx.y * 128;
@@ -366,8 +380,11 @@ __global__ __launch_bounds__(256, 2) void nn_gemm_split_kernel(const float* __re
 
 // sigma refinement of the tall path: Y = X Vr (unscaled) -> sigma_j = |y_j| (fp64, fixed order), u_j = y_j / sigma_j.
 // |X v_j| is second-order accurate in the error of v_j and does not see the fp32 rounding of R.
-__global__ __launch_bounds__(256) void colsumsq_kernel(const float* __restrict__ Y, int64_t ldy, int rows, int k, int rows_per_split,
-                                                       double* __restrict__ part) {
+__global__ __launch_bounds__(256) void colsumsq_kernel(TallBatch tb, int64_t ldy, int rows, int k, int rows_per_split, double* __restrict__ part_all,
+                                                       int64_t part_stride) {
+    const float* __restrict__ Y = tb.lng[blockIdx.z];
+    if (!Y) return;
+    double* __restrict__ part = part_all + (int64_t)blockIdx.z * part_stride;
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6, split = blockIdx.y;
     const int rb = split * rows_per_split, re = min(rb + rows_per_split, rows);
     double acc = 0.0;
@@ -383,8 +400,12 @@ __global__ __launch_bounds__(256) void colsumsq_kernel(const float* __restrict__
 }
 // one workgroup: ordered sum of the partials, sqrt, then a running minimum keeps S non-increasing (refined values of nearly equal
 // singular values may swap by ~1e-6 relative; the columns are not re-ordered)
-__global__ __launch_bounds__(256) void colfinish_kernel(const double* __restrict__ part, int nsplit, int k, float* __restrict__ S,
-                                                        float* __restrict__ inv) {
+__global__ __launch_bounds__(256) void colfinish_kernel(TallBatch tb, const double* __restrict__ part_all, int64_t part_stride, int nsplit, int k,
+                                                        float* __restrict__ inv_all) {
+    if (!tb.lng[blockIdx.x]) return;
+    const double* __restrict__ part = part_all + (int64_t)blockIdx.x * part_stride;
+    float* __restrict__ S = tb.S[blockIdx.x];
+    float* __restrict__ inv = inv_all + (int64_t)blockIdx.x * k;
     for (int c = threadIdx.x; c < k; c += 256) {
         double acc = 0.0;
         for (int sp = 0; sp < nsplit; ++sp) acc += part[(int64_t)sp * k + c];
@@ -405,9 +426,11 @@ __global__ __launch_bounds__(256) void colfinish_kernel(const double* __restrict
     for (int t = 0; t < (int)threadIdx.x; ++t) run = fminf(run, cmin[t]);
     for (int c = c0; c < c1; ++c) { run = fminf(run, S[c]); S[c] = run; }
 }
-__global__ void colscale_kernel(float* __restrict__ Y, int64_t ldy, int rows, int k, const float* __restrict__ inv) {
+__global__ void colscale_kernel(TallBatch tb, int64_t ldy, int rows, int k, const float* __restrict__ inv_all) {
+    float* __restrict__ Y = tb.lng[blockIdx.z];
     const int c = blockIdx.x * blockDim.x + threadIdx.x, r0 = blockIdx.y * 32;
-    if (c >= k) return;
+    if (!Y || c >= k) return;
+    const float* __restrict__ inv = inv_all + (int64_t)blockIdx.z * k;
     const float f = inv[c];
     for (int r = r0; r < min(r0 + 32, rows); ++r) Y[(int64_t)r * ldy + c] *= f;
 }
