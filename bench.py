@@ -67,39 +67,50 @@ def sharded_model_leg(name, rank, world, dev, ratio=0.9, dry=False):
     ratios = [0.4, 0.5, 0.6, 0.7, 0.8, 0.9]
     load = [sum(c for c, o in zip(costs, owner) if o == r) for r in range(world)]
     mine = [(n, o, i) for (n, o, i), ow in zip(layers, owner) if ow == rank]
-    local, t_dec, sweeps = {}, 0.0, []
+    local, t_dec, sweeps, err = {}, 0.0, [], None
     if dry:
         for n, o, i in mine:
             local[n] = {r: 5.0 + (zlib.crc32(f"{n}:{r}".encode()) % 1000) / 1000.0 for r in ratios}
     else:
-        import torch.nn as nn
-        from asvd4llm_amd.modules.svd_linear import SVDLinear
-        lins = []
-        for idx, (n, o, i) in enumerate(mine):
-            g = torch.Generator(device=dev).manual_seed(233 + 7919 * rank + idx)
-            lin = nn.Linear(i, o, bias=False, device="meta")
-            lin.weight = nn.Parameter((torch.randn(o, i, generator=g, device=dev) * 0.02).half(), requires_grad=False)
-            scal = 32 * torch.randn(i, generator=g, device=dev).abs()
-            scal[torch.randperm(i, generator=g, device=dev)[:max(1, i // 100)]] *= 30
-            lin.scaling_diag_matrix = scal.half()
-            lins.append(lin)
-        ranks = {l: SVDLinear.compute_rank(l, ratio) for l in lins}
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        t0 = time.perf_counter()
-        SVDLinear.prefactorize(lins, act_aware=True, alpha=0.5, ranks=ranks, max_batch=32)
-        for (n, o, i), l in zip(mine, lins):
-            mod = SVDLinear.from_linear(l, ratio, act_aware=True, alpha=0.5, sigma_fuse="UV")
-            assert isinstance(mod, SVDLinear) and l._asvd_svd_info.status == 0, n
-            sweeps.append(l._asvd_svd_info.sweeps)
-            S = l._asvd_factor_cache[1][1].float()
-            # a sensitivity made of the layer's own spectrum (the real sweep would put calibration perplexities here): what matters is that real
-            # per-layer numbers computed on the owning rank cross the collective
-            local[n] = {r: float(1.0 + S[min(SVDLinear.compute_rank(l, r), S.numel()) - 1] / S[0]) for r in ratios}
-            SVDLinear.drop_factor_cache(l)
-        torch.cuda.synchronize()
-        t_dec = time.perf_counter() - t0
+        # a failure of this rank's share must not leave the other ranks waiting in the collectives below (nor cost the bench line): it is
+        # recorded, the rank contributes NaNs, every rank learns about it from the reduction at the end
+        at_start = False
+        try:
+            import torch.nn as nn
+            from asvd4llm_amd.modules.svd_linear import SVDLinear
+            lins = []
+            for idx, (n, o, i) in enumerate(mine):
+                g = torch.Generator(device=dev).manual_seed(233 + 7919 * rank + idx)
+                lin = nn.Linear(i, o, bias=False, device="meta")
+                lin.weight = nn.Parameter((torch.randn(o, i, generator=g, device=dev) * 0.02).half(), requires_grad=False)
+                scal = 32 * torch.randn(i, generator=g, device=dev).abs()
+                scal[torch.randperm(i, generator=g, device=dev)[:max(1, i // 100)]] *= 30
+                lin.scaling_diag_matrix = scal.half()
+                lins.append(lin)
+            ranks = {l: SVDLinear.compute_rank(l, ratio) for l in lins}
+            torch.cuda.synchronize()
+            at_start = True
+            if world > 1:
+                dist.barrier()
+            t0 = time.perf_counter()
+            SVDLinear.prefactorize(lins, act_aware=True, alpha=0.5, ranks=ranks, max_batch=32)
+            for (n, o, i), l in zip(mine, lins):
+                mod = SVDLinear.from_linear(l, ratio, act_aware=True, alpha=0.5, sigma_fuse="UV")
+                assert isinstance(mod, SVDLinear) and l._asvd_svd_info.status == 0, n
+                sweeps.append(l._asvd_svd_info.sweeps)
+                S = l._asvd_factor_cache[1][1].float()
+                # a sensitivity made of the layer's own spectrum (the real sweep would put calibration perplexities here): what matters is that real
+                # per-layer numbers computed on the owning rank cross the collective
+                local[n] = {r: float(1.0 + S[min(SVDLinear.compute_rank(l, r), S.numel()) - 1] / S[0]) for r in ratios}
+                SVDLinear.drop_factor_cache(l)
+            torch.cuda.synchronize()
+            t_dec = time.perf_counter() - t0
+        except Exception as e:   # noqa: BLE001 — reported in the record
+            err = f"{type(e).__name__}: {e}"[:300]
+            local = {n: {r: float("nan") for r in ratios} for n, _, _ in mine}
+            sweeps = []
+            if world > 1 and not at_start:   # failed while building its layers: still meet the others at the start line
+                dist.barrier()
     # ---- the one exchange step of the path: all-gather of the sensitivities ----
     if world > 1:
         dist.barrier()
@@ -115,18 +126,25 @@ def sharded_model_leg(name, rank, world, dev, ratio=0.9, dry=False):
     if not dry:
         torch.cuda.synchronize()
     t_ag2 = time.perf_counter() - t0
-    assert full2 == full and list(full.keys()) == names
+    assert list(full.keys()) == names and list(full2.keys()) == names
+    broken = any(v != v for d in full.values() for v in d.values())   # a rank contributed NaNs (its share failed)
+    assert broken or full2 == full
     # ---- replicated search on the complete dict: every rank must arrive at the same plan ----
-    plans = _CutPlans(full, lambda r: r < 1, 1)
     weights = {n: o * i for n, o, i in layers}
-    cut = _bisect_cut(plans.size, lambda lo, mid, hi: (lambda ct: ct[0] / ct[1] > ratio)(_plan_params(plans.plan(mid), weights)))
-    plan = plans.plan(cut)
-    digest = int(hashlib.sha256(json.dumps(sorted(plan.items())).encode()).hexdigest()[:15], 16)
+    plan, digest = {}, 0
+    if not broken:
+        plans = _CutPlans(full, lambda r: r < 1, 1)
+        cut = _bisect_cut(plans.size, lambda lo, mid, hi: (lambda ct: ct[0] / ct[1] > ratio)(_plan_params(plans.plan(mid), weights)))
+        plan = plans.plan(cut)
+        digest = int(hashlib.sha256(json.dumps(sorted(plan.items())).encode()).hexdigest()[:15], 16)
     comm_dev = dev if (world > 1 and dist.get_backend() == "nccl") else torch.device("cpu")
-    red = torch.tensor([float(digest), -float(digest), t_dec, t_ag, t_ag2], dtype=torch.float64, device=comm_dev)
+    red = torch.tensor([float(digest), -float(digest), t_dec, t_ag, t_ag2, 1.0 if err else 0.0], dtype=torch.float64, device=comm_dev)
     if world > 1:
         dist.all_reduce(red, op=dist.ReduceOp.MAX)
     red = red.cpu()
+    if broken or float(red[5]) > 0:
+        return {"model": name, "error": err or "another rank's share failed (see its stderr)", "ranks_failed": bool(float(red[5]) > 0),
+                "collective_world_size": dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1}
     comp, total = _plan_params(plan, weights)
     return {"model": name, "config": "BASELINE configs[3] shape: every Linear of the model, ratio %.2f, alpha 0.5, synthetic weights / statistics" % ratio,
             "linears": len(layers), "collective_world_size": dist.get_world_size() if (world > 1 or (dist.is_available() and dist.is_initialized())) else 1,
@@ -283,7 +301,11 @@ def main():
     sharded = None
     sm = args.sharded_model if args.sharded_model != "auto" else ("llama-2-7b" if world > 1 else "none")
     if sm != "none":
-        sharded = sharded_model_leg(sm, rank, world, dev)
+        try:
+            sharded = sharded_model_leg(sm, rank, world, dev)
+        except Exception as e:   # noqa: BLE001 — the untimed extra must not cost the bench line
+            sharded = {"model": sm, "error": f"{type(e).__name__}: {e}"[:300]}
+            print(f"[bench] rank {rank}: sharded-model leg failed: {sharded['error']}", file=sys.stderr)
 
     # per-rank rates (N > 1): every rank's own SVDs/s over its own wall clock
     per_rank = None
