@@ -368,9 +368,11 @@ def main():
                         "unit": "GB/s", "frac": ach / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
                         "frac_of_measured_copy_rate_6290GBps": ach / 6290.0, "matrix_pipe_busy_frac": mfma_busy, "shader_clock_GHz_under_pmc": pmc_clock,
                         "algorithmic_bytes_per_launch": alg[dom], "avg_launch_us": classes[dom]["avg_us"],
-                        "bound_evidence": "HBM path: the launch takes the same time at 2.31 GHz (short PMC pass, profiles/r4_pmc_GRBM_*.txt) and at the 1.95 GHz the 1400 W socket "
-                                          "cap allows in sustained runs (profiles/r4_power.jsonl), measured traffic is 1.02x the algorithmic bytes, and removing the panel "
-                                          "stores is the only ablation that shortens it (DESIGN.md 3.10); the fp16 matrix pipe is a quarter busy (33 MFMAs per wave and tile)",
+                        "bound_evidence": "HBM path first, shader clock second: measured traffic is 1.02x the algorithmic bytes, the fp16 matrix pipe is a quarter busy (33 MFMAs "
+                                          "per wave and tile), removing the panel stores is the only ablation that shortens a launch (DESIGN.md 3.10).  Clock: in this bench, "
+                                          "with lighter kernels between its launches, the kernel runs at 2.2-2.3 GHz (877-881 us; the PMC passes read 2.20-2.31 GHz); launched back "
+                                          "to back it holds the socket at its 1400 W cap at 1.87-1.95 GHz and takes 957-968 us (profiles/r4_supgram_micro.jsonl, r4_power.jsonl): "
+                                          "20 % of clock are worth 9 % of time",
                         "note": "dominant streaming kernel by total time; bytes from the library's own counters of the profiled step, duration = HIP "
                                 "events around every launch on the launch stream, averaged over ALL its launches (one stream: nothing else runs beside it)"}
         else:

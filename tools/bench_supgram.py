@@ -80,7 +80,7 @@ def main():
     us = e0.elapsed_time(e1) * 1e3 / a.reps
     gb = 2 * X.numel() * 4 / 1e9
     tiles = (ns // 4) * batch * (R // 32) / 256.0   # 32-row tiles per CU
-    out = {"near_identity": a.near_identity, "pad_rows": a.pad_rows, "lib": os.path.basename(os.environ.get("ASVD_HIP_LIB", "default")), "ablate": a.ablate, "us_per_launch": round(us, 1), "us_per_tile": round(us / tiles, 3), "TBps_rw": round(gb / us * 1e3 / 1e3, 3)}
+    out = {"near_identity": a.near_identity, "pad_rows": a.pad_rows, "lib": os.path.basename(os.environ.get("ASVD_HIP_LIB", "default")), "ablate": a.ablate, "us_per_launch": round(us, 1), "us_per_tile": round(us / tiles, 3), "TBps_rw": round(gb / us * 1e3, 3)}
     if a.timing:
         buf = (ctypes.c_ulonglong * 20)()
         lib.asvd_test_sg_timing.restype = ctypes.c_int

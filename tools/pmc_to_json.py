@@ -16,9 +16,9 @@ fetch, write = table(os.path.join(d, "pmc_FETCH_SIZE.txt")), table(os.path.join(
 names = {"supgram": "supgram_kernel", "supdate": "supdate_split_kernel", "sgram": "sgram6_kernel", "evd": "evdw12_kernel", "snapshot": "fullcheck_kernel"}
 import hashlib
 _lib_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "asvd4llm_amd", "libasvd_hip.so")
-res = {"batch": int(os.environ.get("PMC_BATCH", "16")), "lib_sha256": hashlib.sha256(open(_lib_path, "rb").read()).hexdigest() if os.path.exists(_lib_path) else None, "source": "profiles/" + os.path.basename(d).replace("prof_", "") + "_pmc_*.txt",
+res = {"batch": int(os.environ.get("PMC_BATCH", "32")), "lib_sha256": hashlib.sha256(open(_lib_path, "rb").read()).hexdigest() if os.path.exists(_lib_path) else None, "source": "profiles/" + os.path.basename(d).replace("prof_", "") + "_pmc_*.txt",
        "note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes of `python bench.py --no_cpu_baseline --no_latency --steps 1 --warmup 0 --prewarm_s 0` "
-               "(" + os.environ.get("PMC_BATCH", "16") + " x 4096x4096 fp32, one stream); mean per dispatch over all launches of the run; FETCH doubled (gfx950 half-count), WRITE as reported",
+               "(" + os.environ.get("PMC_BATCH", "32") + " x 4096x4096 fp32, one stream); mean per dispatch over all launches of the run; FETCH doubled (gfx950 half-count), WRITE as reported",
        "kernels": {}}
 import glob
 def first(pattern):
