@@ -957,22 +957,21 @@ void launch_evdw12(int npairs_s, int batch, hipStream_t st, const Sched& sc, uns
     // latency form when the launch cannot even give every CU one workgroup: four waves per solve (bit-identical results).  It needs one
     // full inner sweep per visit (the default) and the standard 32 phase pairs.  ASVD_EVDQ=0 / 1 forces the choice.
     const bool coop = inner_sweeps == 1 && (evdq_env() == 1 || (evdq_env() != 0 && (long long)npairs_s * batch <= 256));
-    if (coop) {
-        evdw12_kernel<EVDQ_NW><<<dim3((unsigned)npairs_s, (unsigned)batch), 128 * EVDQ_NW, evdq12_lds_bytes(), st>>>(sc, maxoff_bits, nrot, done, tol, inner_sweeps, nb,
-                                                                                                              step, kb, v3, nullptr);
-        return;
-    }
     static long long* trace = nullptr;
     static int traced = 0;
-    if (getenv("ASVD_EVDW_TRACE") && !trace) (void)hipMalloc(&trace, 32 * sizeof(long long));
-    evdw12_kernel<1><<<dim3((unsigned)npairs_s, (unsigned)batch), 128, evdw12_lds_bytes(), st>>>(sc, maxoff_bits, nrot, done, tol, inner_sweeps, nb, step,
-                                                                                               kb, v3, traced < 3 ? trace : nullptr);
-    if (trace && traced < 3) {
+    if (getenv("ASVD_EVDW_TRACE") && !trace) (void)hipMalloc(&trace, 16 * 16 * sizeof(long long));
+    long long* tr = traced < 3 ? trace : nullptr;
+    if (coop)
+        evdw12_kernel<EVDQ_NW><<<dim3((unsigned)npairs_s, (unsigned)batch), 128 * EVDQ_NW, evdq12_lds_bytes(), st>>>(sc, maxoff_bits, nrot, done, tol, inner_sweeps, nb,
+                                                                                                              step, kb, v3, tr);
+    else
+        evdw12_kernel<1><<<dim3((unsigned)npairs_s, (unsigned)batch), 128, evdw12_lds_bytes(), st>>>(sc, maxoff_bits, nrot, done, tol, inner_sweeps, nb, step, kb, v3, tr);
+    if (tr) {
         long long h[32];
         (void)hipStreamSynchronize(st);
         (void)hipMemcpy(h, trace, sizeof(h), hipMemcpyDeviceToHost);
-        for (int w = 0; w < 2; ++w) {
-            fprintf(stderr, "[evdw12 trace] launch %d wave %d stage deltas (clocks):", traced, w);
+        for (int w = 0; w < 2; ++w) {   // the two main waves
+            fprintf(stderr, "[evdw12 trace] launch %d (%s) wave %d stage deltas (clocks):", traced, coop ? "four waves per solve" : "wave-local", w);
             for (int i = 1; i < 14; ++i) fprintf(stderr, " %lld", h[w * 16 + i] - h[w * 16 + i - 1]);
             fprintf(stderr, "\n");
         }
