@@ -296,35 +296,40 @@ __global__ __launch_bounds__(256, 2) void nn_gemm_split_kernel(TallBatch tb, con
     f32x16 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = (f32x16){0};
-    // A pieces: q = tid + 256 j -> row q >> 2 of the 128, k-chunk q & 3 (8 values = 32 B); B pieces: column tid & 127, k-chunk (tid >> 7) + 2 j
-    f32x4 pa[2][2];
-    float pb[2][8];
+    // A pieces: q = tid + 256 j -> row q >> 2 of the 128, k-chunk q & 3 (8 values = 32 B); B pieces: column tid & 127, k-chunk (tid >> 7) + 2 j.
+    // TWO panels are in flight (register sets 0 / 1): with one, the loads of panel p + 1 had only the matrix segment of panel p (~0.8 us) to
+    // arrive.  Every load is unconditional — rows, columns and the panel index are clamped instead of guarded — so that the wait counts in front
+    // of a set's first use are exact (a guarded load makes the compiler wait for ALL loads): rows beyond `rows` and columns beyond `k` only reach
+    // outputs that are never stored, and the K range beyond `cols` multiplies the zero padding of the packed panels.  (finalize 35.0 -> 31.0 ms per
+    // 32 x 4096^2.  Measured and dropped: ONE workgroup per CU with double-buffered images and the split of panel p + 1 issued between the four
+    // groups of 12 matrix instructions of panel p — 37.6 ms: a lone wave per SIMD exposes the LDS latency in front of every group.)
+    f32x4 pa[2][2][2];
+    float pb[2][2][8];
     int adst[2], bdst[2];
+    const float* asrc[2];
+    const float* bsrc[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int q = tid + 256 * j, row = q >> 2, kc = q & 3;
         adst[j] = (((row >> 5) * 2 + (kc >> 1)) * 3) * NG_BLK + (kc & 1) * NG_HB + (row & 31);
         const int cc = tid & 127, kb = (tid >> 7) + 2 * j;
         bdst[j] = (((cc >> 5) * 2 + (kb >> 1)) * 3) * NG_BLK + (kb & 1) * NG_HB + (cc & 31);
+        asrc[j] = X + (int64_t)min(r0 + row, rows - 1) * PB + 8 * kc;
+        bsrc[j] = Vr + min(c0 + cc, k - 1);
     }
-    auto fetch = [&](int p) {
-        const float* P = X + (int64_t)p * panel_stride;
+    auto fetch = [&](int p_, f32x4 (&xa)[2][2], float (&xb)[2][8]) {
+        const int p = min(p_, nb - 1);
+        const float* P = (const float*)0 + (int64_t)p * panel_stride;   // offset only
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int q = tid + 256 * j, row = q >> 2, kc = q & 3;
-            if (r0 + row < rows) {
-                const float* src = P + (int64_t)(r0 + row) * PB + 8 * kc;
-                pa[j][0] = *(const f32x4*)src;
-                pa[j][1] = *(const f32x4*)(src + 4);
-            } else {
-                pa[j][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-                pa[j][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-            const int cc = tid & 127, kb = (tid >> 7) + 2 * j, vc = c0 + cc;
+            const float* src = asrc[j] + (P - (const float*)0);
+            xa[j][0] = *(const f32x4*)src;
+            xa[j][1] = *(const f32x4*)(src + 4);
+            const int kb = (tid >> 7) + 2 * j;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const int vr = p * PB + 8 * kb + e;
-                pb[j][e] = (vr < cols && vc < k) ? Vr[(int64_t)vr * ldv + vc] : 0.0f;
+                const int vr = min(p * PB + 8 * kb + e, cols - 1);
+                xb[j][e] = bsrc[j][(int64_t)vr * ldv];
             }
         }
     };
@@ -337,16 +342,15 @@ __global__ __launch_bounds__(256, 2) void nn_gemm_split_kernel(TallBatch tb, con
         split3(v6, v7, x, y, z); p1[3] = x; p2[3] = y; p3[3] = z;
         dst[0] = p1; dst[NG_BLK] = p2; dst[2 * NG_BLK] = p3;
     };
-    fetch(0);
-    for (int p = 0; p < nb; ++p) {
+    auto panel_step = [&](int p, f32x4 (&xa)[2][2], float (&xb)[2][8]) __attribute__((always_inline)) {
         __syncthreads();  // previous panel's images fully consumed
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            put(Aimg + adst[j], pa[j][0][0], pa[j][0][1], pa[j][0][2], pa[j][0][3], pa[j][1][0], pa[j][1][1], pa[j][1][2], pa[j][1][3]);
-            put(Bimg + bdst[j], pb[j][0], pb[j][1], pb[j][2], pb[j][3], pb[j][4], pb[j][5], pb[j][6], pb[j][7]);
+            put(Aimg + adst[j], xa[j][0][0], xa[j][0][1], xa[j][0][2], xa[j][0][3], xa[j][1][0], xa[j][1][1], xa[j][1][2], xa[j][1][3]);
+            put(Bimg + bdst[j], xb[j][0], xb[j][1], xb[j][2], xb[j][3], xb[j][4], xb[j][5], xb[j][6], xb[j][7]);
         }
         __syncthreads();
-        if (p + 1 < nb) fetch(p + 1);
+        fetch(p + 2, xa, xb);   // into the set just emptied (clamped: the last two refills re-read the last panel and are never used)
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             const u32x4* ap = Aimg + ((w * 2 + s2) * 3) * NG_BLK + h * NG_HB + c;
@@ -363,7 +367,15 @@ __global__ __launch_bounds__(256, 2) void nn_gemm_split_kernel(TallBatch tb, con
                 acc[tl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B1, acc[tl], 0, 0, 0);
             }
         }
+    };
+    fetch(0, pa[0], pb[0]);
+    fetch(1, pa[1], pb[1]);
+    int p = 0;
+    for (; p + 1 < nb; p += 2) {
+        panel_step(p, pa[0], pb[0]);
+        panel_step(p + 1, pa[1], pb[1]);
     }
+    if (p < nb) panel_step(p, pa[0], pb[0]);
 #pragma unroll
     for (int tl = 0; tl < 4; ++tl) {
         const int col = c0 + tl * 32 + c;
