@@ -24,8 +24,9 @@ constexpr int EVD_PHASE_PAIRS = PW / 2;   // (A, B) phase pairs of one inner swe
 //   super_order 1 XOR, 2 grouped (below);  gm / gpair: group pairs per round / {gA, gB} of the grouped schedule
 struct Sched {
     int pair_order, super_order, gm;
+    int gb;         // grouped schedule: log2 of the group size G (1..4)
     int meas;       // measurement builds only (-DASVD_SG_TIMING, tools/bench_supgram.py): timing-only ablation bits of the fused kernel; 0 in the product
-    signed char gpair[8][4][2];
+    signed char gpair[16][8][2];
 };
 static Sched default_sched() {
     Sched sc;
@@ -54,10 +55,12 @@ static __device__ __forceinline__ void rr_pair(const Sched& sc, int nb, int step
 // by the callers.
 //   super_order 1: XOR like the panel level, over the super-panel count padded to a power of two.  A padded schedule runs P-1 super-steps
 //     with many empty slots (13B: 80 super-panels -> 127 steps, 37 % empty).
-//   super_order 2: GROUPED schedule for counts that are a multiple of 16 but not a power of two: XOR (d = 1..15) inside groups of 16
-//     super-panels, then the group pairs of a round-robin tournament over the groups, each for the 16 offsets s (A_i <-> B_{i ^ s}): the
-//     nearest-neighbour-first order of the XOR schedule inside a group and inside a group pair, and 15 + rounds * 16 super-steps with
-//     (almost) every slot filled.  sc.gpair[round][m] = {gA, gB} (gA < gB), sc.gm = pairs per round.  (A plain round-robin tournament over
+//   super_order 2: GROUPED schedule for counts that are not a power of two: groups of G = 2^gb super-panels (G = 2 .. 16, ns / G <= 16 groups):
+//     XOR (d = 1..G-1) inside the groups, then the group pairs of a round-robin tournament over the groups, each for the G offsets s
+//     (A_i <-> B_{i ^ s}): the nearest-neighbour-first order of the XOR schedule inside a group and inside a group pair, and G - 1 + rounds * G
+//     super-steps.  With an EVEN number of groups every slot of every step is filled and the sweep has the minimum ns - 1 steps (80 super-panels:
+//     G = 8, 10 groups, 79 steps; round 2-3 used G = 16 only: 5 groups, a bye per round, 95 steps; the padded XOR schedule: 127).  The host
+//     picks the G with the fewest steps (svd_jacobi.hip, group_bits_for).  sc.gpair[round][m] = {gA, gB} (gA < gB), sc.gm = pairs per round.  (A plain round-robin tournament over
 //     the super-panels — ns-1 full steps — was measured in round 2: sweeps 7-9 -> 8-12, the nearest-neighbour-first order is worth more.)
 static __device__ __forceinline__ void super_pair(const Sched& sc, int ns, int step, int k, int& S, int& T) {
     if (sc.super_order == 1) {
@@ -68,17 +71,18 @@ static __device__ __forceinline__ void super_pair(const Sched& sc, int ns, int s
         return;
     }
     if (sc.super_order == 2) {
-        if (step < 15) {
+        const int gb = sc.gb, G = 1 << gb;
+        if (step < G - 1) {
             if (k >= ns / 2) { S = ns; T = ns; return; }
-            const int d = step + 1, h = 31 - __clz(d), g = k >> 3, kk = k & 7;
-            S = 16 * g + (((kk >> h) << (h + 1)) | (kk & ((1 << h) - 1)));
+            const int d = step + 1, h = 31 - __clz(d), g = k >> (gb - 1), kk = k & ((G >> 1) - 1);
+            S = G * g + (((kk >> h) << (h + 1)) | (kk & ((1 << h) - 1)));
             T = S ^ d;
             return;
         }
-        const int r = (step - 15) >> 4, sft = (step - 15) & 15, m = k >> 4, i = k & 15;
+        const int r = (step - (G - 1)) >> gb, sft = (step - (G - 1)) & (G - 1), m = k >> gb, i = k & (G - 1);
         if (m >= sc.gm) { S = ns; T = ns; return; }
-        S = 16 * sc.gpair[r][m][0] + i;
-        T = 16 * sc.gpair[r][m][1] + (i ^ sft);
+        S = G * sc.gpair[r][m][0] + i;
+        T = G * sc.gpair[r][m][1] + (i ^ sft);
         return;
     }
     S = ns; T = ns;   // no other order exists

@@ -179,10 +179,34 @@ int make_plan(int batch, int64_t m, int64_t n, int want_u, int want_vv, Plan& p)
     return ASVD_OK;
 }
 
-// group pairs of every round of the grouped schedule: circle method over the ns / 16 groups (+ a bye when their number is odd)
-static void set_group_table(Sched& sc, int ns) {
-    const int ng = ns / 16, n = ng + (ng & 1), gm = ng / 2;
-    signed char (*tab)[4][2] = sc.gpair;
+// grouped schedule (super_pair, super_order = 2): the group size G = 2^gb, 2 <= G <= 16, that divides ns into at most 16 groups with the fewest
+// super-steps, G - 1 + G * rounds (rounds of a round-robin tournament over the groups: ng - 1 for an even group count, ng with a bye for an odd one);
+// ties go to the larger group.  0: ns is a power of two, or nothing beats the padded XOR schedule.
+static int group_bits_for(int ns) {
+    if (ns < 4 || (ns & (ns - 1)) == 0) return 0;
+    int pw2 = 2;
+    while (pw2 < ns) pw2 <<= 1;
+    int best = pw2 - 1, best_gb = 0;
+    // groups of 16 first, as rounds 2-3 had them: with the 13B shapes' 80 super-panels the 95 steps of five groups of 16 (one with a bye per
+    // round: 32 pairs per step = exactly one round of eigen-solve waves at batch 32) beat the 79 steps of ten groups of 8 (40 pairs per step,
+    // one more dense sweep: 22.4 vs 27.1 SVD/s at 5120^2 x 32) — locality inside a group is worth more than a full schedule
+    if (ns % 16 == 0 && ns / 16 <= 8 && 15 + 16 * (((ns / 16) & 1) ? ns / 16 : ns / 16 - 1) < pw2 - 1) return 4;
+    for (int gb = 4; gb >= 1; --gb) {
+        const int G = 1 << gb;
+        if (ns % G) continue;
+        const int ng = ns / G;
+        if (ng < 2 || ng > 16) continue;
+        const int steps = G - 1 + G * ((ng & 1) ? ng : ng - 1);
+        if (steps < best) { best = steps; best_gb = gb; }
+    }
+    return best_gb;
+}
+static int grouped_rounds(int ns, int gb) { const int ng = ns >> gb; return (ng & 1) ? ng : ng - 1; }
+static int grouped_steps(int ns, int gb) { return (1 << gb) - 1 + (1 << gb) * grouped_rounds(ns, gb); }
+// group pairs of every round: circle method over the ns / G groups (+ a bye when their number is odd)
+static void set_group_table(Sched& sc, int ns, int gb) {
+    const int ng = ns >> gb, n = ng + (ng & 1), gm = ng / 2;
+    signed char (*tab)[8][2] = sc.gpair;
     std::memset(sc.gpair, 0, sizeof(sc.gpair));
     for (int r = 0; r < n - 1; ++r) {
         int m = 0;
@@ -197,20 +221,12 @@ static void set_group_table(Sched& sc, int ns) {
         }
     }
     sc.gm = gm;
+    sc.gb = gb;
 }
-
-// grouped schedule (super_pair, c_super_order = 2): ns a multiple of 16, not a power of two, at most 8 groups
-static bool grouped_applies(int ns) {  // a multiple of 16, not a power of two, at most 8 groups, and fewer super-steps than the padded XOR schedule
-    if ((ns & (ns - 1)) == 0 || (ns % 16) || ns / 16 > 8) return false;
-    int pw2 = 2;
-    while (pw2 < ns) pw2 <<= 1;
-    const int ng = ns / 16;
-    return 15 + 16 * ((ng & 1) ? ng : ng - 1) < pw2 - 1;
-}
+static bool grouped_applies(int ns) { return group_bits_for(ns) > 0; }
 static bool super_grouped_for(const Plan& p) {
     return p.two && grouped_applies(p.ns);
 }
-static int super_grouped_rounds(const Plan& p) { const int ng = p.ns / 16; return (ng & 1) ? ng : ng - 1; }
 
 // ---- optional per-class timing with HIP events on the call's stream ------------------------------
 // profiling state is per host thread: concurrent calls from different threads (on their own streams and workspaces) do not share it
@@ -389,7 +405,7 @@ static int svd_direct_run(int batch, const void* const* a_host, int a_dtype, int
     Sched sc = default_sched();
     sc.pair_order = pair_order_xor() ? 1 : 0;
     sc.super_order = super_grouped_for(p) ? 2 : 1;
-    if (sc.super_order == 2) set_group_table(sc, p.ns);
+    if (sc.super_order == 2) set_group_table(sc, p.ns, group_bits_for(p.ns));
     const int nsteps = pair_order_xor() ? 2 * p.npairs - 1 : p.nb - 1;
     // panels whose convergence is enforced: those holding the k leading columns, plus one panel of margin
     const int kb = (int)(ceil_div64(k, PB) + 1 < p.nb ? ceil_div64(k, PB) + 1 : p.nb);
@@ -567,7 +583,8 @@ static int svd_direct_run(int batch, const void* const* a_host, int a_dtype, int
         }
         if (two_now) {
             const bool super_grp = super_grouped_for(p);
-            const int nsuper = super_grp ? 15 + 16 * super_grouped_rounds(p) : 2 * p.npairs_s - 1;
+            const int sgb = super_grp ? group_bits_for(p.ns) : 0, sG1 = (1 << sgb) - 1;   // grouped schedule: group size - 1
+            const int nsuper = super_grp ? grouped_steps(p.ns, sgb) : 2 * p.npairs_s - 1;
             // supgram: the update of step D also leaves the Gram tiles of the step that follows (one pass instead of two); the stand-alone Gram
             // pass then runs only in front of the first super-step.  ASVD_SUPGRAM=0 keeps the separate passes (fp32 Gram pass, split-bf16 update
             // pass: also what a call falls back to when the split-fp16 path of the fused kernel turns a problem NaN).
@@ -586,7 +603,7 @@ static int svd_direct_run(int batch, const void* const* a_host, int a_dtype, int
                     if (!fuse_ug || dj < 0 || dj + 1 >= nsuper) return false;
                     if (super_grp) {  // consecutive steps inside the groups (XOR distances 1..15), or consecutive offsets of the same round of group pairs
                         const int s0 = dj, s1 = dj + 1;   // 0-based super-steps
-                        return s1 < 15 || (s0 >= 15 && ((s0 - 15) >> 4) == ((s1 - 15) >> 4));
+                        return s1 < sG1 || (s0 >= sG1 && ((s0 - sG1) >> sgb) == ((s1 - sG1) >> sgb));
                     }
                     return ns_pow2;
                 };
@@ -948,14 +965,13 @@ int asvd_test_super_schedule(int ns, int grouped, int* out_dev, int out_capacity
     while (pw2 < ns) pw2 <<= 1;
     const int npairs = pw2 / 2;
     const bool grp = grouped && grouped_applies(ns);
-    const int ng = ns / 16;
-    const int nsteps = grp ? 15 + 16 * ((ng & 1) ? ng : ng - 1) : pw2 - 1;
+    const int nsteps = grp ? grouped_steps(ns, group_bits_for(ns)) : pw2 - 1;
     *nsteps_out = nsteps;
     *npairs_out = npairs;
     if ((int64_t)nsteps * npairs > out_capacity || npairs > 1024) return ASVD_E_WORKSPACE;
     Sched sc = default_sched();
     sc.super_order = grp ? 2 : 1;
-    if (grp) set_group_table(sc, ns);
+    if (grp) set_group_table(sc, ns, group_bits_for(ns));
     super_schedule_kernel<<<nsteps, npairs>>>(sc, ns, nsteps, npairs, out_dev);
     ASVD_HIP_CHECK(hipGetLastError());
     ASVD_HIP_CHECK(hipDeviceSynchronize());

@@ -345,20 +345,21 @@ __global__ __launch_bounds__(512, 1) void supgram_kernel(Sched sc, float* __rest
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5, c = lane & 31;
     // ---- quad geometry (uniform) ----
     // XOR steps (the whole schedule when ns is a power of two; the steps inside the groups of the grouped schedule): super-panels
-    // {a, a^D, a^E, a^D^E}.  Group-pair steps of the grouped schedule (sc.super_order == 2, 0-based step D-1 >= 15): round r pairs group gA with
-    // gB for the 16 offsets s (A_i <-> B_(i^s)); two consecutive offsets s, s' of a round close the quads {A_i, B_(i^s), B_(i^s'), A_(i^e)},
+    // {a, a^D, a^E, a^D^E}.  Group-pair steps of the grouped schedule (sc.super_order == 2, 0-based step D-1 >= G-1, G = 2^sc.gb): round r pairs group gA with
+    // gB for the G offsets s (A_i <-> B_(i^s)); two consecutive offsets s, s' of a round close the quads {A_i, B_(i^s), B_(i^s'), A_(i^e)},
     // e = s ^ s' — the same four slots with the same roles: slots (0,1) and (3,2) rotate now, slots (0,2) and (3,1) meet next.
     int P0, P1, P2, P3, kcur0, kcur1, knxt0, knxt1;
     bool swapB, swapD;
-    if (sc.super_order == 2 && D > 15) {
-        const int st = D - 1 - 15, rnd = st >> 4, s0 = st & 15, s1 = (E - 1 - 15) & 15, e = s0 ^ s1;
-        const int m = quad >> 3;
+    if (sc.super_order == 2 && D > (1 << sc.gb) - 1) {
+        const int gb = sc.gb, G = 1 << gb;
+        const int st = D - 1 - (G - 1), rnd = st >> gb, s0 = st & (G - 1), s1 = (E - 1 - (G - 1)) & (G - 1), e = s0 ^ s1;
+        const int m = quad >> (gb - 1);
         if (m >= sc.gm) return;
         const int gA = sc.gpair[rnd][m][0], gB = sc.gpair[rnd][m][1];
-        const int i = insert_zero_bit(quad & 7, 31 - __clz(e));
-        P0 = 16 * gA + i; P1 = 16 * gB + (i ^ s0); P2 = 16 * gB + (i ^ s1); P3 = 16 * gA + (i ^ e);
+        const int i = insert_zero_bit(quad & ((G >> 1) - 1), 31 - __clz(e));
+        P0 = G * gA + i; P1 = G * gB + (i ^ s0); P2 = G * gB + (i ^ s1); P3 = G * gA + (i ^ e);
         swapB = true; swapD = true;
-        kcur0 = 16 * m + i; kcur1 = 16 * m + (i ^ e);
+        kcur0 = G * m + i; kcur1 = G * m + (i ^ e);
         knxt0 = kcur0; knxt1 = kcur1;
     } else {
         const int h1 = 31 - __clz(D);
