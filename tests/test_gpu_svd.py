@@ -236,6 +236,17 @@ def check_svd_large(gpu, W, s, r, n_sample=192, seed=5):
 
 
 @pytest.mark.timeout(1500)
+@pytest.mark.parametrize("shape", [(1536, 1536), (1280, 2560), (2560, 2560), (3072, 3072)])
+def test_svd_grouped_schedules_of_small_groups(gpu, shape):
+    """column counts whose super-panel count is not a power of two and not served by groups of 16: 24 super-panels = six groups of 4, 20 = ten
+    groups of 2, 40 = ten groups of 4, 48 = six groups of 8 (svd_jacobi.hip, group_bits_for) — full parity against the oracle's vectors"""
+    m, n = shape
+    W, s = llm_like(m, n, seed=31)
+    r = O.rank_from_ratio(m, n, 0.9)
+    info = check_svd(gpu, W, s, min(r, min(m, n)))
+    assert info.sweeps <= 10
+
+
 @pytest.mark.parametrize("shape", [(5120, 5120), (13824, 5120), (5120, 13824)])
 def test_svd_llama13b_shapes(gpu, shape):
     """Llama-2-13B q/k/v/o, gate/up and down shapes: 160 panels padded to a 256-wide XOR schedule (80 super-panels -> 128)."""
@@ -246,12 +257,13 @@ def test_svd_llama13b_shapes(gpu, shape):
 
 
 @pytest.mark.timeout(900)
-def test_grouped_schedule_fused_and_separate_passes_agree(gpu, monkeypatch):
-    """13B column counts (80 super-panels) run the grouped super-panel schedule; the update of a super-step is fused with the Gram tiles of the
+@pytest.mark.parametrize("n", [5120, 1536])
+def test_grouped_schedule_fused_and_separate_passes_agree(gpu, monkeypatch, n):
+    """13B column counts (80 super-panels: five groups of 16) and 1536 columns (24: six groups of 4) run the grouped super-panel schedule; the update of a super-step is fused with the Gram tiles of the
     next one there too (inside the groups AND between the offsets of a group pair).  Fused (split-fp16) and separate passes (ASVD_SUPGRAM=0)
     must meet parity with the same sweep count, and agree with each other to rounding."""
     from asvd4llm_amd import ops
-    W, s = llm_like(5120, 5120, seed=29)
+    W, s = llm_like(n, n, seed=29)
     Wd, sd = W.to(gpu), s.to(gpu)
     res = {}
     for flag in ("1", "0"):
@@ -261,7 +273,7 @@ def test_grouped_schedule_fused_and_separate_passes_agree(gpu, monkeypatch):
         res[flag] = (S.cpu(), info.sweeps)
     monkeypatch.delenv("ASVD_SUPGRAM")
     So = torch.linalg.svdvals(O.scaled_weight(W, s).double())
-    r = O.rank_from_ratio(5120, 5120, 0.9)
+    r = O.rank_from_ratio(n, n, 0.9)
     for flag in ("1", "0"):
         assert O.sigma_rel_err(res[flag][0], So.float(), r) <= SIG_TOL
     assert abs(res["1"][1] - res["0"][1]) <= 1
