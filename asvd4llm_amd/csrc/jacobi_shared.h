@@ -17,7 +17,7 @@ constexpr int EVD_PHASE_PAIRS = PW / 2;   // (A, B) phase pairs of one inner swe
 //    which on the norm-sorted, Cholesky-preconditioned matrices is where the coupling is: measured 10 -> 8 sweeps at 4096^2
 //    and 14 -> 9 on the row-scaled wide layers against the round-robin tournament (CPU prototype at n = 1024: 8 -> 6).
 //  * c_pair_order = 0 (ASVD_ORDER=rr, for A/B measurements): round-robin tournament (circle method), nb-1 steps of nb/2 pairs.
-// Everything a kernel needs to know about the call's pair schedules travels BY VALUE in its argument list (84 bytes of kernarg): round 2
+// Everything a kernel needs to know about the call's pair schedules travels BY VALUE in its argument list (under 300 bytes of kernarg): round 2
 // kept these in __constant__ symbols rewritten by every call, so two concurrent calls with different shapes (a grouped 13B schedule next
 // to an XOR one) overwrote each other's tables mid-flight.
 //   pair_order  1 XOR (default), 0 round-robin (ASVD_ORDER=rr)
