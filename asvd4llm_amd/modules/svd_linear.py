@@ -178,8 +178,13 @@ class SVDLinear(nn.Module):
             gk = (tuple(wc.shape), wc.dtype, wc.stride(0), wc.device, None if s is None else s.dtype)
             groups.setdefault(gk, []).append((lin, key, wc, s, k))
         for gk, items in groups.items():
-            for i in range(0, len(items), max_batch):
-                chunk = items[i:i + max_batch]
+            # max_batch is the chunk size of the big shapes (>= 2048 columns: one chunk of 32 fills every phase of a sweep); smaller problems are
+            # latency chains — 768 x 768: 944 SVD/s in chunks of 16, 1568 at 32, 1812 at 64, 2270 at 128 (bench.py --m 768 --n 768 --batch ...) —
+            # and their workspaces are small: twice / four times the chunk below 2048 / 1024 columns
+            kcols = min(gk[0])
+            chunk_size = max_batch * (1 if kcols >= 2048 else (2 if kcols >= 1024 else 4))
+            for i in range(0, len(items), chunk_size):
+                chunk = items[i:i + chunk_size]
                 k = max(it[4] for it in chunk)
                 scs = None if chunk[0][3] is None else [it[3] for it in chunk]
                 U, S, V, infos = ops.svd_batched([it[2] for it in chunk], scs, k=k)
