@@ -161,7 +161,7 @@ class SVDLinear(nn.Module):
         return U, S, V, s
 
     @staticmethod
-    def prefactorize(linears, act_aware=False, alpha=1, ranks=None, max_batch=32):
+    def prefactorize(linears, act_aware=False, alpha=1, ranks=None, max_batch=32, concurrent=True):
         """Factorise many Linears up front, same-shape ones CONCURRENTLY (asvd_svd_batched): independent matrices are what
         fills the 256 CUs during the 64-workgroup eigen-solve phase, and 288 GB of HBM hold the factors of a whole 7B/13B
         shard.  ranks: optional {linear: largest rank needed} (convergence is then only enforced for those leading triplets).
@@ -177,6 +177,7 @@ class SVDLinear(nn.Module):
             s = SVDLinear._scale_vector(lin, act_aware, alpha)
             gk = (tuple(wc.shape), wc.dtype, wc.stride(0), wc.device, None if s is None else s.dtype)
             groups.setdefault(gk, []).append((lin, key, wc, s, k))
+        jobs = []
         for gk, items in groups.items():
             # max_batch is the chunk size of the big shapes (>= 2048 columns: one chunk of 32 fills every phase of a sweep); smaller problems are
             # latency chains — 768 x 768: 944 SVD/s in chunks of 16, 1568 at 32, 1812 at 64, 2270 at 128 (bench.py --m 768 --n 768 --batch ...) —
@@ -184,15 +185,59 @@ class SVDLinear(nn.Module):
             kcols = min(gk[0])
             chunk_size = max_batch * (1 if kcols >= 2048 else (2 if kcols >= 1024 else 4))
             for i in range(0, len(items), chunk_size):
-                chunk = items[i:i + chunk_size]
-                k = max(it[4] for it in chunk)
-                scs = None if chunk[0][3] is None else [it[3] for it in chunk]
-                U, S, V, infos = ops.svd_batched([it[2] for it in chunk], scs, k=k)
-                for j, (lin, key, wc, s, _) in enumerate(chunk):
-                    if infos[j].status != 0:
-                        continue  # NaN / not converged: from_linear -> factorize handles it (retry, strict raise, or NaN fallback)
-                    lin._asvd_factor_cache = (key, (U[j], S[j], V[j], s))
-                    lin._asvd_svd_info = infos[j]
+                jobs.append((kcols, items[i:i + chunk_size]))
+
+        def run(chunk):
+            k = max(it[4] for it in chunk)
+            scs = None if chunk[0][3] is None else [it[3] for it in chunk]
+            U, S, V, infos = ops.svd_batched([it[2] for it in chunk], scs, k=k)
+            for j, (lin, key, wc, s, _) in enumerate(chunk):
+                if infos[j].status != 0:
+                    continue  # NaN / not converged: from_linear -> factorize handles it (retry, strict raise, or NaN fallback)
+                lin._asvd_factor_cache = (key, (U[j], S[j], V[j], s))
+                lin._asvd_svd_info = infos[j]
+            return U, S, V
+
+        # Calls of small problems (< 2048 columns) leave most of the chip idle between the launches of their dependency chain, and the library
+        # takes concurrent calls on different streams (include/asvd_hip.h; tests/test_gpu_concurrency.py): the groups of an opt-125m-shaped model
+        # (48 x 768^2, 12 x 3072x768, 12 x 768x3072, the 50272x768 lm_head) run side by side, one host thread and one stream each.
+        small = [c for kc, c in jobs if kc < 2048 and c[0][2].is_cuda]
+        if concurrent and len(small) > 1:
+            import threading
+            dev = small[0][0][2].device
+            main = torch.cuda.current_stream(dev)
+            errors, outs = [], []
+            lock = threading.Lock()
+            sem = threading.Semaphore(4)
+
+            def worker(chunk):
+                with sem:
+                    try:
+                        st = torch.cuda.Stream(device=dev)
+                        st.wait_stream(main)   # weights and scale vectors were produced on the caller's stream
+                        with torch.cuda.stream(st):
+                            res = run(chunk)
+                        st.synchronize()
+                        with lock:
+                            outs.append(res)
+                    except Exception as e:  # noqa: BLE001 — re-raised by the caller's thread below
+                        with lock:
+                            errors.append(e)
+
+            threads = [threading.Thread(target=worker, args=(c,)) for c in small]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+            for U, S, V in outs:   # allocated on the side streams, consumed on the caller's stream from here on
+                for lst in (U, S, V):
+                    for t in (lst or []):
+                        t.record_stream(main)
+            if errors:
+                raise errors[0]
+            jobs = [(kc, c) for kc, c in jobs if not (kc < 2048 and c[0][2].is_cuda)]
+        for _, chunk in jobs:
+            run(chunk)
 
     @staticmethod
     def drop_factor_cache(linear):
