@@ -204,6 +204,8 @@ class SVDLinear(nn.Module):
         small = [c for kc, c in jobs if kc < 2048 and c[0][2].is_cuda]
         if concurrent and len(small) > 1:
             import threading
+            from .. import _lib
+            _lib.load(True)   # loaded (and, if need be, built) once, by this thread
             dev = small[0][0][2].device
             main = torch.cuda.current_stream(dev)
             errors, outs = [], []
