@@ -82,7 +82,7 @@ def calib_input_distribution(model, calib_loader, method, use_cache=True, shard_
     cache_file = f"cache/{model_id.replace('/','_')}_calib_input_distribution_{method}.pt"
     from . import parallel
     if use_cache and parallel.cache_exists(cache_file):
-        all_scaling_diag_matrix = torch.load(cache_file, map_location="cpu")
+        all_scaling_diag_matrix = parallel.load_cache(cache_file)
         for name, module in model.named_modules():
             if isinstance(module, nn.Linear):
                 module.scaling_diag_matrix = all_scaling_diag_matrix[name].to(module.weight.device)
@@ -123,7 +123,7 @@ def calib_fisher_info(model, calib_loader, use_cache=True):
     cache_file = f"cache/{model_id.replace('/','_')}_calib_fisher_info.pt"
     from . import parallel
     if use_cache and parallel.cache_exists(cache_file):
-        all_fisher_info = torch.load(cache_file, map_location="cpu")
+        all_fisher_info = parallel.load_cache(cache_file)
         for name, module in model.named_modules():
             if isinstance(module, nn.Linear):
                 module.fisher_info = all_fisher_info[name].to(module.weight.device)

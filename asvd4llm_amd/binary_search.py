@@ -141,6 +141,13 @@ def _decompose(model, modules, linear_info, layers_min_ratio, default_ratio, fro
     linears = list(linear_info.items())
     owner_list = parallel.lpt_assign([parallel.svd_flops(l.out_features, l.in_features) for l, _ in linears], ws)
     owner = {info["full_name"]: o for (_, info), o in zip(linears, owner_list)}
+    # a ppl sweep that ran in this process sharded the layers on ITS cost model (parallel.sweep_layer_costs) and left the factorisations cached
+    # with those owners: follow that map (slicing a cached factorisation is ~1 ms; the map above would re-factorise on another rank).  The map
+    # is a deterministic function of the model and the arguments, so it is identical on every rank; a sensitivity dict that came from a
+    # cache file or from the stable-rank metric has no such map and the decomposition is balanced on its own cost, the SVD flops.
+    sweep_owner = getattr(model, "_asvd_sweep_owner", None)
+    if shard and sweep_owner is not None and set(sweep_owner) == set(owner) and max(sweep_owner.values()) < ws:
+        owner = dict(sweep_owner)
     # tied weights (OPT: lm_head.weight IS embed_tokens.weight): the reference's `raw_linear.to("cpu")` would drag the embedding to the
     # CPU with it and break the next forward; only weights no other module shares are offloaded
     uses = {}

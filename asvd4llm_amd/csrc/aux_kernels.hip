@@ -351,8 +351,9 @@ typedef __bf16 b16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256) void pad_rows16_kernel(const uint16_t* __restrict__ A, int64_t m, int64_t r, int64_t rp, uint16_t* __restrict__ Ap) {
-    const int64_t row = blockIdx.y;
-    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < rp; k += (int64_t)gridDim.x * 256) Ap[row * rp + k] = k < r ? A[row * r + k] : (uint16_t)0;
+    // rows on gridDim.x (no 65535 limit: a 128256-row lm_head), the columns of a row strided over the workgroup
+    const int64_t row = blockIdx.x;
+    for (int64_t k = threadIdx.x; k < rp; k += 256) Ap[row * rp + k] = k < r ? A[row * r + k] : (uint16_t)0;
 }
 // Bt[j][k] = B[k][j] through 32 x 32 tiles (both sides coalesced), zero for k >= r.  grid (ceil(n/32), rp/32)
 __global__ __launch_bounds__(256) void transpose_pad16_kernel(const uint16_t* __restrict__ B, int64_t r, int64_t n, int64_t rp, uint16_t* __restrict__ Bt) {
@@ -653,7 +654,7 @@ int asvd_reconstruct_err(const void* W, int w_dtype, int64_t ldw, const void* A,
     const int64_t rp = round_up64(r, 64);
     uint16_t* Ap = (uint16_t*)((char*)work + recon_part_bytes(m, n));
     uint16_t* Bt = Ap + m * rp;
-    pad_rows16_kernel<<<dim3((unsigned)std::min<int64_t>(ceil_div64(rp, 256), 64), (unsigned)m), 256, 0, st>>>((const uint16_t*)A, m, r, rp, Ap);
+    pad_rows16_kernel<<<dim3((unsigned)m), 256, 0, st>>>((const uint16_t*)A, m, r, rp, Ap);
     transpose_pad16_kernel<<<dim3((unsigned)ceil_div64(n, 32), (unsigned)(rp / 32)), 256, 0, st>>>((const uint16_t*)B, r, n, rp, Bt);
     const int64_t gx = ceil_div64(n, 128), gy = ceil_div64(m, 128);
     dim3 grid((unsigned)gx, (unsigned)gy);

@@ -43,7 +43,7 @@ __device__ __forceinline__ void grid_barrier(unsigned* bar, unsigned nwg) {
     // requests in issue order) and the compiler barrier keeps the program order.  The spin is BOUNDED: the launch is not cooperative, so
     // co-residency of the <= #CUs workgroups is an assumption (another stream's persistent kernel could hold CUs); after ~2^22 polls a
     // waiter sets bar[2] and leaves instead of hanging the GPU.  What it computes next comes from an incomplete z, so the failure is made
-    // VISIBLE: every workgroup ends with poison_if_gave_up(), which overwrites its slice of y with NaN when the flag is set.  (A waiter gives
+    // VISIBLE: every workgroup ends by overwriting the elements of y it stored with NaN when the flag is set (gave_up).  (A waiter gives
     // up only while the barrier is incomplete, so every workgroup that passes normally does so AFTER the flag was set and sees it at its end.)
     // ops.lowrank_forward additionally reads and clears the word under ASVD_STRICT / ASVD_DEBUG and raises.
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's z stores have been acknowledged (s_waitcnt vmcnt(0)); no L2 write-back
@@ -70,11 +70,11 @@ __device__ __forceinline__ void grid_barrier(unsigned* bar, unsigned nwg) {
     __syncthreads();
 }
 
-// last statement of both kernels: a launch in which some workgroup left the barrier without its peers has no valid output
-__device__ __forceinline__ void poison_if_gave_up(const unsigned* bar, uint16_t* __restrict__ y, int64_t count) {
-    if (__hip_atomic_load(&bar[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (int64_t)gridDim.x * blockDim.x) y[e] = 0x7e00;  // fp16 NaN
-}
+// last statement of both kernels: a launch in which some workgroup left the barrier without its peers has no valid output.  Every workgroup
+// overwrites exactly the elements of y IT stored, after its own stores (a slice of all of y would race with the stores of workgroups that
+// are still in phase 2: NaN mixed with finite garbage).  The flag is read after the workgroup's last store: a workgroup can only give up
+// while the barrier is incomplete, i.e. before any workgroup starts phase 2.
+__device__ __forceinline__ bool gave_up(const unsigned* bar) { return __hip_atomic_load(&bar[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u; }
 
 // One 32 x 32 output tile  C[i][j] = sum_k P[prow0+i][k] * Q[qrow0+j][k]  over k in [0, 64*nk), fp32, all four waves.
 // Rows i >= pvalid of P and j >= qvalid of Q read as zero.  Result is left in red[] (sum of the 4 wave partials is done by the caller).
@@ -168,7 +168,14 @@ __global__ __launch_bounds__(256, 1) void lowrank_forward_kernel(const uint16_t*
         }
         __syncthreads();
     }
-    poison_if_gave_up(bar, y, (int64_t)T * N);
+    if (gave_up(bar))   // poison this workgroup's own tiles
+        for (int u = blockIdx.x; u < nT * ns2; u += G) {
+            const int t0 = (u / ns2) * 32, n0 = (u % ns2) * sl2, nvalid = min(sl2, N - n0);
+            for (int e = tid; e < 1024; e += 256) {
+                const int row = e >> 5, col = e & 31;
+                if (col < nvalid && t0 + row < T) y[(int64_t)(t0 + row) * N + n0 + col] = 0x7e00;  // fp16 NaN
+            }
+        }
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -257,8 +264,9 @@ __global__ __launch_bounds__(512, 1) void lowrank_gemv_kernel(const uint16_t* __
     for (int e = tid; e < TT * r8; e += 512) gv_smem[e] = z_load16((const uint4*)z + e);
     __syncthreads();
     gemv_rows<TT, false>(wv, (const uint4*)Ap, r8, N, r8, gv_smem, gw, nw, lane, y, N, bias, T);
-    __syncthreads();
-    poison_if_gave_up(bar, y, (int64_t)T * N);
+    if (gave_up(bar) && lane == 0)   // poison the rows this wave stored (gemv_rows: rows gw, gw + nw, ...)
+        for (int j = gw; j < N; j += nw)
+            for (int t = 0; t < T; ++t) y[(int64_t)t * N + j] = 0x7e00;  // fp16 NaN
 }
 
 }  // namespace

@@ -596,9 +596,31 @@ static int svd_direct_run(int batch, const void* const* a_host, int a_dtype, int
             // which reads every panel of a quad with a present member, loses to the separate passes, which touch only the pairs that exist
             // (13B shapes, ns = 80 in a 128-wide schedule: always fused 21.4 s, never fused 16.9 s for the model): fused on full schedules only
             const bool ns_pow2 = (p.ns & (p.ns - 1)) == 0;
+            // ASVD_SPREAD_FROM=<k> (measurement knob, XOR schedules over 4^j super-panels only): from dense sweep k (0-based) on, the XOR
+            // distances run in LINE-SPREAD order — triples {d, w(d), w^2(d)}, w: base-4 digits 1 -> 2 -> 3 -> 1, which XOR to zero, so that the
+            // four super-panels {a, a^D, a^E, a^D^E} of a quad are closed under all three steps of a triple (what a
+            // three-steps-per-pass kernel would need).  Any order of the distances is a valid sweep; this one gives up nearest-neighbour-first.
+            std::vector<int> dist(nsuper);
+            for (int di = 0; di < nsuper; ++di) dist[di] = di + 1;
+            {
+                const char* es = getenv("ASVD_SPREAD_FROM");
+                int lg = 0;
+                while ((1 << lg) < p.ns) ++lg;
+                if (es && !super_grp && ns_pow2 && (lg % 2) == 0 && sweep >= atoi(es)) {
+                    auto w = [](int d) { int o = 0; for (int sh = 0; sh < 30; sh += 2) { const int g = (d >> sh) & 3; o |= (g == 0 ? 0 : (g == 1 ? 2 : (g == 2 ? 3 : 1))) << sh; } return o; };
+                    std::vector<char> used(p.ns, 0);
+                    int at = 0;
+                    for (int d = 1; d < p.ns; ++d) {
+                        if (used[d]) continue;
+                        const int d2 = w(d), d3 = w(d2);
+                        used[d] = used[d2] = used[d3] = 1;
+                        dist[at++] = d; dist[at++] = d2; dist[at++] = d3;
+                    }
+                }
+            }
             for (int di = 0; di < nsuper; ++di) {
-                const int D = di + 1;
-                const int E = (di + 1 < nsuper) ? D + 1 : 0;  // 0: last super-step of the sweep
+                const int D = dist[di];
+                const int E = (di + 1 < nsuper) ? dist[di + 1] : 0;  // 0: last super-step of the sweep
                 auto fused_after = [&](int dj) {  // does the launch of super-step index dj also leave the tiles of index dj + 1 ?
                     if (!fuse_ug || dj < 0 || dj + 1 >= nsuper) return false;
                     if (super_grp) {  // consecutive steps inside the groups (XOR distances 1..15), or consecutive offsets of the same round of group pairs

@@ -10,7 +10,7 @@ def get_calib_data(name, tokenizer, model_id, nsamples, seqlen=2048, seed=3, use
     cache_file = f"cache/{name}_{model_id.replace('/','_')}_{nsamples}_{seqlen}_{seed}_bos{use_bos}.pt"
     from . import parallel
     if parallel.cache_exists(cache_file):  # one answer for all ranks; the file is complete (written under a temporary name, then renamed)
-        return torch.load(cache_file)
+        return parallel.load_cache(cache_file)
     if name != "synthetic":
         raise RuntimeError(f"calibration dataset '{name}' needs HF datasets + network, unavailable here; use --calib_dataset synthetic")
     if vocab_size is None:

@@ -206,32 +206,46 @@ class SVDLinear(nn.Module):
             import threading
             from .. import _lib
             _lib.load(True)   # loaded (and, if need be, built) once, by this thread
-            dev = small[0][0][2].device
-            main = torch.cuda.current_stream(dev)
+            # every chunk lives on ONE device (the group key holds it): its side stream, the stream it waits for and the stream its outputs
+            # are handed back to are that device's.  A small fixed pool of side streams per device is reused by the workers (a fresh stream
+            # per chunk would leave its workspace cached in a pool nobody uses again)
             errors, outs = [], []
             lock = threading.Lock()
-            sem = threading.Semaphore(4)
+            nslots = 4
+            pools = {}
+            for c in small:
+                d = c[0][2].device
+                if d not in pools:   # (side streams, admission, free slots, the CALLER's current stream of that device — current streams are per thread)
+                    pools[d] = ([torch.cuda.Stream(device=d) for _ in range(nslots)], threading.Semaphore(nslots), list(range(nslots)), torch.cuda.current_stream(d))
 
             def worker(chunk):
+                dev = chunk[0][2].device
+                streams, sem, free, main = pools[dev]
                 with sem:
+                    with lock:
+                        slot = free.pop()
                     try:
-                        st = torch.cuda.Stream(device=dev)
-                        st.wait_stream(main)   # weights and scale vectors were produced on the caller's stream
-                        with torch.cuda.stream(st):
+                        st = streams[slot]
+                        st.wait_stream(main)   # weights and scale vectors were produced on the caller's stream of that device
+                        with torch.cuda.device(dev), torch.cuda.stream(st):
                             res = run(chunk)
                         st.synchronize()
                         with lock:
-                            outs.append(res)
+                            outs.append((dev, res))
                     except Exception as e:  # noqa: BLE001 — re-raised by the caller's thread below
                         with lock:
                             errors.append(e)
+                    finally:
+                        with lock:
+                            free.append(slot)
 
             threads = [threading.Thread(target=worker, args=(c,)) for c in small]
             for t in threads:
                 t.start()
             for t in threads:
                 t.join()
-            for U, S, V in outs:   # allocated on the side streams, consumed on the caller's stream from here on
+            for dev, (U, S, V) in outs:   # allocated on the side streams, consumed on the caller's stream of their device from here on
+                main = pools[dev][3]
                 for lst in (U, S, V):
                     for t in (lst or []):
                         t.record_stream(main)

@@ -36,6 +36,77 @@ def lpt_assign(costs, world_size):
     return owner
 
 
+# ---- cost model of the ppl sweep (what the LPT shard of calib_sensitivity_ppl balances) -----------------------------------------------
+# One layer of the sweep = one factorisation + ONE batched suffix pass per calibration sample (sweep_eval.PrefixCachedEvaluator): the blocks
+# in FRONT of the swapped layer are replayed from cached hidden states, so a layer in block i of an N-block model costs the N - i blocks behind
+# it plus the head, times the number of candidate ratios (they run as one batch), and lm_head costs its own GEMM only.  On Llama-2-7B with
+# n_calib 32 the forwards are 755 of the 761 s (profiles/r4_e2e_llama2_7b_ncalib32.json): balancing the shard on SVD flops alone says nothing
+# about the stage that is 99 % of the wall-clock.  Rates are the measured ones of round 4 (one MI355X): 826 TFLOP/s sustained through the
+# fp16 forwards of the sweep, 109 TFLOP/s (full-SVD flop count) through the factorisations.
+SWEEP_FORWARD_FLOPS_PER_S = 826e12
+SWEEP_SVD_FLOPS_PER_S = 109e12
+
+
+def sweep_layer_costs(layers, n_blocks, block_params, head_params, n_ratios, n_samples, seqlen, attn_flops_per_token_block=0.0):
+    """Predicted seconds of every layer's share of the ppl sweep.  layers: [(out_features, in_features, where)] in traversal order with
+    where = block index (0-based) for a Linear inside decoder block `where`, "after" for one that runs behind the last block (lm_head),
+    "before" for one in front of the blocks (nothing can be replayed: full forward).  block_params / head_params: Linear parameters of one
+    decoder block / of the layers behind the blocks (2 flop per parameter and token)."""
+    tokens = float(n_samples) * float(seqlen) * float(n_ratios)
+    per_block = 2.0 * block_params + attn_flops_per_token_block
+    head = 2.0 * head_params
+    costs = []
+    for out_f, in_f, where in layers:
+        if where == "after":
+            fwd = head
+        elif where == "before":
+            fwd = n_blocks * per_block + head
+        else:
+            fwd = (n_blocks - int(where)) * per_block + head
+        costs.append(svd_flops(out_f, in_f) / SWEEP_SVD_FLOPS_PER_S + tokens * fwd / SWEEP_FORWARD_FLOPS_PER_S)
+    return costs
+
+
+def sweep_costs_for_model(model, linears, n_ratios, n_samples, seqlen, prefix_cached=True):
+    """sweep_layer_costs for the nn.Linears of `model` (linears: [(module, info)] as sensitivity.collect_linear_info yields them): the block
+    structure is read the way the evaluator reads it (sweep_eval.find_decoder_blocks); a model without a block list falls back to SVD flops."""
+    import torch.nn as nn
+    from .sweep_eval import find_decoder_blocks
+    blocks_name, blocks = find_decoder_blocks(model)
+    if blocks is None:
+        return [svd_flops(l.out_features, l.in_features) for l, _ in linears]
+    prefix = blocks_name + "."
+    n_blocks = len(blocks)
+    block_params = sum(m.weight.numel() for m in blocks[0].modules() if isinstance(m, nn.Linear))
+    where, head_params = [], 0
+    for l, info in linears:
+        name = info["full_name"]
+        if name.startswith(prefix):
+            where.append(int(name[len(prefix):].split(".")[0]))
+        else:
+            # the capture pass of the evaluator decides "before" / "after" from the call order; by name: heads come after, projections in
+            # front of the blocks (OPT project_in) before
+            w = "before" if ("project_in" in name or "embed" in name) else "after"
+            where.append(w)
+            if w == "after":
+                head_params += l.weight.numel()
+    hidden = getattr(getattr(model, "config", None), "hidden_size", None) or 0
+    attn = 4.0 * hidden * (seqlen / 2.0)   # QK^T and PV under a causal mask, per token and block
+    if not prefix_cached:   # --no_fused_sweep: every evaluation is a full forward
+        where = ["before"] * len(where)
+    return sweep_layer_costs([(l.out_features, l.in_features, w) for (l, _), w in zip(linears, where)], n_blocks, block_params, head_params,
+                             n_ratios, n_samples, seqlen, attn)
+
+
+def load_balance(costs, owner, world_size):
+    """max over ranks / mean over ranks of the summed cost"""
+    load = [0.0] * world_size
+    for c, o in zip(costs, owner):
+        load[o] += c
+    mean = sum(load) / world_size
+    return (max(load) / mean) if mean > 0 else 1.0
+
+
 def _comm_device():
     backend = dist.get_backend()
     return torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
@@ -59,16 +130,35 @@ def cache_exists(path):
 
 def save_cache(obj, path):
     """`.pt` cache files are written by rank 0 only, to a temporary name that is renamed into place (a reader sees the complete file or
-    none), and every rank waits until the file is there before it goes on."""
-    rank, _ = world()
+    none), and every rank learns whether that worked before it goes on: a failure on rank 0 (disk full, permissions) is raised on EVERY
+    rank instead of leaving the others in a barrier.  The caches assume ONE working directory shared by all ranks (single node)."""
+    rank, ws = world()
+    err = None
     if rank == 0:
-        d = os.path.dirname(path)
-        if d:
-            os.makedirs(d, exist_ok=True)
-        tmp = f"{path}.tmp.{os.getpid()}"
-        torch.save(obj, tmp)
-        os.replace(tmp, path)
-    barrier()
+        try:
+            d = os.path.dirname(path)
+            if d:
+                os.makedirs(d, exist_ok=True)
+            tmp = f"{path}.tmp.{os.getpid()}"
+            torch.save(obj, tmp)
+            os.replace(tmp, path)
+        except Exception as e:  # noqa: BLE001 — re-raised below, on all ranks
+            err = e
+    if ws > 1:
+        ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device=_comm_device())
+        dist.broadcast(ok, src=0)
+        if int(ok.item()) == 0 and err is None:
+            err = RuntimeError(f"rank 0 could not write the cache file {path} (see its stderr)")
+    if err is not None:
+        raise err
+
+
+def load_cache(path):
+    """torch.load of a cache file every rank is about to read; a rank that does not see it (no shared working directory) gets a clear error"""
+    if not os.path.exists(path):
+        raise FileNotFoundError(f"{path}: rank 0 reported this cache file but rank {world()[0]} cannot see it — the .pt caches need ONE working "
+                                "directory shared by all ranks (or run with use_cache=False)")
+    return torch.load(path, map_location="cpu")
 
 
 def allgather_sensitivities(local, names, ratios, owner):
@@ -108,6 +198,53 @@ def allgather_sensitivities(local, names, ratios, owner):
     return full
 
 
+def _wire_of(mod, raw):
+    """(header, payload tensors) of one decomposed layer: int64 [kind, rank, has_bias, out, in], then ALinear.weight, BLinear.weight (kind 1 =
+    SVDLinear) or weight (kind 0 = plain nn.Linear: the reference's random-Linear fallback after a failed factorisation), then the bias"""
+    from .modules.svd_linear import SVDLinear
+    if isinstance(mod, SVDLinear):
+        bias = mod.ALinear.bias
+        hdr = [1, mod.truncation_rank, int(bias is not None), raw.out_features, raw.in_features]
+        payload = [mod.ALinear.weight.data, mod.BLinear.weight.data]
+    else:
+        bias = mod.bias
+        hdr = [0, 0, int(bias is not None), raw.out_features, raw.in_features]
+        payload = [mod.weight.data]
+    if bias is not None:
+        payload.append(bias.data)
+    return hdr, payload
+
+
+def _module_from_wire(kind, r, has_bias, out_f, in_f, ts, dtype):
+    import torch.nn as nn
+    from .modules.svd_linear import SVDLinear
+    bias_t = ts[-1] if has_bias else None
+    if kind == 1:
+        return SVDLinear._from_factors(ts[0], ts[1], bias_t, r)
+    new = nn.Linear(in_f, out_f, bias=bool(has_bias)).to(dtype)
+    new.weight.data = ts[0]
+    if has_bias:
+        new.bias.data = bias_t
+    return new
+
+
+def _wire_shapes(kind, r, has_bias, out_f, in_f):
+    shapes = [(out_f, r), (r, in_f)] if kind == 1 else [(out_f, in_f)]
+    if has_bias:
+        shapes.append((out_f,))
+    return shapes
+
+
+def _p2p_all(ops):
+    """post every send / receive of `ops` at once ((fn, tensor, peer, tag) tuples), then wait for all of them: the transfers of different
+    peers run side by side (RCCL: one group call, every xGMI link of the receiver busy; gloo: one pending request per message)"""
+    if not ops:
+        return
+    reqs = dist.batch_isend_irecv([dist.P2POp(fn, t, peer, tag=tag) for fn, t, peer, tag in ops])
+    for q in reqs:
+        q.wait()
+
+
 def exchange_factors(items, owner, mode="rank0"):
     """Complete the model after a sharded decomposition (binary_search_truncation_rank with layers LPT-sharded over ranks).
 
@@ -115,71 +252,78 @@ def exchange_factors(items, owner, mode="rank0"):
     identical on all ranks; `owner[full_name]` decomposed it and holds the new module under father.child_name, every other rank
     still holds the raw nn.Linear there.
       mode "all"   : the owner broadcasts its factors, every rank ends with the complete compressed model;
-      mode "rank0" : the owner sends them to rank 0 only (point-to-point: each transfer crosses one xGMI link, nothing is relayed
-                     around a ring) — rank 0 exports / evaluates, the other ranks keep their shard;
+      mode "rank0" : the owners send them to rank 0 only, point to point (each transfer crosses one xGMI link, nothing is relayed around a
+                     ring) and ALL AT ONCE: rank 0 posts every receive, every owner posts every send, then everybody waits — the seven
+                     links into rank 0 carry their shards concurrently (SURVEY 5 sizes the ~12 GB of Llama-2-7B at 10-12 ms per link-load
+                     only if all links are driven; a layer-by-layer blocking send / recv used one link at a time).  Two rounds: the
+                     headers (rank 0 cannot know whether an owner fell back to a plain Linear), then the payloads;
       mode "none"  : nothing moves.
-    Wire format per layer: int64 header [kind, rank, has_bias, out, in] (kind 1 = SVDLinear, 0 = plain nn.Linear: the reference's
-    random-Linear fallback after a failed factorisation), then ALinear.weight, BLinear.weight (or weight), then bias.
-    Returns the number of layers this rank received."""
+    Wire format per layer: see _wire_of.  Returns the number of layers this rank received."""
     if mode == "none" or not (dist.is_available() and dist.is_initialized()):
         return 0
-    import torch.nn as nn
-    from .modules.svd_linear import SVDLinear
     rank, ws = world()
     dev = _comm_device()
     received = 0
+    if mode == "rank0":
+        moving = [(i, it) for i, it in enumerate(items) if owner[it[0]] != 0]
+        if rank != 0:
+            moving = [(i, it) for i, it in moving if owner[it[0]] == rank]
+        if not moving:
+            return 0
+        # round 1: headers
+        hdrs, wires, ops = {}, {}, []
+        for i, (full_name, father, child, raw) in moving:
+            if rank == 0:
+                hdrs[i] = torch.empty(5, dtype=torch.int64, device=dev)
+                ops.append((dist.irecv, hdrs[i], owner[full_name], 4 * i))
+            else:
+                h, payload = _wire_of(getattr(father, child), raw)
+                hdrs[i] = torch.tensor(h, dtype=torch.int64, device=dev)
+                wires[i] = [t.to(dev).contiguous() for t in payload]
+                ops.append((dist.isend, hdrs[i], 0, 4 * i))
+        _p2p_all(ops)
+        # round 2: payloads
+        ops, metas = [], {}
+        for i, (full_name, father, child, raw) in moving:
+            if rank == 0:
+                kind, r, has_bias, out_f, in_f = (int(v) for v in hdrs[i].tolist())
+                assert (out_f, in_f) == (raw.out_features, raw.in_features), f"factor exchange out of step at {full_name}"
+                ts = [torch.empty(shp, dtype=raw.weight.dtype, device=dev) for shp in _wire_shapes(kind, r, has_bias, out_f, in_f)]
+                metas[i] = (kind, r, has_bias, out_f, in_f, ts)
+                for j, t in enumerate(ts):
+                    ops.append((dist.irecv, t, owner[full_name], 4 * i + 1 + j))
+            else:
+                for j, t in enumerate(wires[i]):
+                    ops.append((dist.isend, t, 0, 4 * i + 1 + j))
+        _p2p_all(ops)
+        if rank == 0:
+            for i, (full_name, father, child, raw) in moving:
+                kind, r, has_bias, out_f, in_f, ts = metas[i]
+                wdev = raw.weight.device
+                ts = [(t.to(wdev) if wdev.type != "cpu" or dev.type == "cpu" else t) for t in ts]
+                setattr(father, child, _module_from_wire(kind, r, has_bias, out_f, in_f, ts, raw.weight.dtype))
+                received += 1
+        return received
 
-    def xfer(t, src, sending):
-        if mode == "all":
-            dist.broadcast(t, src=src)
-        elif sending:
-            dist.send(t, dst=0)
-        else:
-            dist.recv(t, src=src)
-
+    # mode "all": one broadcast per tensor, layer by layer (a broadcast is a collective of the whole group: they serialise anyway)
     for full_name, father, child, raw in items:
         src = owner[full_name]
-        if mode == "rank0" and (src == 0 or rank not in (0, src)):
-            continue
-        sending = rank == src
         dtype, wdev = raw.weight.dtype, raw.weight.device
-        if sending:
-            mod = getattr(father, child)
-            if isinstance(mod, SVDLinear):
-                bias = mod.ALinear.bias
-                hdr = [1, mod.truncation_rank, int(bias is not None), raw.out_features, raw.in_features]
-                payload = [mod.ALinear.weight.data, mod.BLinear.weight.data]
-            else:
-                bias = mod.bias
-                hdr = [0, 0, int(bias is not None), raw.out_features, raw.in_features]
-                payload = [mod.weight.data]
-            if bias is not None:
-                payload.append(bias.data)
-            h = torch.tensor(hdr, dtype=torch.int64, device=dev)
-            xfer(h, src, True)
+        if rank == src:
+            hdr, payload = _wire_of(getattr(father, child), raw)
+            dist.broadcast(torch.tensor(hdr, dtype=torch.int64, device=dev), src=src)
             for t in payload:
-                xfer(t.to(dev).contiguous(), src, True)
+                dist.broadcast(t.to(dev).contiguous(), src=src)
             continue
         h = torch.empty(5, dtype=torch.int64, device=dev)
-        xfer(h, src, False)
+        dist.broadcast(h, src=src)
         kind, r, has_bias, out_f, in_f = (int(v) for v in h.tolist())
         assert (out_f, in_f) == (raw.out_features, raw.in_features), f"factor exchange out of step at {full_name}"
-        shapes = [(out_f, r), (r, in_f)] if kind == 1 else [(out_f, in_f)]
-        if has_bias:
-            shapes.append((out_f,))
         ts = []
-        for shp in shapes:
+        for shp in _wire_shapes(kind, r, has_bias, out_f, in_f):
             t = torch.empty(shp, dtype=dtype, device=dev)
-            xfer(t, src, False)
+            dist.broadcast(t, src=src)
             ts.append(t.to(wdev) if wdev.type != "cpu" or dev.type == "cpu" else t)
-        bias_t = ts[-1] if has_bias else None
-        if kind == 1:
-            new = SVDLinear._from_factors(ts[0], ts[1], bias_t, r)
-        else:
-            new = nn.Linear(in_f, out_f, bias=bool(has_bias)).to(dtype)
-            new.weight.data = ts[0]
-            if has_bias:
-                new.bias.data = bias_t
-        setattr(father, child, new)
+        setattr(father, child, _module_from_wire(kind, r, has_bias, out_f, in_f, ts, dtype))
         received += 1
     return received

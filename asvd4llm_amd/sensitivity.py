@@ -72,7 +72,7 @@ def calib_sensitivity_ppl(model, calib_loader, args, use_cache=True):
     model_id = model.config._name_or_path
     cache_file = f"cache/{model_id.replace('/','_')}_sensitivity_{args.scaling_method}_{args.alpha}_{args.n_calib_samples}_{args.calib_dataset}.pt"
     if use_cache and parallel.cache_exists(cache_file):
-        sensitivity_dict = torch.load(cache_file, map_location="cpu")
+        sensitivity_dict = parallel.load_cache(cache_file)
         return sensitivity_dict
     model.eval()
     linear_info = collect_linear_info(model)
@@ -83,7 +83,13 @@ def calib_sensitivity_ppl(model, calib_loader, args, use_cache=True):
     rank, ws = parallel.world()
     linears = list(linear_info.items())
     names = [info["full_name"] for _, info in linears]
-    owner = parallel.lpt_assign([parallel.svd_flops(l.out_features, l.in_features) for l, _ in linears], ws)
+    # the shard is balanced on the stage that costs the time: the suffix forwards behind each layer (parallel.sweep_layer_costs: a layer of
+    # block 0 replays the whole model for every sample, lm_head replays nothing) plus its factorisation — not on the SVD flops alone
+    costs = parallel.sweep_costs_for_model(model, linears, len(param_ratio_candidates), min(input_ids.shape[0], args.n_calib_samples), input_ids.shape[1],
+                                           prefix_cached=getattr(args, "fused_sweep", True))
+    owner = parallel.lpt_assign(costs, ws)
+    model._asvd_sweep_owner = {n: o for n, o in zip(names, owner)}   # the factor caches live with these owners: the final decomposition follows them
+    model._asvd_sweep_balance = {"predicted_seconds_per_rank_max_over_mean": parallel.load_balance(costs, owner, ws), "world_size": ws}
     keep_cache = getattr(args, "keep_svd_cache", True)
 
     local = {}
@@ -157,7 +163,7 @@ def calib_sensitivity_stable_rank(model, calib_loader, args, use_cache=True):
     model_id = model.config._name_or_path
     cache_file = f"cache/{model_id.replace('/','_')}_sensitivity_stable_rank_{args.scaling_method}_{args.alpha}_{args.n_calib_samples}_{args.calib_dataset}.pt"
     if use_cache and parallel.cache_exists(cache_file):
-        sensitivity_dict = torch.load(cache_file, map_location="cpu")
+        sensitivity_dict = parallel.load_cache(cache_file)
         return sensitivity_dict
     model.eval()
     linear_info = collect_linear_info(model)

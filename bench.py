@@ -49,11 +49,56 @@ def model_linears(name):
     return out
 
 
-def sharded_model_leg(name, rank, world, dev, ratio=0.9, dry=False):
+def model_sweep_costs(name, n_ratios=6, n_samples=32, seqlen=2048):
+    """predicted seconds of every layer's share of the ppl sweep (parallel.sweep_layer_costs) for the Linears of model_linears(name)"""
+    from asvd4llm_amd import parallel
+    c = MODEL_SHAPES[name]
+    block_params = 4 * c["attn"][0] * c["attn"][1] + 2 * c["up"][0] * c["up"][1] + c["down"][0] * c["down"][1]
+    lay = [(o, i, "after" if n == "lm_head" else int(n.split(".")[2])) for n, o, i in model_linears(name)]
+    return parallel.sweep_layer_costs(lay, c["layers"], block_params, c["head"][0] * c["head"][1], n_ratios, n_samples, seqlen,
+                                      4.0 * c["attn"][1] * seqlen / 2.0)
+
+
+def predicted_sweep_balance(world=8, models=("llama-2-7b", "llama-2-13b")):
+    """BASELINE configs[3] / [4] are 99 % sweep: the LPT shard of calib_sensitivity_ppl is balanced on the predicted sweep seconds per layer
+    (suffix forwards + factorisation), the final decomposition on SVD flops.  Host arithmetic only — reported so that the first 8-GPU run
+    does not have to discover a straggler."""
+    from asvd4llm_amd import parallel
+    out = {}
+    for name in models:
+        costs = model_sweep_costs(name)
+        flops = [parallel.svd_flops(o, i) for _, o, i in model_linears(name)]
+        own = parallel.lpt_assign(costs, world)
+        own_f = parallel.lpt_assign(flops, world)
+        out[name] = {"ranks": world, "n_calib": 32, "seqlen": 2048, "ratios": 6, "predicted_sweep_s_one_gpu": sum(costs),
+                     "predicted_sweep_s_per_rank_max": max(sum(c for c, o in zip(costs, own) if o == r) for r in range(world)),
+                     "sweep_s_max_over_mean": parallel.load_balance(costs, own, world),
+                     "sweep_s_max_over_mean_if_sharded_on_svd_flops": parallel.load_balance(costs, own_f, world),
+                     "decompose_flops_max_over_mean": parallel.load_balance(flops, own_f, world)}
+    return out
+
+
+class _Slot:
+    """stand-in for the father module of a layer in the factor-exchange leg (parallel.exchange_factors only needs getattr / setattr)"""
+
+
+class _RawShape:
+    """what exchange_factors reads of a raw nn.Linear it does not own: shape, dtype and device of the weight"""
+
+    def __init__(self, out_features, in_features, dev, dtype):
+        import torch
+        self.out_features, self.in_features = out_features, in_features
+        self.weight = torch.empty(0, dtype=dtype, device=dev)
+
+
+def sharded_model_leg(name, rank, world, dev, ratio=0.9, dry=False, samples=None):
     """BASELINE configs[3]: the Linears of a Llama-2-7B-shaped model LPT-sharded over the ranks, every rank decomposes its own layers with the HIP
     path, ONE all-gather of the per-layer sensitivities on the process group (RCCL when the bench runs on GPUs), then the replicated search.
-    Untimed extra of `bench.py --gpus N` (not part of `value`); returns the record rank 0 prints under "sharded_model".  dry: no kernels (gloo
-    plumbing test): the sensitivities are made up, everything else is the real code path."""
+    Untimed extra of `bench.py --gpus N` (not part of `value`); returns the record rank 0 prints under "sharded_model" — at ONE GPU it is the
+    whole-model decomposition of configs[2], printed under "full_model": the second component of BASELINE.json's metric ("full-model ASVD
+    wall-clock"; the stage the reference itself times, binary_search.py:111-131).  dry: no kernels (gloo plumbing test): the sensitivities are
+    made up, everything else is the real code path.  samples: a list that receives, for the first layer of every distinct shape, what the
+    CPU-oracle parity check of the caller needs (weight, statistics, spectrum and emitted factors, all still on the device)."""
     import hashlib
     import zlib
     import torch
@@ -67,7 +112,7 @@ def sharded_model_leg(name, rank, world, dev, ratio=0.9, dry=False):
     ratios = [0.4, 0.5, 0.6, 0.7, 0.8, 0.9]
     load = [sum(c for c, o in zip(costs, owner) if o == r) for r in range(world)]
     mine = [(n, o, i) for (n, o, i), ow in zip(layers, owner) if ow == rank]
-    local, t_dec, sweeps, err = {}, 0.0, [], None
+    local, t_dec, sweeps, err, mods = {}, 0.0, [], None, {}
     if dry:
         for n, o, i in mine:
             local[n] = {r: 5.0 + (zlib.crc32(f"{n}:{r}".encode()) % 1000) / 1000.0 for r in ratios}
@@ -94,11 +139,17 @@ def sharded_model_leg(name, rank, world, dev, ratio=0.9, dry=False):
                 dist.barrier()
             t0 = time.perf_counter()
             SVDLinear.prefactorize(lins, act_aware=True, alpha=0.5, ranks=ranks, max_batch=32)
+            seen_shapes = set()
             for (n, o, i), l in zip(mine, lins):
                 mod = SVDLinear.from_linear(l, ratio, act_aware=True, alpha=0.5, sigma_fuse="UV")
                 assert isinstance(mod, SVDLinear) and l._asvd_svd_info.status == 0, n
                 sweeps.append(l._asvd_svd_info.sweeps)
                 S = l._asvd_factor_cache[1][1].float()
+                mods[n] = mod
+                if samples is not None and (o, i) not in seen_shapes:
+                    seen_shapes.add((o, i))
+                    samples.append({"name": n, "shape": [o, i], "rank": ranks[l], "W": l.weight.data, "stat": l.scaling_diag_matrix, "S": S.clone(),
+                                    "A": mod.ALinear.weight.data, "B": mod.BLinear.weight.data, "sweeps": l._asvd_svd_info.sweeps})
                 # a sensitivity made of the layer's own spectrum (the real sweep would put calibration perplexities here): what matters is that real
                 # per-layer numbers computed on the owning rank cross the collective
                 local[n] = {r: float(1.0 + S[min(SVDLinear.compute_rank(l, r), S.numel()) - 1] / S[0]) for r in ratios}
@@ -137,8 +188,32 @@ def sharded_model_leg(name, rank, world, dev, ratio=0.9, dry=False):
         cut = _bisect_cut(plans.size, lambda lo, mid, hi: (lambda ct: ct[0] / ct[1] > ratio)(_plan_params(plans.plan(mid), weights)))
         plan = plans.plan(cut)
         digest = int(hashlib.sha256(json.dumps(sorted(plan.items())).encode()).hexdigest()[:15], 16)
+    # ---- the only multi-GB transfer of the path: the owners' factors to rank 0 (parallel.exchange_factors, mode "rank0": every receive and every
+    # send posted at once, so all links into rank 0 are driven together) ----
+    t_gather, gathered, gather_bytes = 0.0, 0, 0
+    if world > 1 and not dry and not broken and not err:
+        try:
+            items, own_by_name = [], {}
+            for (n, o, i), ow in zip(layers, owner):
+                slot = _Slot()
+                if ow == rank:
+                    slot.m = mods[n]
+                items.append((n, slot, "m", _RawShape(o, i, dev, torch.float16)))
+                own_by_name[n] = ow
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            gathered = parallel.exchange_factors(items, own_by_name, mode="rank0")
+            torch.cuda.synchronize()
+            dist.barrier()
+            t_gather = time.perf_counter() - t0
+            if rank == 0:
+                gather_bytes = sum(2 * (it[1].m.ALinear.weight.numel() + it[1].m.BLinear.weight.numel()) for it in items if own_by_name[it[0]] != 0)
+        except Exception as e:   # noqa: BLE001 — reported, the bench line survives
+            err = f"factor gather: {type(e).__name__}: {e}"[:300]
+    mods.clear()
     comm_dev = dev if (world > 1 and dist.get_backend() == "nccl") else torch.device("cpu")
-    red = torch.tensor([float(digest), -float(digest), t_dec, t_ag, t_ag2, 1.0 if err else 0.0], dtype=torch.float64, device=comm_dev)
+    red = torch.tensor([float(digest), -float(digest), t_dec, t_ag, t_ag2, 1.0 if err else 0.0, t_gather, float(gather_bytes)], dtype=torch.float64, device=comm_dev)
     if world > 1:
         dist.all_reduce(red, op=dist.ReduceOp.MAX)
     red = red.cpu()
@@ -146,7 +221,7 @@ def sharded_model_leg(name, rank, world, dev, ratio=0.9, dry=False):
         return {"model": name, "error": err or "another rank's share failed (see its stderr)", "ranks_failed": bool(float(red[5]) > 0),
                 "collective_world_size": dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1}
     comp, total = _plan_params(plan, weights)
-    return {"model": name, "config": "BASELINE configs[3] shape: every Linear of the model, ratio %.2f, alpha 0.5, synthetic weights / statistics" % ratio,
+    return {"model": name, "config": "BASELINE %s: every Linear of the model, ratio %.2f, alpha 0.5, synthetic weights / statistics" % ("configs[3] (layers sharded over the ranks)" if world > 1 else "configs[2] (all Linears on one GPU)", ratio),
             "linears": len(layers), "collective_world_size": dist.get_world_size() if (world > 1 or (dist.is_available() and dist.is_initialized())) else 1,
             "collective_backend": (dist.get_backend() if (dist.is_available() and dist.is_initialized()) else "none (single process)") + (" = RCCL" if (dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl") else ""),
             "layers_per_rank": [sum(1 for o in owner if o == r) for r in range(world)],
@@ -155,7 +230,52 @@ def sharded_model_leg(name, rank, world, dev, ratio=0.9, dry=False):
             "allgather_first_call_ms": 1e3 * float(red[3]), "allgather_ms": 1e3 * float(red[4]),
             "allgather_payload_bytes_per_rank": 2 * 8 * max(1, max(sum(1 for o in owner if o == r) for r in range(world)) * len(ratios)),
             "plan_identical_on_all_ranks": bool(float(red[0]) == -float(red[1])), "plan_param_ratio": comp / total,
-            "layers_factorised_by_plan": sum(1 for v in plan.values() if v < 1), "sweeps_min_max_rank0": [min(sweeps), max(sweeps)] if sweeps else None}
+            "layers_factorised_by_plan": sum(1 for v in plan.values() if v < 1), "sweeps_min_max_rank0": [min(sweeps), max(sweeps)] if sweeps else None,
+            "decompose_s": float(red[2]), "decompose_stage": "scale + factorise + truncate / split of every Linear (what the reference times as `decompose time`, binary_search.py:111-131)",
+            "gather_factors_s": float(red[6]) if world > 1 else None, "gather_factors_bytes_into_rank0": int(red[7]) if world > 1 else None,
+            "gather_factors_GBps_into_rank0": (float(red[7]) / float(red[6]) / 1e9) if (world > 1 and float(red[6]) > 0) else None,
+            "predicted_sweep_balance_8_ranks": predicted_sweep_balance(8)}
+
+
+def full_model_parity(samples, model_name, dev, threads, decompose_s=None):
+    """Per-shape parity of the model leg against the CPU oracle, and the CPU reference the full-model wall-clock divides: the oracle pipeline
+    (scale + torch.linalg.svd + truncate / split) timed ONCE per distinct shape at `threads` host threads, times the number of Linears of that
+    shape ("per-shape x count": the whole model on the host would be ~13 minutes).  Checker code: the only place of this file besides the
+    cpu_baseline leg that touches oracle/ (bench.py's CPU leg and tests/test_gpu_full_model.py call it)."""
+    import torch
+    from oracle import asvd_oracle as O
+    torch.set_num_threads(threads)
+    counts = {}
+    for _, o_, i_ in model_linears(model_name):
+        counts[(o_, i_)] = counts.get((o_, i_), 0) + 1
+    per_shape, cpu_total = [], 0.0
+    for smp in samples:
+        o_, i_ = smp["shape"]
+        Wc, stc = smp["W"].cpu(), smp["stat"].cpu()
+        sc_ = O.make_scale(stc, 0.5)
+        t1 = time.perf_counter()
+        ws_ = O.scaled_weight(Wc, sc_)
+        Uo, So, Vo = O.exact_svd(ws_)
+        Ao, Bo, _ = O.truncate_split(Uo, So, Vo, sc_, smp["rank"], "UV", torch.float16)
+        t_shape = time.perf_counter() - t1
+        cpu_total += t_shape * counts[(o_, i_)]
+        # reconstruction parity in fp64 ON THE DEVICE (checker arithmetic: torch matmul; the factors under test came from the HIP path)
+        live = O.live_channels(sc_).to(dev)
+        sd = sc_.double().to(dev).flatten()
+        D = smp["A"].double() @ smp["B"].double() - Ao.to(dev).double() @ Bo.to(dev).double()
+        Wd = smp["W"].double()
+        rec_live = float((D[:, live].norm() / Wd.norm()).item())
+        rec_scaled = float(((D * sd).norm() / (Wd * sd).norm()).item())
+        del D, Wd
+        per_shape.append({"shape": [o_, i_], "layer": smp["name"], "count_in_model": counts[(o_, i_)], "rank": smp["rank"], "sweeps": smp["sweeps"],
+                          "sigma_rel_err_top_r": O.sigma_rel_err(smp["S"].cpu(), So, smp["rank"]), "recon_fro_err_vs_oracle": rec_live,
+                          "recon_fro_err_scaled_norm": rec_scaled, "cpu_oracle_seconds": t_shape})
+    return {"parity_per_shape": per_shape,
+            "parity_ok": all(p_["sigma_rel_err_top_r"] <= 1e-4 and p_["recon_fro_err_vs_oracle"] <= 1e-3 for p_ in per_shape),
+            "parity_tolerance": {"sigma": 1e-4, "recon": 1e-3, "note": "north_star's bars; the factors compared are the emitted fp16 ones on both sides"},
+            "cpu_reference": {"seconds_whole_model_per_shape_x_count": cpu_total, "threads": threads, "kind": "port",
+                              "method": "oracle scale + torch.linalg.svd + truncate/split timed once per distinct shape on this host, x the number of Linears of that shape"},
+            "speedup_vs_cpu_reference": (cpu_total / decompose_s) if decompose_s else None}
 
 
 def dry_run(args, rank, world):
@@ -202,8 +322,9 @@ def main():
     ap.add_argument("--no_latency", action="store_true", help="skip the batch-1 latency leg (profiling runs: keeps per-kernel averages to the batch workload)")
     ap.add_argument("--cpu_reps", type=int, default=3, help="repetitions of the CPU oracle pipeline at the best thread count (>= 3; median reported)")
     ap.add_argument("--cpu_budget_s", type=float, default=90.0, help="soft bound on the CPU-baseline leg (warm-up + thread sweep + repetitions)")
-    ap.add_argument("--sharded_model", default="auto", help="untimed extra: LPT-sharded decomposition of a model's Linears + the sensitivity all-gather on the "
-                    "process group (BASELINE configs[3]); auto = llama-2-7b when --gpus > 1, none at one GPU; or llama-2-7b / llama-2-13b / tiny / none")
+    ap.add_argument("--sharded_model", default="auto", help="untimed extra: decomposition of a whole model's Linears, LPT-sharded over the ranks, + the sensitivity "
+                    "all-gather and the factor gather on the process group (BASELINE configs[2] at one GPU -> \"full_model\", configs[3] at N -> \"sharded_model\"); "
+                    "auto = llama-2-7b; or llama-2-7b / llama-2-13b / tiny / none")
     ap.add_argument("--dry_run", action="store_true", help="launch plumbing only (CPU, gloo): spawn/bind ranks, barrier, max-reduce, JSON line; no kernels, value = null")
     args = ap.parse_args()
 
@@ -298,11 +419,12 @@ def main():
     assert all(i.status == 0 for i in infos), [i.status for i in infos]  # every SVD of the batch converged
 
     # ---- configs[3] in one line (untimed): LPT-sharded model decomposition + the real sensitivity all-gather on this process group ----
-    sharded = None
-    sm = args.sharded_model if args.sharded_model != "auto" else ("llama-2-7b" if world > 1 else "none")
+    sharded, fm_samples = None, ([] if world == 1 else None)
+    sm = args.sharded_model if args.sharded_model != "auto" else "llama-2-7b"
     if sm != "none":
         try:
-            sharded = sharded_model_leg(sm, rank, world, dev)
+            res = None   # drop the held outputs of the last timed step (3 GB)
+            sharded = sharded_model_leg(sm, rank, world, dev, samples=fm_samples)
         except Exception as e:   # noqa: BLE001 — the untimed extra must not cost the bench line
             sharded = {"model": sm, "error": f"{type(e).__name__}: {e}"[:300]}
             print(f"[bench] rank {rank}: sharded-model leg failed: {sharded['error']}", file=sys.stderr)
@@ -404,7 +526,7 @@ def main():
         if per_rank is not None:
             out["per_rank_svds_per_s"] = per_rank
         if sharded is not None:
-            out["sharded_model"] = sharded
+            out["sharded_model" if world > 1 else "full_model"] = sharded
         # ---- batch-1 latency (BASELINE configs[1] says "single ... Linear"): one matrix alone, same path, median of 3 ----
         if world == 1 and not args.no_latency:
             lat = []
@@ -498,6 +620,12 @@ def main():
             out["parity"] = {"sigma_rel_err_top_r": serr, "r": r9, "recon_fro_err_rank512_vs_oracle": rerr, "recon_fro_err_scaled_norm": rerr_scaled,
                              "truncation_err_over_W_device_k9": k9["recon_err_over_W_device"] if k9 else None, "truncation_err_over_W_oracle_fp64": oracle_err,
                              "tolerance": {"sigma": 1e-4, "recon": 1e-3}}
+            # ---- full model (BASELINE.json metric, second component): per-shape parity of the model leg against the CPU oracle, and the CPU
+            # reference it divides — the oracle pipeline timed ONCE per distinct shape at the best thread count found above, times the number
+            # of Linears of that shape ("per-shape x count": the whole model on the host would be ~13 minutes) ----
+            if sharded is not None and fm_samples and "error" not in sharded:
+                sharded.update(full_model_parity(fm_samples, sharded["model"], dev, best_t, sharded.get("decompose_s")))
+                torch.set_num_threads(default_threads)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -109,12 +109,15 @@ int asvd_scale_cols(const void* w, int w_dtype, int64_t m, int64_t n, int64_t ld
  * U = V = NULL, the values-only `torch.svd(w.float(), compute_uv=False)` at sensitivity.py:101.
  *
  * Algorithm: the oriented matrix (rows >= cols) is reduced to a square one by a Cholesky-QR in fp64 (Gram matrix
- * by fp64 MFMA, columns ordered by norm), then one-sided block Jacobi runs on R^T: XOR pair schedule over 32-column panels;
- * dense sweeps work on 64-column super-panels (per step ONE launch of wave-local 64x64 eigen-solves — one wave per solve, the
- * matrix in registers, both inner steps of a super-pair — and one 128-wide update pass in split-bf16 arithmetic fused with the
- * Gram tiles of the next step), tail sweeps rotate only the pairs a blocked X^T X snapshot marks.  Right
- * vectors are the rotated columns, left vectors X V by one GEMM, sigma_j = |X v_j| in fp64.  No vector is accumulated during
- * the sweeps.  Problems too small or rank-deficient for the reduction take the same sweeps on the matrix itself.
+ * by fp64 MFMA, columns ordered by norm), then one-sided block Jacobi runs on R^T: XOR pair schedule over 32-column panels
+ * (panel counts that are not a power of two: a grouped schedule — XOR inside groups of 2..16 super-panels, round-robin over
+ * the groups); dense sweeps work on 64-column super-panels, TWO launches per super-step: the wave-local 64x64 eigen-solves
+ * (one wave per solve, the matrix in registers, both inner steps of a super-pair) and one 128-wide update pass fused with the
+ * Gram tiles of the next step, in split-fp16 arithmetic (three products per fp32 product, power-of-two column scales from the
+ * carried column norms; a problem that turns NaN on that path is repeated with the separate fp32 Gram / split-bf16 update
+ * passes); tail sweeps rotate only the pairs a blocked X^T X snapshot marks.  Right vectors are the rotated columns, left
+ * vectors X V by one GEMM, sigma_j = |X v_j| in fp64.  No vector is accumulated during the sweeps.  Problems too small or
+ * rank-deficient for the reduction take the same sweeps on the matrix itself.
  *
  *   batch       number of same-shape problems solved concurrently (fills the 256 CUs)
  *   a_host      host array [batch] of device pointers to A_b  [m, n] row-major, leading dim lda
@@ -127,14 +130,20 @@ int asvd_scale_cols(const void* w, int w_dtype, int64_t m, int64_t n, int64_t ld
  *               the leading part is done (the discarded tail converges last and would cost 2-4 more sweeps)
  *   max_sweeps  <=0: default (30);  tol <=0: default (1e-6) on max |cos(a_i, a_j)|
  *   info_host   optional host int[4*batch]: {status, sweeps, rotated pairs in last sweep, float bits of the last sweep's max |cos|}
- * Host-synchronous: the call returns when S/U/V are complete.  Sync points: one after the reduction (Cholesky breakdown flag),
- * one per Jacobi sweep (convergence flags; a second one when a sparse sweep reads back its pair marks), one at the end.
- * Everything is enqueued on `stream` (no other stream is used unless ASVD_GROUPS / ASVD_EPI_STREAMS ask for it); concurrent
- * calls from different host threads on different streams and workspaces are safe: no shared mutable state — schedule tables
- * and modes travel by value in the kernel arguments, not in __constant__ memory; the profiling counters are per thread — and
- * no kernel uses scratch.  tests/test_gpu_concurrency.py holds the library to it (two threads x 8 x 4096^2 next to a stream of
- * foreign GEMMs: bit-identical results and sweep counts against serial runs).  Rounds 1-2 did NOT keep this promise: their LDS
- * eigen-solver raced under concurrent load; it is reachable only through ASVD_EVDW=0 now.
+ * Host-synchronous: the call returns when S/U/V are complete.  Sync points (csrc/svd_jacobi.hip): one after the reduction
+ * (Cholesky breakdown flag), one per Jacobi sweep (convergence flags: four ints per problem), one more per sparse sweep
+ * (the pair marks of the coupling snapshot go to the host, which packs them into rounds of disjoint pairs), one when a
+ * problem finishes early (its `done` flag goes to the device), one at the end — 13 for a 4096 x 4096 call, 0.3 % of its time.
+ * Everything is enqueued on `stream`, and only there: the library creates no stream of its own.  Concurrent calls from
+ * different host threads on different streams and workspaces are safe: no shared mutable state — schedule tables and modes
+ * travel by value in the kernel arguments, not in __constant__ memory; the profiling counters are per thread — and no kernel
+ * uses scratch.  tests/test_gpu_concurrency.py holds the library to it (two threads x 8 x 4096^2 next to a stream of foreign
+ * GEMMs, and calls with different pair schedules side by side: bit-identical results and sweep counts against serial runs).
+ * Environment (read on the host, all optional; none changes results beyond rounding): ASVD_DEBUG (trace on stderr),
+ * ASVD_DEBUG_HIST (pair-measure histogram per sweep), ASVD_ORDER=rr (round-robin instead of XOR pair order, single-level sweeps),
+ * ASVD_TWOLEVEL=0, ASVD_SUPGRAM=0 (separate Gram / update passes), ASVD_SPARSE=0, ASVD_NO_REDUCE (skip the Cholesky-QR),
+ * ASVD_EVDQ=0/1 (force the throughput / latency form of the eigen-solver), ASVD_EVDW_TRACE (stage stamps of the solver),
+ * ASVD_SPREAD_FROM=<sweep> (line-spread order of the XOR distances from that dense sweep on: a measurement knob).
  * Returns worst status over the batch.
  */
 int asvd_svd_worksize(int batch, int64_t m, int64_t n, int want_vectors, size_t* bytes);

@@ -84,3 +84,28 @@ def test_product_path_fails_loudly_without_gpu():
     from asvd4llm_amd.modules.svd_linear import SVDLinear
     with pytest.raises(_lib.AsvdHipError):
         SVDLinear.from_linear(lin, 0.5)
+
+
+def test_environment_names_in_header_exist_in_the_sources():
+    """The header is the contract a maintainer of the reference reads: every ASVD_* environment variable it mentions must be read somewhere
+    in csrc/ (getenv) or in the package (os.environ), and every knob csrc/ reads must be documented in the header or in DESIGN.md — a knob
+    that was deleted from the code may not survive in the prose."""
+    src = open(os.path.join(ROOT, "include", "asvd_hip.h")).read()
+    code = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    defined = set(re.findall(r"\b(ASVD_[A-Z0-9_]+)\b", code))            # macros / enumerators the header itself defines
+    mentioned = set(re.findall(r"\b(ASVD_[A-Z0-9_]+)\b", src)) - defined - {"ASVD_E_", "ASVD_N_"}
+    csrc = os.path.join(ROOT, "asvd4llm_amd", "csrc")
+    read_c = set()
+    for f in os.listdir(csrc):
+        read_c |= set(re.findall(r'getenv\("(ASVD_[A-Z0-9_]+)"\)', open(os.path.join(csrc, f)).read()))
+    read_py = set()
+    for d, _, files in os.walk(os.path.join(ROOT, "asvd4llm_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                read_py |= set(re.findall(r'environ[^\n]*?"(ASVD_[A-Z0-9_]+)"', open(os.path.join(d, f)).read()))
+    assert mentioned, "the header documents its environment knobs"
+    stale = sorted(mentioned - read_c - read_py)
+    assert not stale, f"asvd_hip.h mentions environment names nothing reads: {stale}"
+    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    undocumented = sorted(n for n in read_c if n not in src and n not in design)
+    assert not undocumented, f"csrc/ reads environment names neither asvd_hip.h nor DESIGN.md mention: {undocumented}"

@@ -173,3 +173,38 @@ def test_perplexity_quirk_matches_reference(golden):
     ids = torch.cat([torch.tensor(i) for i in t["calib_ids"]], 0)
     ppl = evaluate_perplexity(model, ids, 3)
     assert abs(ppl - t["ppl_raw"]) <= 1e-5 * t["ppl_raw"]
+
+
+def test_sweep_shard_is_balanced_on_the_sweep_cost_model():
+    """configs[3] / [4] are 99 % sweep: the LPT shard of calib_sensitivity_ppl must be balanced on the predicted sweep seconds per layer (suffix
+    forwards behind the layer + its factorisation), not on SVD flops.  Llama-2-7B / 13B shapes at 8 ranks: max / mean <= 1.05."""
+    import bench
+    table = bench.predicted_sweep_balance(8)
+    for name in ("llama-2-7b", "llama-2-13b"):
+        rec = table[name]
+        assert rec["sweep_s_max_over_mean"] <= 1.05, rec
+        assert rec["decompose_flops_max_over_mean"] <= 1.05, rec
+        assert rec["predicted_sweep_s_per_rank_max"] <= 1.05 * rec["predicted_sweep_s_one_gpu"] / 8
+    # the model reproduces the measured one-GPU sweep of round 4 (755 s of forwards + factorisations, profiles/r4_e2e_llama2_7b_ncalib32.json) to 5 %
+    assert abs(table["llama-2-7b"]["predicted_sweep_s_one_gpu"] - 755.0) / 755.0 < 0.05
+    # structure of the cost: lm_head replays nothing, a layer of block 0 replays the whole model, a layer of the last block one block
+    costs = bench.model_sweep_costs("llama-2-7b")
+    names = [n for n, _, _ in bench.model_linears("llama-2-7b")]
+    c = dict(zip(names, costs))
+    assert c["model.layers.0.self_attn.q_proj"] > 15 * c["model.layers.31.self_attn.q_proj"] > 0
+    assert c["lm_head"] < c["model.layers.31.mlp.down_proj"]
+
+
+def test_sweep_costs_for_model_reads_the_block_structure():
+    """the model-based wrapper (what calib_sensitivity_ppl calls) on the tiny Llama: deeper blocks are cheaper, the head is cheapest, every
+    rank computes the same owner map"""
+    from asvd4llm_amd.sensitivity import collect_linear_info
+    from tests.tiny_lm import ShapedLlama
+    model = ShapedLlama(hidden=64, inter=176, layers=3, vocab=320)
+    linears = list(collect_linear_info(model).items())
+    costs = parallel.sweep_costs_for_model(model, linears, 6, 4, 128)
+    by = {info["full_name"]: c for (_, info), c in zip(linears, costs)}
+    assert by["model.layers.0.mlp.up_proj"] > by["model.layers.1.mlp.up_proj"] > by["model.layers.2.mlp.up_proj"] > by["lm_head"] > 0
+    assert parallel.lpt_assign(costs, 2) == parallel.lpt_assign(list(costs), 2)
+    flat = parallel.sweep_costs_for_model(model, linears, 6, 4, 128, prefix_cached=False)
+    assert max(flat) / min(flat) < 1.5   # full forwards: every evaluation costs the same, only the factorisations differ
