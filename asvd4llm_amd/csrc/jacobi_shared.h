@@ -139,6 +139,10 @@ struct EvdV3 {
                           //              the power-of-two column scales of the split-fp16 update (twolevel.h, supgram_kernel) come from these
 };
 
+// CUs the current call may use (0 = the whole device, 256): set by asvd_svd_batched per host thread when it runs a batch as two halves on
+// CU-masked streams; the launch-form switches of the eigen-solver follow it
+extern thread_local int g_call_cus;
+
 // ---- launchers of the wave-local eigen-solver (evd_wave.hip) -------------------------------------------------------------------
 // single-level solves: the work of evd_kernel<0, KEEPG> (grid: npairs x batch), one wave per pair
 void launch_evdw0(bool keepg, int npairs, int batch, hipStream_t st, const Sched& sc, const float* Gpart, int nsplit, float* Qbuf, int* active,

@@ -24,7 +24,12 @@
 #include <cstdlib>
 #include <algorithm>
 #include <type_traits>
+#include <thread>
+#include <mutex>
 
+namespace asvdk {
+thread_local int g_call_cus = 0;   // see call_cus(): set per host thread for the duration of a half-batch call (0: the whole device)
+}
 namespace {
 using namespace asvdk;
 
@@ -54,8 +59,13 @@ struct Plan {
     size_t off_x, off_xorig, off_gpart, off_q, off_active, off_sig, off_ina, off_inv, off_perm, off_flags, off_pflag, off_plist, total;
 };
 
+// CUs the launches of the current call may use: 256 (the device), or the 128 of one half when asvd_svd_batched runs a batch as two halves on
+// CU-masked streams (below).  The launch geometry of a plan (row splits, chunk counts) is sized for this many.
+static int64_t call_cus() { return g_call_cus > 0 ? g_call_cus : 256; }
+
 int make_plan(int batch, int64_t m, int64_t n, int want_u, int want_vv, Plan& p) {
     if (batch < 1 || m < 1 || n < 1 || m > (1 << 24) || n > (1 << 24)) return ASVD_E_BADARG;
+    const int64_t cu = call_cus();
     p.batch = batch;
     p.m = m;
     p.n = n;
@@ -84,7 +94,7 @@ int make_plan(int batch, int64_t m, int64_t n, int want_u, int want_vv, Plan& p)
         double best_cost = 1e300;
         for (int64_t ns = 1; ns <= nchunk_total && ns <= 64; ++ns) {
             const int64_t wgs = ns * p.npairs * launch_batch;
-            const int64_t rounds = ceil_div64(wgs, 768);
+            const int64_t rounds = ceil_div64(wgs, 3 * cu);
             const int64_t chunks_wg = ceil_div64(nchunk_total, ns);
             const int64_t chunks_wave = ceil_div64(chunks_wg, 4);
             const double cost = (double)rounds * ((double)chunks_wave + 1.5) + 0.02 * ns;  // mild penalty: partials traffic
@@ -94,7 +104,7 @@ int make_plan(int batch, int64_t m, int64_t n, int want_u, int want_vv, Plan& p)
         p.nsplit = (int)ceil_div64(p.m_pad, p.rows_per_split);
     }
     // update: 128-row iterations; aim for >= 1024 workgroups but >= 2 iterations per workgroup when possible
-    int64_t wantc = ceil_div64(1024, (int64_t)p.npairs * batch);
+    int64_t wantc = ceil_div64(4 * cu, (int64_t)p.npairs * batch);
     int64_t iters_total = ceil_div64(p.R_upd, 128);
     int64_t nc = wantc < 1 ? 1 : (wantc > iters_total ? iters_total : wantc);
     p.rows_per_wg = (int)(ceil_div64(iters_total, nc) * 128);
@@ -114,7 +124,7 @@ int make_plan(int batch, int64_t m, int64_t n, int want_u, int want_vv, Plan& p)
         double best_cost = 1e300;
         for (int64_t ns = 1; ns <= nchunk_total && ns <= 64; ++ns) {
             const int64_t wgs = ns * p.npairs_s * launch_batch;
-            const int64_t rounds = ceil_div64(wgs, 768);
+            const int64_t rounds = ceil_div64(wgs, 3 * cu);
             const int64_t chunks_wave = ceil_div64(2 * ceil_div64(nchunk_total, ns), 4);
             const double cost = (double)rounds * ((double)chunks_wave + 1.5) + 0.02 * ns;
             if (cost < best_cost) { best_cost = cost; best_ns = ns; }
@@ -123,7 +133,7 @@ int make_plan(int batch, int64_t m, int64_t n, int want_u, int want_vv, Plan& p)
         p.nsplit_s = (int)ceil_div64(p.m_pad, p.rows_per_split_s);
         // supdate: 32-row tiles; aim for >= 1024 workgroups per launch and >= 4 tiles per workgroup
         const int64_t tiles = ceil_div64(p.R_upd, 32);
-        int64_t wantc = ceil_div64(1024, (int64_t)p.npairs_s * launch_batch);
+        int64_t wantc = ceil_div64(4 * cu, (int64_t)p.npairs_s * launch_batch);
         int64_t nc = std::max<int64_t>(1, std::min<int64_t>(wantc, ceil_div64(tiles, 4)));
         p.rows_per_wg_s = (int)(ceil_div64(tiles, nc) * 32);
         p.nchunks_s = (int)ceil_div64(p.R_upd, p.rows_per_wg_s);
@@ -134,16 +144,16 @@ int make_plan(int batch, int64_t m, int64_t n, int want_u, int want_vv, Plan& p)
         // (and 1 chunk = exactly one workgroup per CU beats 2 once the quads alone fill the chip: 170.7 vs 174.0 ms per step, solves 97 vs 100)
         // small batches: one round of 256 workgroups too (batch 4: 43.7 ms of supgram per step with 4 chunks, 47.3 with 8, 52.8 with 16);
         // the solves sum the partial tiles with independent loads, so their cost no longer grows with the chunk count
-        int64_t nq = std::max<int64_t>(1, std::min<int64_t>(ceil_div64(256, quads), std::max<int64_t>(1, tiles / 8)));
+        int64_t nq = std::max<int64_t>(1, std::min<int64_t>(ceil_div64(cu, quads), std::max<int64_t>(1, tiles / 8)));
         {
             // counts that are not a power of two (13B: 80 super-panels = 20 real quads per problem in a 32-quad grid): one workgroup per CU means
             // the launch runs in whole rounds of 256 workgroups, and 320 real workgroups cost two rounds (measured 1179 us per launch at
             // 16 x 5120^2; four row chunks = exactly five rounds of a quarter length: 737 us).  Pick the chunk count that wastes the least.
             const int64_t real = ceil_div64(p.ns, 4) * batch;
-            if (real != quads && real >= 256) {
+            if (real != quads && real >= cu) {
                 double best = 1e300;
                 for (int64_t c = 1; c <= 8 && c <= std::max<int64_t>(1, tiles / 8); c *= 2) {
-                    const double cost = (double)ceil_div64(real * c, 256) / (double)c * (1.0 + 0.03 * (double)c);
+                    const double cost = (double)ceil_div64(real * c, cu) / (double)c * (1.0 + 0.03 * (double)c);
                     if (cost < best) { best = cost; nq = c; }
                 }
             }
@@ -316,8 +326,8 @@ int asvd_svd_get_profile(float* ms_host, int* launches_host) {
 static bool tall_wanted(const Plan& p);
 static size_t tall_worksize(int batch, int64_t m, int64_t n, int want_vectors, int64_t k);
 
-int asvd_svd_worksize(int batch, int64_t m, int64_t n, int want_vectors, size_t* bytes) {
-    if (!bytes) return ASVD_E_BADARG;
+// workspace of ONE call of `batch` problems whose launches are sized for the CUs of the current thread (call_cus())
+static int worksize_one(int batch, int64_t m, int64_t n, int want_vectors, size_t* bytes) {
     Plan p;
     int rc = make_plan(batch, m, n, want_vectors, want_vectors, p);
     if (rc) return rc;
@@ -325,6 +335,68 @@ int asvd_svd_worksize(int batch, int64_t m, int64_t n, int want_vectors, size_t*
     if (tall_wanted(p)) {
         const size_t t = tall_worksize(batch, m, n, want_vectors, p.cols);
         if (t > need) need = t;
+    }
+    *bytes = need;
+    return ASVD_OK;
+}
+
+// ---- a batch as two halves on disjoint halves of the chip --------------------------------------------------------------------------------
+// The two launches that alternate through a dense sweep use complementary resources — the eigen-solves the VALUs (no HBM), the fused update +
+// Gram kernel the HBM path (VALUs nearly idle) — but they cannot share a CU (2 x 216 + 215 VGPRs per SIMD against the 512 of the register
+// file), and two half-batches that share the WHOLE chip fall into lock-step (each kernel fills every CU as soon as it is free): 608 vs 628 ms.
+// What does overlap them is SPACE: every half gets its own 128 CUs (hipExtStreamCreateWithCUMask) and its own host thread, the halves
+// drift apart, and while one is in a compute-bound phase (eigen-solves, fp64 Cholesky-QR, snapshots, the long-side GEMM) the other's
+// HBM-bound launches have the memory system to themselves — the fused kernel reaches 72 % of its full-chip throughput on half of the CUs
+// (it saturates the HBM path at ~190 CUs: profiles/r5_cu_mask_scaling.jsonl).  Measured, 32 x 4096^2: 628 -> 595 ms (-5.3 %); 11008 x 4096
+// and 4096 x 11008 x 32: -5 %; 2048-column problems: nothing (profiles/r5_ab_two_streams.jsonl).  So: batches of >= 16 problems with
+// >= 3072 columns are split unless ASVD_SPLIT=0; a profiled call (asvd_svd_set_profiling) runs unsplit, so that the per-class
+// durations describe each kernel alone on the chip.  The halves are ordinary calls with disjoint workspaces and outputs (the
+// concurrency contract of the library), sized for 128 CUs; results are those of two half-batch calls.
+struct SplitStreams { hipStream_t s[2] = {nullptr, nullptr}; int cus = 0; bool tried = false, ok = false; };
+static SplitStreams g_split_streams[64];
+static std::mutex g_split_mutex;
+
+static SplitStreams* split_streams() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lk(g_split_mutex);
+    SplitStreams& ss = g_split_streams[dev];
+    if (!ss.tried) {
+        ss.tried = true;
+        int ncu = 0;
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 64 || (ncu & 1)) return nullptr;
+        const int words = (ncu + 31) / 32;
+        bool ok = true;
+        for (int h = 0; h < 2 && ok; ++h) {
+            std::vector<uint32_t> mask((size_t)words, 0u);
+            for (int c = h * (ncu / 2); c < (h + 1) * (ncu / 2); ++c) mask[c >> 5] |= 1u << (c & 31);
+            ok = hipExtStreamCreateWithCUMask(&ss.s[h], (uint32_t)words, mask.data()) == hipSuccess;
+        }
+        ss.ok = ok;
+        ss.cus = ncu / 2;
+    }
+    return ss.ok ? &ss : nullptr;
+}
+
+static bool split_applies(int batch, int64_t m, int64_t n) {
+    const char* e = getenv("ASVD_SPLIT");   // read per call: tests and A/B runs toggle it inside one process
+    return !(e && atoi(e) == 0) && batch >= 16 && std::min(m, n) >= 3072;
+}
+
+int asvd_svd_worksize(int batch, int64_t m, int64_t n, int want_vectors, size_t* bytes) {
+    if (!bytes) return ASVD_E_BADARG;
+    size_t need = 0;
+    int rc = worksize_one(batch, m, n, want_vectors, &need);
+    if (rc) return rc;
+    if (split_applies(batch, m, n)) {   // room for the two halves, each planned for half of the CUs
+        const int saved = g_call_cus;
+        g_call_cus = 128;
+        size_t h0 = 0, h1 = 0;
+        rc = worksize_one((batch + 1) / 2, m, n, want_vectors, &h0);
+        if (!rc) rc = worksize_one(batch / 2, m, n, want_vectors, &h1);
+        g_call_cus = saved;
+        if (rc) return rc;
+        need = std::max(need, ((h0 + 255) & ~(size_t)255) + h1);
     }
     *bytes = need;
     return ASVD_OK;
@@ -535,13 +607,13 @@ static int svd_direct_run(int batch, const void* const* a_host, int a_dtype, int
                 const int* pl = plist_dev + sl_off[step];
                 // few pairs per launch: split the rows further to fill the CUs, within the partial-Gram capacity of a problem
                 const int64_t chunks = p.m_pad / 32, cap = (int64_t)p.npairs * p.nsplit / slots;
-                int64_t ns = std::max<int64_t>(p.nsplit, ceil_div64(768, (int64_t)slots * batch));
+                int64_t ns = std::max<int64_t>(p.nsplit, ceil_div64(3 * call_cus(), (int64_t)slots * batch));
                 ns = std::min<int64_t>(std::min<int64_t>(ns, cap), std::min<int64_t>(chunks, 64));
                 if (ns < 1) ns = 1;
                 const int rps = (int)(ceil_div64(chunks, ns) * 32);
                 const int nsp = (int)ceil_div64(p.m_pad, rps);
                 const int64_t iters = ceil_div64(p.R_upd, 128);
-                int64_t nc = std::min<int64_t>(iters, std::max<int64_t>(1, ceil_div64(1024, (int64_t)slots * batch)));
+                int64_t nc = std::min<int64_t>(iters, std::max<int64_t>(1, ceil_div64(4 * call_cus(), (int64_t)slots * batch)));
                 const int rpw = (int)(ceil_div64(iters, nc) * 128);
                 const int nch = (int)ceil_div64(p.R_upd, rpw);
                 {
@@ -1038,18 +1110,13 @@ int asvd_test_evd_wave(const float* G, int batch, int sweeps, float* Q, float* d
     return ASVD_OK;
 }
 
-int asvd_svd_batched(int batch, const void* const* a_host, int a_dtype, int64_t m, int64_t n, int64_t lda,
-                     const void* const* cs_host, int cs_dtype, float* const* U_host, float* const* S_host,
-                     float* const* V_host, int64_t k, int max_sweeps, float tol, void* work, size_t work_bytes,
-                     int* info_host, void* stream) {
-    if (!a_host || !S_host || !work || !dtype_ok(a_dtype) || lda < n) return ASVD_E_BADARG;
-    if (cs_host && !dtype_ok(cs_dtype)) return ASVD_E_BADARG;
+static int svd_batched_one(int batch, const void* const* a_host, int a_dtype, int64_t m, int64_t n, int64_t lda,
+                           const void* const* cs_host, int cs_dtype, float* const* U_host, float* const* S_host,
+                           float* const* V_host, int64_t k, int max_sweeps, float tol, void* work, size_t work_bytes,
+                           int* info_host, void* stream) {
     Plan p;
     int rc = make_plan(batch, m, n, 0, 0, p);
     if (rc) return rc;
-    if (k < 1 || k > p.cols) return ASVD_E_BADARG;
-    for (int b = 0; b < batch; ++b)
-        if (!a_host[b] || !S_host[b]) return ASVD_E_BADARG;
     if (g_prof_enabled) prof_begin();
     rc = -100;
     if (tall_wanted(p))
@@ -1060,6 +1127,66 @@ int asvd_svd_batched(int batch, const void* const* a_host, int a_dtype, int64_t 
                         info_host, stream, false);
     if (g_prof_enabled) prof_end();
     return rc;
+}
+
+int asvd_svd_batched(int batch, const void* const* a_host, int a_dtype, int64_t m, int64_t n, int64_t lda,
+                     const void* const* cs_host, int cs_dtype, float* const* U_host, float* const* S_host,
+                     float* const* V_host, int64_t k, int max_sweeps, float tol, void* work, size_t work_bytes,
+                     int* info_host, void* stream) {
+    if (!a_host || !S_host || !work || !dtype_ok(a_dtype) || lda < n) return ASVD_E_BADARG;
+    if (cs_host && !dtype_ok(cs_dtype)) return ASVD_E_BADARG;
+    if (batch < 1 || m < 1 || n < 1) return ASVD_E_BADARG;
+    if (k < 1 || k > std::min(m, n)) return ASVD_E_BADARG;
+    for (int b = 0; b < batch; ++b)
+        if (!a_host[b] || !S_host[b]) return ASVD_E_BADARG;
+    // two halves on disjoint halves of the chip (see split_streams above)
+    if (split_applies(batch, m, n) && !g_prof_enabled && g_call_cus == 0) {
+        SplitStreams* ss = split_streams();
+        const int want_vectors = (U_host || V_host) ? 1 : 0;
+        const int nb0 = (batch + 1) / 2, nb1 = batch / 2;
+        size_t h0 = 0, h1 = 0;
+        int rcw = ASVD_OK;
+        if (ss) {
+            g_call_cus = ss->cus;
+            rcw = worksize_one(nb0, m, n, want_vectors, &h0);
+            if (!rcw) rcw = worksize_one(nb1, m, n, want_vectors, &h1);
+            g_call_cus = 0;
+        }
+        const size_t off1 = (h0 + 255) & ~(size_t)255;
+        if (ss && !rcw && work_bytes >= off1 + h1) {
+            int dev = 0;
+            ASVD_HIP_CHECK(hipGetDevice(&dev));
+            // everything the caller queued on its stream (weights, scale vectors) is visible to both halves
+            hipEvent_t ev;
+            ASVD_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            ASVD_HIP_CHECK(hipEventRecord(ev, (hipStream_t)stream));
+            ASVD_HIP_CHECK(hipStreamWaitEvent(ss->s[0], ev, 0));
+            ASVD_HIP_CHECK(hipStreamWaitEvent(ss->s[1], ev, 0));
+            const int cus = ss->cus;
+            int rc1 = ASVD_OK;
+            std::thread t1([&]() {
+                if (hipSetDevice(dev) != hipSuccess) { rc1 = ASVD_E_HIP; return; }
+                g_call_cus = cus;
+                rc1 = svd_batched_one(nb1, a_host + nb0, a_dtype, m, n, lda, cs_host ? cs_host + nb0 : nullptr, cs_dtype, U_host ? U_host + nb0 : nullptr,
+                                      S_host + nb0, V_host ? V_host + nb0 : nullptr, k, max_sweeps, tol, (char*)work + off1, h1,
+                                      info_host ? info_host + 4 * nb0 : nullptr, (void*)ss->s[1]);
+                g_call_cus = 0;
+            });
+            g_call_cus = cus;
+            const int rc0 = svd_batched_one(nb0, a_host, a_dtype, m, n, lda, cs_host, cs_dtype, U_host, S_host, V_host, k, max_sweeps, tol, work, h0,
+                                            info_host, (void*)ss->s[0]);
+            g_call_cus = 0;
+            t1.join();
+            (void)hipStreamSynchronize(ss->s[0]);
+            (void)hipStreamSynchronize(ss->s[1]);
+            (void)hipEventDestroy(ev);
+            if (rc0 < 0) return rc0;
+            if (rc1 < 0) return rc1;
+            return std::max(rc0, rc1);
+        }
+    }
+    return svd_batched_one(batch, a_host, a_dtype, m, n, lda, cs_host, cs_dtype, U_host, S_host, V_host, k, max_sweeps, tol, work, work_bytes, info_host,
+                           stream);
 }
 
 int asvd_svd(const void* a, int a_dtype, int64_t m, int64_t n, int64_t lda, const void* col_scale, int cs_dtype, float* U,

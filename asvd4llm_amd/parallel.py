@@ -236,13 +236,19 @@ def _wire_shapes(kind, r, has_bias, out_f, in_f):
 
 
 def _p2p_all(ops):
-    """post every send / receive of `ops` at once ((fn, tensor, peer, tag) tuples), then wait for all of them: the transfers of different
-    peers run side by side (RCCL: one group call, every xGMI link of the receiver busy; gloo: one pending request per message)"""
-    if not ops:
-        return
-    reqs = dist.batch_isend_irecv([dist.P2POp(fn, t, peer, tag=tag) for fn, t, peer, tag in ops])
-    for q in reqs:
-        q.wait()
+    """ops: (fn, tensor, peer, tag) tuples in posting order.  Posted in ROUNDS that hold at most one message per peer — the c-th message of
+    every peer goes into round c — and every round is one batch_isend_irecv (RCCL: one group call): the messages of different peers travel
+    side by side (rank 0 drives all its xGMI links at once), the messages of one peer keep their order, and no group holds more than one
+    operation per peer (older RCCL / NCCL releases refuse several sends to the same peer inside one group).  A round ends when all its
+    transfers have; both ends of a pair post their c-th message in their c-th round, so the rounds need no global agreement."""
+    queues = {}
+    for op in ops:
+        queues.setdefault(op[2], []).append(op)
+    depth = max((len(q) for q in queues.values()), default=0)
+    for c in range(depth):
+        batch = [dist.P2POp(q[c][0], q[c][1], q[c][2], tag=q[c][3]) for q in queues.values() if c < len(q)]
+        for req in dist.batch_isend_irecv(batch):
+            req.wait()
 
 
 def exchange_factors(items, owner, mode="rank0"):
@@ -253,10 +259,10 @@ def exchange_factors(items, owner, mode="rank0"):
     still holds the raw nn.Linear there.
       mode "all"   : the owner broadcasts its factors, every rank ends with the complete compressed model;
       mode "rank0" : the owners send them to rank 0 only, point to point (each transfer crosses one xGMI link, nothing is relayed around a
-                     ring) and ALL AT ONCE: rank 0 posts every receive, every owner posts every send, then everybody waits — the seven
-                     links into rank 0 carry their shards concurrently (SURVEY 5 sizes the ~12 GB of Llama-2-7B at 10-12 ms per link-load
-                     only if all links are driven; a layer-by-layer blocking send / recv used one link at a time).  Two rounds: the
-                     headers (rank 0 cannot know whether an owner fell back to a plain Linear), then the payloads;
+                     ring), ALL OWNERS AT ONCE: in every round rank 0 posts one receive per owner and every owner one send (_p2p_all), so
+                     the seven links into rank 0 carry their shards concurrently (SURVEY 5 sizes the ~12 GB of Llama-2-7B for all links
+                     driven together; a layer-by-layer blocking send / recv used one link at a time).  Two phases: the headers (rank 0
+                     cannot know whether an owner fell back to a plain Linear), then the payloads;
       mode "none"  : nothing moves.
     Wire format per layer: see _wire_of.  Returns the number of layers this rank received."""
     if mode == "none" or not (dist.is_available() and dist.is_initialized()):

@@ -309,3 +309,69 @@ def test_cache_files_are_written_once_and_read_complete_world2(tmp_path, shard):
     for n in out0[0][1]:   # computed (first pass) vs loaded from the cache (second pass)
         assert (out0[0][1][n] == out0[1][1][n]).all()
         assert abs(out0[0][1][n]).sum() > 0
+
+
+def _gather_worker(rank, ws, port, q):
+    """exchange_factors(mode "rank0") with several owners: every owner holds SVDLinear-shaped factors (and one a plain-Linear fallback with a
+    bias) of its layers; rank 0 must end with every layer, bit for bit, whatever the number of messages per peer"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    try:
+        import torch.nn as nn
+        from asvd4llm_amd.modules.svd_linear import SVDLinear
+
+        class Slot:
+            pass
+
+        shapes = [(48, 32), (32, 32), (64, 32), (32, 64), (32, 32), (40, 24), (24, 40), (32, 32), (16, 16), (48, 32), (32, 48)]
+        owner = {f"l{i}": (i * 3 + 1) % ws for i in range(len(shapes))}   # uneven: some peers hold more layers than others
+        items, want = [], {}
+        for i, (o, n) in enumerate(shapes):
+            g = torch.Generator().manual_seed(1000 + i)
+            r = 4 + i
+            A, B = torch.randn(o, r, generator=g), torch.randn(r, n, generator=g)
+            bias = torch.randn(o, generator=g) if i % 4 == 0 else None
+            raw = nn.Linear(n, o, bias=bias is not None)
+            slot = Slot()
+            if i == 5:   # the reference's fallback after a failed factorisation: a plain Linear travels as kind 0
+                mod = nn.Linear(n, o, bias=False)
+                mod.weight.data = torch.randn(o, n, generator=g)
+                want[f"l{i}"] = ("lin", mod.weight.data.clone(), None, None)
+            else:
+                mod = SVDLinear._from_factors(A.clone(), B.clone(), None if bias is None else bias.clone(), r)
+                want[f"l{i}"] = ("svd", A, B, bias)
+            slot.m = mod if owner[f"l{i}"] == rank else raw
+            items.append((f"l{i}", slot, "m", raw))
+        got = parallel.exchange_factors(items, owner, mode="rank0")
+        ok = True
+        if rank == 0:
+            for name, slot, _, _ in items:
+                kind, a, b, bias = want[name]
+                m = slot.m
+                if kind == "svd":
+                    ok = ok and isinstance(m, SVDLinear) and torch.equal(m.ALinear.weight.data, a) and torch.equal(m.BLinear.weight.data, b)
+                    ok = ok and ((bias is None and m.ALinear.bias is None) or torch.equal(m.ALinear.bias.data, bias))
+                else:
+                    ok = ok and type(m) is nn.Linear and torch.equal(m.weight.data, a)
+        q.put((rank, got, ok, sum(1 for v in owner.values() if v != 0)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(240)
+def test_factor_gather_from_several_owners_world4():
+    ws = 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, ws, port, q)) for r in range(ws)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(ws))
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    rank0 = res[0]
+    assert rank0[1] == rank0[3] and rank0[2], rank0        # rank 0 received every layer it does not own, bit for bit
+    assert all(r[1] == 0 for r in res[1:])

@@ -117,3 +117,38 @@ def test_mixed_schedules_concurrently(gpu):
     for i in range(len(jobs)):
         for k, r in enumerate(res[i]):
             assert _same(r, ref[i]), f"job {i} round {k} differs from its serial run"
+
+
+@pytest.mark.timeout(900)
+def test_split_batch_on_two_chip_halves_matches_the_unsplit_call(gpu, monkeypatch):
+    """asvd_svd_batched runs a batch of >= 16 problems with >= 3072 columns as two halves, each on its own host thread and on a stream masked
+    to one half of the CUs (csrc/svd_jacobi.hip, split_streams).  Same singular values and vectors as the unsplit call up to fp32 rounding
+    (the halves are planned for 128 CUs: other row splits, other summation orders), every problem converged, run-to-run deterministic,
+    the info block of every problem filled, and ASVD_SPLIT=0 restores the one-stream call."""
+    from asvd4llm_amd import ops
+    n = 3072
+    mats = _problems(gpu, 16, n, n, seed=77)
+    monkeypatch.setenv("ASVD_SPLIT", "0")
+    U0, S0, V0, i0 = ops.svd_batched(mats, k=1024)
+    monkeypatch.setenv("ASVD_SPLIT", "1")
+    U1, S1, V1, i1 = ops.svd_batched(mats, k=1024)
+    U2, S2, V2, i2 = ops.svd_batched(mats, k=1024)
+    assert all(i.status == 0 and 0 < i.sweeps <= 12 for i in i0 + i1)
+    for b in range(16):
+        assert torch.equal(S1[b], S2[b]) and torch.equal(U1[b], U2[b]) and torch.equal(V1[b], V2[b])     # deterministic
+        rel = ((S1[b].double() - S0[b].double()).abs() / S0[b].double()).max().item()
+        assert rel <= 2e-5, (b, rel)
+        # same leading subspace (the 15 outlier columns of _problems stand clear of the bulk): all principal cosines are 1
+        nout = max(1, n // 200)
+        c = torch.linalg.svdvals((U0[b][:, :nout].double().T @ U1[b][:, :nout].double()).cpu())
+        assert (1 - c.min().item()) <= 1e-8, (b, c.min().item())
+        idx = torch.arange(0, 64, device=gpu)
+        eye = torch.eye(64, dtype=torch.float64, device=gpu)
+        assert (V1[b][:, idx].double().T @ V1[b][:, idx].double() - eye).abs().max().item() <= 1e-5
+    # a profiled call runs unsplit (per-class durations describe each kernel alone on the chip) and still gives the unsplit bits
+    ops.svd_profile(True)
+    U3, S3, V3, i3 = ops.svd_batched(mats, k=1024)
+    prof = ops.svd_profile()
+    ops.svd_profile(False)
+    assert prof["supgram"]["launches"] > 0
+    assert all(torch.equal(a, b) for a, b in zip(S3, S0))

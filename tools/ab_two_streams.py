@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--masks", default="")
     ap.add_argument("--mask_mode", default="first", help="first: the first N bits; stride: bits spread evenly over the 256")
     ap.add_argument("--warm_s", type=float, default=4.0)
+    ap.add_argument("--mask_overlap", type=int, default=0)
     ap.add_argument("--group_masks", action="store_true", help="give every group its own 1/G of the CUs (masked streams) instead of sharing the chip")
     args = ap.parse_args()
     _lib.load(True)
@@ -109,13 +110,14 @@ def main():
         # hipMalloc for its 3 GB of outputs + workspace inside the timed region
         if args.group_masks:
             per_cu = ncu // G
-            streams = [masked_stream(dev, [1 if (i * per_cu <= c < (i + 1) * per_cu) else 0 for c in range(ncu)]) for i in range(G)]
+            ov = args.mask_overlap   # every group additionally gets `ov` CUs of its neighbours (shared between two groups)
+            streams = [masked_stream(dev, [1 if (i * per_cu - ov <= c < (i + 1) * per_cu + ov) else 0 for c in range(ncu)]) for i in range(G)]
         else:
             streams = [torch.cuda.Stream(device=dev) for _ in range(G)]
         dt, res = run_groups(mats, G, 2, streams)           # allocator warm-up for this split
         dt, res = run_groups(mats, G, args.reps, streams)
         same = all(torch.equal(a, b) for i in range(G) for a, b in zip(res[i][1], ref[1][i * (args.batch // G):(i + 1) * (args.batch // G)]))
-        print(json.dumps({"exp": "groups", "cu_masked_partition": bool(args.group_masks), "m": args.m, "n": args.n, "batch": args.batch, "groups": G, "ms_per_batch": 1e3 * dt,
+        print(json.dumps({"exp": "groups", "cu_masked_partition": bool(args.group_masks), "mask_overlap": args.mask_overlap, "m": args.m, "n": args.n, "batch": args.batch, "groups": G, "ms_per_batch": 1e3 * dt,
                           "svd_per_s": args.batch / dt, "sigma_bit_identical_to_one_call": bool(same),
                           "sweeps": sorted(set(i.sweeps for r in res for i in r[3]))}), flush=True)
     for N in [int(x) for x in args.masks.split(",") if x]:
