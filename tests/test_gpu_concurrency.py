@@ -141,7 +141,7 @@ def test_split_batch_on_two_chip_halves_matches_the_unsplit_call(gpu, monkeypatc
         # same leading subspace (the 15 outlier columns of _problems stand clear of the bulk): all principal cosines are 1
         nout = max(1, n // 200)
         c = torch.linalg.svdvals((U0[b][:, :nout].double().T @ U1[b][:, :nout].double()).cpu())
-        assert (1 - c.min().item()) <= 1e-8, (b, c.min().item())
+        assert abs(1 - c.min().item()) <= 1e-5 and abs(1 - c.max().item()) <= 1e-5, (b, c.min().item(), c.max().item())   # fp32 vectors: orthonormal to ~1e-6
         idx = torch.arange(0, 64, device=gpu)
         eye = torch.eye(64, dtype=torch.float64, device=gpu)
         assert (V1[b][:, idx].double().T @ V1[b][:, idx].double() - eye).abs().max().item() <= 1e-5
