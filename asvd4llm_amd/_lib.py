@@ -53,6 +53,7 @@ SIGNATURES = {
     "asvd_test_super_schedule": (_i, [_i, _i, _vp, _i, _c.POINTER(_i), _c.POINTER(_i)]),
     "asvd_test_evd_wave": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "asvd_svd_set_profiling": (None, [_i]),
+    "asvd_svd_set_call_cus": (None, [_i]),
     "asvd_svd_get_profile": (_i, [_c.POINTER(_f), _c.POINTER(_i)]),
     "asvd_svd_get_pair_counts": (_i, [_c.POINTER(_c.c_longlong)]),
     "asvd_svd_get_sweep_times": (_i, [_c.POINTER(_f), _c.POINTER(_c.c_longlong), _i]),

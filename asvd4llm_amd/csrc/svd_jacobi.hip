@@ -299,6 +299,9 @@ int launch_pack(const void* src, int64_t ld, const void* s, int cs_dtype, const 
 extern "C" {
 
 void asvd_svd_set_profiling(int enabled) { g_prof_enabled = enabled != 0; }
+// CUs the calls of THIS host thread may use (0 = the whole device): a caller that runs asvd_svd_batched on a CU-masked stream of its own says so
+// here, so that the launch geometry (row splits, chunk counts, launch forms) is sized for those CUs; such calls are never split again.
+void asvd_svd_set_call_cus(int cus) { g_call_cus = cus > 0 ? cus : 0; }
 int asvd_svd_get_sweep_times(float* ms_host, long long* rotated_host, int cap) {
     const int n = (int)g_prof_sweep_ms.size();
     for (int i = 0; i < n && i < cap; ++i) {
@@ -348,7 +351,7 @@ static int worksize_one(int batch, int64_t m, int64_t n, int want_vectors, size_
 // drift apart, and while one is in a compute-bound phase (eigen-solves, fp64 Cholesky-QR, snapshots, the long-side GEMM) the other's
 // HBM-bound launches have the memory system to themselves — the fused kernel reaches 72 % of its full-chip throughput on half of the CUs
 // (it saturates the HBM path at ~190 CUs: profiles/r5_cu_mask_scaling.jsonl).  Measured, 32 x 4096^2: 628 -> 595 ms (-5.3 %); 11008 x 4096
-// and 4096 x 11008 x 32: -5 %; 2048-column problems: nothing (profiles/r5_ab_two_streams.jsonl).  So: batches of >= 16 problems with
+// and 4096 x 11008 x 32: -5 %; 2048-column problems: nothing (profiles/r5_ab_two_streams.jsonl).  So: batches of >= 4 problems with
 // >= 3072 columns are split unless ASVD_SPLIT=0; a profiled call (asvd_svd_set_profiling) runs unsplit, so that the per-class
 // durations describe each kernel alone on the chip.  The halves are ordinary calls with disjoint workspaces and outputs (the
 // concurrency contract of the library), sized for 128 CUs; results are those of two half-batch calls.
@@ -380,7 +383,7 @@ static SplitStreams* split_streams() {
 
 static bool split_applies(int batch, int64_t m, int64_t n) {
     const char* e = getenv("ASVD_SPLIT");   // read per call: tests and A/B runs toggle it inside one process
-    return !(e && atoi(e) == 0) && batch >= 16 && std::min(m, n) >= 3072;
+    return !(e && atoi(e) == 0) && batch >= 4 && std::min(m, n) >= 3072;   // measured: 4 x 4096^2 -3 %, 8: -8 %, 12: -6 %, 16: -9 %, 32: -6 %; 2048 columns: nothing
 }
 
 int asvd_svd_worksize(int batch, int64_t m, int64_t n, int want_vectors, size_t* bytes) {
@@ -508,6 +511,11 @@ static int svd_direct_run(int batch, const void* const* a_host, int a_dtype, int
     bool fused_used = false;
     int* hist_dev = nullptr;
     if (getenv("ASVD_DEBUG_HIST")) { ASVD_HIP_CHECK(hipMalloc(&hist_dev, 10 * sizeof(int))); }
+    // every exit of this function — the ASVD_HIP_CHECK returns included — frees the debug histogram and closes the profile it opened
+    struct ExitGuard {
+        int*& hist; bool prof;
+        ~ExitGuard() { if (hist) { (void)hipFree(hist); hist = nullptr; } if (prof) prof_end(); }
+    } exit_guard{hist_dev, g_prof_enabled && manage_profile};
     // buffers of the two-level sweeps as the kernels see them
     EvdV3 v3{};
     v3.ns = p.ns;
@@ -784,13 +792,11 @@ static int svd_direct_run(int batch, const void* const* a_host, int a_dtype, int
         }
     }
 
-    if (hist_dev) (void)hipFree(hist_dev);
     if (fused_used && retry_plain) {
         for (int b = 0; b < batch; ++b)
             if (status[b] == ASVD_N_NAN) {
                 if (debug) fprintf(stderr, "[asvd_svd] problem %d turned NaN on the split-fp16 path: repeating the call with the separate passes\n", b);
                 *retry_plain = true;
-                if (g_prof_enabled && manage_profile) prof_end();
                 return ASVD_OK;
             }
     }
@@ -823,7 +829,6 @@ static int svd_direct_run(int batch, const void* const* a_host, int a_dtype, int
     }
     ASVD_HIP_CHECK(hipStreamSynchronize(st));
     ASVD_HIP_CHECK(hipGetLastError());
-    if (g_prof_enabled && manage_profile) prof_end();
 
     int worst = ASVD_OK;
     for (int b = 0; b < batch; ++b) {

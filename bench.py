@@ -520,7 +520,12 @@ def main():
             "step_wall_ms": [1e3 * (b - a) for a, b in zip([t0] + step_marks[:-1], step_marks)], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{B} synthetic {m}x{n} fp32 Linears per GPU per step, abs_mean scaling (alpha 0.5), full SVD + rank-{r} truncation, factors emitted in fp16 (SURVEY 8d; the reference would emit the Linear's own dtype, svd_linear.py:102 - the cast is <0.1% of a step)",
-                       "batch_per_gpu": B, "m": m, "n": n, "rank": r, "parallelism": f"independent matrices x{world}"},
+                       "batch_per_gpu": B, "m": m, "n": n, "rank": r, "parallelism": f"independent matrices x{world}",
+                       "batch_split_over_chip_halves": bool(B >= 4 and min(m, n) >= 3072 and os.environ.get("ASVD_SPLIT", "1") != "0"),
+                       "split_note": "asvd_svd_batched runs a batch of >= 4 problems with >= 3072 columns as two halves on CU-masked streams (128 CUs each, one host "
+                                     "thread each; DESIGN.md 3.11): the timed steps run that way.  The profiled step behind `roofline` runs UNSPLIT (a profiled call "
+                                     "is never split), so `roofline.avg_launch_us` and the class times describe every kernel alone on the whole chip; ASVD_SPLIT=0 "
+                                     "runs the timed steps unsplit too (profiles/r5_bench_nosplit.json: 55.9 vs 59.2 SVD/s)"},
             "roofline": roofline,
         }
         if per_rank is not None:

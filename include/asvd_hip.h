@@ -134,7 +134,8 @@ int asvd_scale_cols(const void* w, int w_dtype, int64_t m, int64_t n, int64_t ld
  * (Cholesky breakdown flag), one per Jacobi sweep (convergence flags: four ints per problem), one more per sparse sweep
  * (the pair marks of the coupling snapshot go to the host, which packs them into rounds of disjoint pairs), one when a
  * problem finishes early (its `done` flag goes to the device), one at the end — 13 for a 4096 x 4096 call, 0.3 % of its time.
- * Everything is enqueued on `stream`, and only there: the library creates no stream of its own.  Concurrent calls from
+ * Everything is enqueued on `stream`; the one exception is the split of a large batch over two internal CU-masked streams
+ * (asvd_svd_set_call_cus below; they wait for everything queued on `stream` before the call, and the call returns synchronised).  Concurrent calls from
  * different host threads on different streams and workspaces are safe: no shared mutable state — schedule tables and modes
  * travel by value in the kernel arguments, not in __constant__ memory; the profiling counters are per thread — and no kernel
  * uses scratch.  tests/test_gpu_concurrency.py holds the library to it (two threads x 8 x 4096^2 next to a stream of foreign
@@ -143,7 +144,8 @@ int asvd_scale_cols(const void* w, int w_dtype, int64_t m, int64_t n, int64_t ld
  * ASVD_DEBUG_HIST (pair-measure histogram per sweep), ASVD_ORDER=rr (round-robin instead of XOR pair order, single-level sweeps),
  * ASVD_TWOLEVEL=0, ASVD_SUPGRAM=0 (separate Gram / update passes), ASVD_SPARSE=0, ASVD_NO_REDUCE (skip the Cholesky-QR),
  * ASVD_EVDQ=0/1 (force the throughput / latency form of the eigen-solver), ASVD_EVDW_TRACE (stage stamps of the solver),
- * ASVD_SPREAD_FROM=<sweep> (line-spread order of the XOR distances from that dense sweep on: a measurement knob).
+ * ASVD_SPREAD_FROM=<sweep> (line-spread order of the XOR distances from that dense sweep on: a measurement knob),
+ * ASVD_SPLIT=0 (never split a batch over the two halves of the chip).
  * Returns worst status over the batch.
  */
 int asvd_svd_worksize(int batch, int64_t m, int64_t n, int want_vectors, size_t* bytes);
@@ -257,6 +259,12 @@ int asvd_comm_destroy(void* comm);
  * ms_host: float[9] total milliseconds; launches_host: int[9].  */
 void asvd_svd_set_profiling(int enabled);
 int asvd_svd_get_profile(float* ms_host, int* launches_host);
+/* CUs the asvd_svd_batched calls of THIS host thread may use (0 = the whole device, the default).  asvd_svd_batched itself runs a batch of
+ * >= 4 problems with >= 3072 columns as two halves, each on its own host thread and on an internal stream masked to one half of the CUs
+ * (hipExtStreamCreateWithCUMask; ASVD_SPLIT=0 disables it, a profiled call runs unsplit): the eigen-solve launches of one half (VALU-bound)
+ * then overlap the HBM-bound update launches of the other, which two launches of one stream never do.  A caller that drives calls on
+ * CU-masked streams of its own announces the CU count here so that the launch geometry is sized for it; such calls are not split again. */
+void asvd_svd_set_call_cus(int cus);
 /* Test hook: one launch of the two-level update kernel ([X_S X_T] <- [X_S X_T] Qfin for every super-pair of XOR step D) on
  * caller-built panels X [batch][nb][R][32]; Qfin [batch][npairs][128*128]; subact [batch][npairs][4] (pair updated when any flag is
  * set); done, nupd [batch] ints.  Used by tests/test_gpu_twolevel.py only. */

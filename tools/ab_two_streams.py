@@ -22,11 +22,13 @@ def problems(dev, B, m, n, seed=233):
     return out
 
 
-def run_groups(mats, G, reps, streams=None):
-    """G host threads, each factorises its slice of the batch `reps` times on its own stream; returns wall seconds per rep (all groups)."""
+def run_groups(mats, G, reps, streams=None, sizes=None, cus=None):
+    """G host threads, each factorises its slice of the batch `reps` times on its own stream; returns wall seconds per rep (all groups).
+    sizes: problems per group (default: equal); cus: CUs of every group's masked stream (the library sizes its launches for them)"""
     dev = mats[0].device
     B = len(mats)
-    per = B // G
+    sizes = sizes or [B // G] * G
+    offs = [sum(sizes[:i]) for i in range(G)]
     res = [None] * G
     errs = []
     bar = threading.Barrier(G + 1)
@@ -34,10 +36,12 @@ def run_groups(mats, G, reps, streams=None):
     def worker(i):
         try:
             st = streams[i] if streams else torch.cuda.Stream(device=dev)
+            if cus:
+                _lib.load(True).asvd_svd_set_call_cus(int(cus[i]))   # per host thread
             with torch.cuda.stream(st):
                 bar.wait()
                 for _ in range(reps):
-                    res[i] = ops.svd_batched(mats[i * per:(i + 1) * per])
+                    res[i] = ops.svd_batched(mats[offs[i]:offs[i] + sizes[i]])
                 st.synchronize()
         except Exception as e:  # noqa: BLE001
             errs.append(repr(e))
@@ -95,6 +99,7 @@ def main():
     ap.add_argument("--mask_mode", default="first", help="first: the first N bits; stride: bits spread evenly over the 256")
     ap.add_argument("--warm_s", type=float, default=4.0)
     ap.add_argument("--mask_overlap", type=int, default=0)
+    ap.add_argument("--parts", default="", help='";"-separated partitions, each "problems:CUs,problems:CUs,..." (masked streams, CU-aware plans)')
     ap.add_argument("--group_masks", action="store_true", help="give every group its own 1/G of the CUs (masked streams) instead of sharing the chip")
     args = ap.parse_args()
     _lib.load(True)
@@ -119,6 +124,18 @@ def main():
         same = all(torch.equal(a, b) for i in range(G) for a, b in zip(res[i][1], ref[1][i * (args.batch // G):(i + 1) * (args.batch // G)]))
         print(json.dumps({"exp": "groups", "cu_masked_partition": bool(args.group_masks), "mask_overlap": args.mask_overlap, "m": args.m, "n": args.n, "batch": args.batch, "groups": G, "ms_per_batch": 1e3 * dt,
                           "svd_per_s": args.batch / dt, "sigma_bit_identical_to_one_call": bool(same),
+                          "sweeps": sorted(set(i.sweeps for r in res for i in r[3]))}), flush=True)
+    for spec in [x for x in args.parts.split(";") if x]:
+        # "16:128,16:128" = two groups of 16 problems on 128 CUs each (consecutive CU ranges), the library told about the CU counts
+        parts = [(int(a), int(b)) for a, b in (p.split(":") for p in spec.split(","))]
+        sizes, cus = [p[0] for p in parts], [p[1] for p in parts]
+        assert sum(sizes) == args.batch and sum(cus) <= ncu
+        starts = [sum(cus[:i]) for i in range(len(cus))]
+        streams = [masked_stream(dev, [1 if starts[i] <= c < starts[i] + cus[i] else 0 for c in range(ncu)]) for i in range(len(cus))]
+        os.environ["ASVD_SPLIT"] = "0"
+        dt, res = run_groups(mats, len(parts), 2, streams, sizes, cus)
+        dt, res = run_groups(mats, len(parts), args.reps, streams, sizes, cus)
+        print(json.dumps({"exp": "parts", "spec": spec, "m": args.m, "n": args.n, "batch": args.batch, "ms_per_batch": 1e3 * dt, "svd_per_s": args.batch / dt,
                           "sweeps": sorted(set(i.sweeps for r in res for i in r[3]))}), flush=True)
     for N in [int(x) for x in args.masks.split(",") if x]:
         if args.mask_mode == "first":
