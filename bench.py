@@ -325,6 +325,7 @@ def main():
     ap.add_argument("--sharded_model", default="auto", help="untimed extra: decomposition of a whole model's Linears, LPT-sharded over the ranks, + the sensitivity "
                     "all-gather and the factor gather on the process group (BASELINE configs[2] at one GPU -> \"full_model\", configs[3] at N -> \"sharded_model\"); "
                     "auto = llama-2-7b; or llama-2-7b / llama-2-13b / tiny / none")
+    ap.add_argument("--sharded_timeout_s", type=float, default=420.0, help="N > 1: give the untimed sharded-model leg this long, then print the bench line without it")
     ap.add_argument("--dry_run", action="store_true", help="launch plumbing only (CPU, gloo): spawn/bind ranks, barrier, max-reduce, JSON line; no kernels, value = null")
     args = ap.parse_args()
 
@@ -418,17 +419,6 @@ def main():
     ops.svd_profile(False)
     assert all(i.status == 0 for i in infos), [i.status for i in infos]  # every SVD of the batch converged
 
-    # ---- configs[3] in one line (untimed): LPT-sharded model decomposition + the real sensitivity all-gather on this process group ----
-    sharded, fm_samples = None, ([] if world == 1 else None)
-    sm = args.sharded_model if args.sharded_model != "auto" else "llama-2-7b"
-    if sm != "none":
-        try:
-            res = None   # drop the held outputs of the last timed step (3 GB)
-            sharded = sharded_model_leg(sm, rank, world, dev, samples=fm_samples)
-        except Exception as e:   # noqa: BLE001 — the untimed extra must not cost the bench line
-            sharded = {"model": sm, "error": f"{type(e).__name__}: {e}"[:300]}
-            print(f"[bench] rank {rank}: sharded-model leg failed: {sharded['error']}", file=sys.stderr)
-
     # per-rank rates (N > 1): every rank's own SVDs/s over its own wall clock
     per_rank = None
     if world > 1:
@@ -437,6 +427,7 @@ def main():
         dist.all_gather(allr, mine)
         per_rank = [float(t.item()) for t in allr]
 
+    out = None
     if rank == 0:
         total_svds = B * args.steps * world
         value = total_svds / dt
@@ -530,6 +521,36 @@ def main():
         }
         if per_rank is not None:
             out["per_rank_svds_per_s"] = per_rank
+
+    # ---- configs[2] / [3] in one line (untimed): the whole model's decomposition, LPT-sharded over the ranks, + the real sensitivity all-gather and
+    # the factor gather on this process group.  The bench line is complete at this point; at N > 1 a watchdog prints it and ends the process if the
+    # extra leg does not come back (a hang in a collective that has never run on this node must not cost the weak-scaling number) ----
+    sharded, fm_samples = None, ([] if world == 1 else None)
+    sm = args.sharded_model if args.sharded_model != "auto" else "llama-2-7b"
+    if sm != "none":
+        watchdog = None
+        if world > 1:
+            import threading
+
+            def give_up():
+                if rank == 0:
+                    out["sharded_model"] = {"model": sm, "error": f"the sharded-model leg did not finish within {args.sharded_timeout_s:.0f} s: abandoned (the line above it is complete)"}
+                    print(json.dumps(out), flush=True)
+                os._exit(0)
+
+            watchdog = threading.Timer(args.sharded_timeout_s, give_up)
+            watchdog.daemon = True
+            watchdog.start()
+        try:
+            res = None   # drop the held outputs of the last timed step (3 GB)
+            sharded = sharded_model_leg(sm, rank, world, dev, samples=fm_samples)
+        except Exception as e:   # noqa: BLE001 — the untimed extra must not cost the bench line
+            sharded = {"model": sm, "error": f"{type(e).__name__}: {e}"[:300]}
+            print(f"[bench] rank {rank}: sharded-model leg failed: {sharded['error']}", file=sys.stderr)
+        if watchdog is not None:
+            watchdog.cancel()
+
+    if rank == 0:
         if sharded is not None:
             out["sharded_model" if world > 1 else "full_model"] = sharded
         # ---- batch-1 latency (BASELINE configs[1] says "single ... Linear"): one matrix alone, same path, median of 3 ----
