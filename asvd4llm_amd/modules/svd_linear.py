@@ -326,7 +326,8 @@ class SVDLinear(nn.Module):
     def forward(self, inp):
         # compute USV^Tx + b  (svd_linear.py:105-109).  Decode-sized inputs (<= 16 fp16 tokens, in/out features <= 8192, no autograd): ONE
         # persistent launch that streams B and A once and keeps the r-wide intermediate on chip (K10, csrc/lowrank_forward.hip) — measured
-        # 21 / 23 / 26 / 32 us at 1 / 2 / 4 / 16 tokens against 36 us for the two hipBLASLt launches at 4096 -> 1843 -> 4096.  Everywhere
+        # 20.9 / 22.2 / 25.0 / 32.2 us at 1 / 2 / 4 / 16 tokens against 37 us for the two hipBLASLt launches at 4096 -> 1843 -> 4096 (round 5,
+        # profiles/r5_k10_nostrict.jsonl; under ASVD_STRICT the wrapper used to read the give-up flag after every launch: +18 us, now every 64th).  Everywhere
         # else the reference's two GEMMs through nn.Linear: at par from 64 tokens on and on the 11008-wide MLP projections (DESIGN.md
         # section 4 has the table).  Opt-in (ASVD_FUSED_FORWARD=1 / self.fused_forward): see _fused_forward_enabled.
         if ((getattr(self, "fused_forward", False) or _fused_forward_enabled()) and inp.is_cuda and inp.dtype == torch.float16 and self.BLinear.weight.dtype == torch.float16 and inp.shape[-1] % 64 == 0

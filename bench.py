@@ -34,6 +34,7 @@ def synth(size_m, size_n, seed, n_calib=32):
 MODEL_SHAPES = {  # (out, in) of the Linears of a decoder layer + lm_head, and the layer count (model configs[2]-[4])
     "llama-2-7b": dict(layers=32, attn=(4096, 4096), up=(11008, 4096), down=(4096, 11008), head=(32000, 4096)),
     "llama-2-13b": dict(layers=40, attn=(5120, 5120), up=(13824, 5120), down=(5120, 13824), head=(32000, 5120)),
+    "llama-7b-2layers": dict(layers=2, attn=(4096, 4096), up=(11008, 4096), down=(4096, 11008), head=(32000, 4096)),   # tests: the 7B shapes, 15 Linears
     "tiny": dict(layers=3, attn=(64, 64), up=(176, 64), down=(64, 176), head=(320, 64)),
 }
 
@@ -326,6 +327,9 @@ def main():
                     "all-gather and the factor gather on the process group (BASELINE configs[2] at one GPU -> \"full_model\", configs[3] at N -> \"sharded_model\"); "
                     "auto = llama-2-7b; or llama-2-7b / llama-2-13b / tiny / none")
     ap.add_argument("--sharded_timeout_s", type=float, default=420.0, help="N > 1: give the untimed sharded-model leg this long, then print the bench line without it")
+    ap.add_argument("--dist_backend", default="nccl", choices=["nccl", "gloo"], help="N > 1: nccl = RCCL over xGMI (the product); gloo = CI stand-in, together with "
+                    "--same_gpu it runs the N ranks of the whole bench — sharded model, all-gather, factor gather — with the real kernels on ONE GPU")
+    ap.add_argument("--same_gpu", action="store_true", help="bind every rank to cuda:0 (with --dist_backend gloo)")
     ap.add_argument("--dry_run", action="store_true", help="launch plumbing only (CPU, gloo): spawn/bind ranks, barrier, max-reduce, JSON line; no kernels, value = null")
     args = ap.parse_args()
 
@@ -355,10 +359,15 @@ def main():
         print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: reporting n_gpus={world} (the ranks that actually run)", file=sys.stderr)
     if args.dry_run:
         return dry_run(args, rank, world)
+    gpu_index = 0 if (world == 1 or args.same_gpu) else local_rank
     if world > 1:
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+        torch.cuda.set_device(gpu_index)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", gpu_index))
+        else:   # CI stand-in: several ranks on ONE GPU (RCCL refuses two ranks per device), collectives over gloo on host tensors
+            dist.init_process_group("gloo")
+    dev = torch.device("cuda", gpu_index)
+    comm_dev = dev if (world > 1 and args.dist_backend == "nccl") else torch.device("cpu")
     _lib.load(require_device=True)  # fails loudly without the HIP library / a gfx950 device
 
     B, m, n, r = args.batch, args.m, args.n, args.rank
@@ -407,7 +416,7 @@ def main():
     dt = time.perf_counter() - t0
     dt_local = dt
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -422,7 +431,7 @@ def main():
     # per-rank rates (N > 1): every rank's own SVDs/s over its own wall clock
     per_rank = None
     if world > 1:
-        mine = torch.tensor([B * args.steps / dt_local], dtype=torch.float64, device=dev)
+        mine = torch.tensor([B * args.steps / dt_local], dtype=torch.float64, device=comm_dev)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         per_rank = [float(t.item()) for t in allr]

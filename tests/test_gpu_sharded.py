@@ -143,3 +143,32 @@ def test_calibration_samples_sharded_allreduce(tmp_path):
             assert np.allclose(scal[n], scal1[n], rtol=1e-5, atol=1e-7), n
     for n in scal1:
         assert np.array_equal(res[0][7][n], res[1][7][n]), n  # every rank ends with the same accumulators
+
+
+@pytest.mark.timeout(1200)
+def test_bench_two_ranks_on_one_gpu_run_the_whole_multi_gpu_leg(tmp_path):
+    """`bench.py --gpus 2` as the driver launches it, except that both ranks share cuda:0 and the collectives run over gloo (RCCL refuses two ranks
+    per device): the timed weak-scaling loop with the real kernels (each rank its own batch, split over the chip halves), barrier + max over ranks,
+    per-rank rates, then the sharded model leg — LPT shard, every rank decomposes its own Linears, the all-gather of the sensitivities, the
+    replicated search, the factor gather into rank 0 — and ONE JSON line on rank 0."""
+    import json
+    import subprocess
+    import sys
+    from tests.conftest import ROOT
+    import os
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist_backend", "gloo", "--same_gpu", "--batch", "4", "--steps", "1", "--warmup", "0",
+           "--prewarm_s", "0", "--sharded_model", "llama-7b-2layers"]
+    env = dict(os.environ, ASVD_STRICT="1")
+    env.pop("WORLD_SIZE", None)
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=1100, env=env, cwd=str(tmp_path))
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak" and len(d["per_rank_svds_per_s"]) == 2
+    sm = d["sharded_model"]
+    assert "error" not in sm, sm
+    assert sm["linears"] == 15 and sum(sm["layers_per_rank"]) == 15 and min(sm["layers_per_rank"]) >= 1
+    assert sm["collective_world_size"] == 2 and sm["plan_identical_on_all_ranks"]
+    assert sm["gather_factors_s"] > 0 and sm["gather_factors_bytes_into_rank0"] > 1e6     # rank 1's factors reached rank 0
+    assert sm["decompose_s"] > 0 and sm["load_flops_max_over_mean"] < 1.3
