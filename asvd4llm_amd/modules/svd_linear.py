@@ -201,8 +201,14 @@ class SVDLinear(nn.Module):
         # Calls of small problems (< 2048 columns) leave most of the chip idle between the launches of their dependency chain, and the library
         # takes concurrent calls on different streams (include/asvd_hip.h; tests/test_gpu_concurrency.py): the groups of an opt-125m-shaped model
         # (48 x 768^2, 12 x 3072x768, 12 x 768x3072, the 50272x768 lm_head) run side by side, one host thread and one stream each.
-        small = [c for kc, c in jobs if kc < 2048 and c[0][2].is_cuda]
-        if concurrent and len(small) > 1:
+        # Round 5: the same goes for LONE large problems (fewer than 4 of a shape: the lm_head of a Llama — one 32000 x 4096 matrix is a latency chain of
+        # ~0.1 s that fills 32 of the 256 CUs): they run on side threads WHILE the caller's thread works through the large batches.
+        def side(kc, c):
+            return c[0][2].is_cuda and (kc < 2048 or len(c) < 4)
+
+        small = [c for kc, c in jobs if side(kc, c)]
+        n_main = sum(1 for kc, c in jobs if not side(kc, c))
+        if concurrent and (len(small) > 1 or (small and n_main > 0)):
             import threading
             from .. import _lib
             _lib.load(True)   # loaded (and, if need be, built) once, by this thread
@@ -242,6 +248,13 @@ class SVDLinear(nn.Module):
             threads = [threading.Thread(target=worker, args=(c,)) for c in small]
             for t in threads:
                 t.start()
+            main_error = None
+            try:
+                for kc, chunk in jobs:   # the large batches, on the caller's thread and stream, next to the side workers
+                    if not side(kc, chunk):
+                        run(chunk)
+            except Exception as e:  # noqa: BLE001 — the workers are joined before anything is raised
+                main_error = e
             for t in threads:
                 t.join()
             for dev, (U, S, V) in outs:   # allocated on the side streams, consumed on the caller's stream of their device from here on
@@ -249,9 +262,11 @@ class SVDLinear(nn.Module):
                 for lst in (U, S, V):
                     for t in (lst or []):
                         t.record_stream(main)
+            if main_error is not None:
+                raise main_error
             if errors:
                 raise errors[0]
-            jobs = [(kc, c) for kc, c in jobs if not (kc < 2048 and c[0][2].is_cuda)]
+            return
         for _, chunk in jobs:
             run(chunk)
 
