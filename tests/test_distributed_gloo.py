@@ -375,3 +375,40 @@ def test_factor_gather_from_several_owners_world4():
     rank0 = res[0]
     assert rank0[1] == rank0[3] and rank0[2], rank0        # rank 0 received every layer it does not own, bit for bit
     assert all(r[1] == 0 for r in res[1:])
+
+
+def _save_cache_fail_worker(rank, ws, port, q, tmpdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    try:
+        os.chdir(tmpdir)
+        open("blocker", "w").write("a FILE where rank 0 wants a directory")     # makedirs("blocker") fails on rank 0
+        outcome = "no error"
+        try:
+            parallel.save_cache({"x": 1}, "blocker/cache.pt")
+        except Exception as e:  # noqa: BLE001
+            outcome = type(e).__name__
+        ok_path = os.path.join(tmpdir, "fine", "cache.pt")
+        parallel.save_cache({"x": 2}, ok_path)                                # and the next write works, on every rank, without a stuck barrier
+        q.put((rank, outcome, parallel.cache_exists(ok_path), parallel.load_cache(ok_path)["x"]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_failed_cache_write_raises_on_every_rank(tmp_path):
+    """rank 0 failing in makedirs / torch.save must not leave the other ranks in a barrier: the ok-flag is broadcast, every rank raises"""
+    ws = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_save_cache_fail_worker, args=(r, ws, port, q, str(tmp_path))) for r in range(ws)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(ws))
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    assert res[0][1] != "no error" and res[1][1] == "RuntimeError", res      # rank 0: its own OSError; rank 1: told by the flag
+    assert all(r[2] and r[3] == 2 for r in res)
