@@ -60,6 +60,14 @@ __device__ __forceinline__ float col_update_b(float y, float own, float cl, floa
     asm("v_fmac_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(z) : "v"(y), "v"(cr));
     return z;
 }
+// RING variants (cross-only visits, see evdw_sweep_ring): phase B also pairs positions 63 and 0, so the partners come by wave ROTATES and no lane idles
+constexpr int DPP_ROL1 = 0x134;   // wave_rol:1 — lane i reads lane (i + 1) & 63
+constexpr int DPP_ROR1 = 0x13C;   // wave_ror:1 — lane i reads lane (i - 1) & 63
+__device__ __forceinline__ float col_update_ring(float y, float own, float cl, float cr) {
+    float z = fmaf(own, y, cl * dppf<DPP_ROL1>(y));
+    asm("v_fmac_f32_dpp %0, %1, %2 wave_ror:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(z) : "v"(y), "v"(cr));
+    return z;
+}
 // one element of the next phase's pivot vector: bn[L] = v[L].  `lane` is made opaque once per phase (an empty asm) so that the 32 lane
 // masks of a phase are not hoisted out of the sweep loop and kept in (spilled) SGPRs.
 __device__ __forceinline__ float put_lane(float bn, float v, int L, int lane) { return (lane == L) ? v : bn; }
@@ -79,7 +87,7 @@ __device__ __forceinline__ float put_lane_s(float bn, float v, int L, unsigned l
 // wave-private LDS (one ds_write_b64 per lane, one broadcast ds_read_b64 per row pair) instead of two v_readlane per row pair: measured
 // 2.3 ns per v_readlane against 1.1 ns per plain VALU instruction on a saturated SIMD (tools/ubench/valu_cost.hip) — 14 % of a phase —
 // while the LDS pipe is idle during the sweep.  A wave's LDS operations complete in order: no barrier.
-template <int PAR>
+template <int PAR, bool RING = false>
 __device__ __forceinline__ void evdw_phase(float (&g)[64], float (&q)[64], float& diag, float& bpiv, const int lane, float* __restrict__ cslds) {
     const bool odd = (lane & 1) != 0;
     float bn = 0.0f;
@@ -119,9 +127,49 @@ __device__ __forceinline__ void evdw_phase(float (&g)[64], float (&q)[64], float
             g[2 * k] = z0;
             g[2 * k + 1] = z1;
             if (k >= 1) bn = put_lane_s(bn, z0, 2 * k - 1, one);    // phase B: lower lanes are odd L, their pivot is register L + 1
+            else if (RING) bn = put_lane_s(bn, z0, 63, one);        // ring: position 63 pairs with position 0, its pivot is register 0
         }
 #pragma unroll
         for (int r = 0; r < 64; ++r) q[r] = fmaf(own, q[r], c * dppf<DPP_XOR1>(q[r]));
+    } else if constexpr (RING) {
+        // phase B on the ring: pairs (2k + 1, (2k + 2) & 63), k = 0..31 — nothing idles
+        const bool lower = odd;
+        const float d_up = dppf<DPP_ROL1>(diag), d_dn = dppf<DPP_ROR1>(diag), b_dn = dppf<DPP_ROR1>(bpiv);
+        const float b = lower ? bpiv : b_dn;
+        const float a_ = lower ? diag : d_dn, d_ = lower ? d_up : diag;
+        float c, s, t;
+        jacobi_rot(a_, d_, b, c, s, t);
+        diag = fmaf(lower ? t : -t, b, lower ? d_ : a_);
+        const float own = lower ? s : -s;
+        const float cl = lower ? c : 0.0f;   // weight of the value of lane + 1 (odd lanes)
+        const float cr = lower ? 0.0f : c;   // weight of the value of lane - 1 (even lanes)
+        *(float2*)(cslds + 2 * lane) = make_float2(c, s);
+        float2 csb[2][8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) csb[0][j] = *(const float2*)(cslds + 2 * (2 * j + 1));
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            if ((k & 7) == 0) {
+                if (k + 8 < 32) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) csb[((k >> 3) + 1) & 1][j] = *(const float2*)(cslds + 2 * (2 * (k + 8 + j) + 1));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const float2 cs2 = csb[(k >> 3) & 1][k & 7];
+            const float ck = cs2.x, sk = cs2.y;
+            const int rp = 2 * k + 1, rq = (2 * k + 2) & 63;
+            const float x0 = g[rp], x1 = g[rq];
+            const float y0 = fmaf(ck, x1, sk * x0);
+            const float y1 = fmaf(-sk, x1, ck * x0);
+            const float z0 = col_update_ring(y0, own, cl, cr);
+            const float z1 = col_update_ring(y1, own, cl, cr);
+            g[rp] = z0;
+            g[rq] = z1;
+            bn = put_lane_s(bn, z0, 2 * k, one);                    // phase A: lower lanes are even L, their pivot is register L + 1
+        }
+#pragma unroll
+        for (int r = 0; r < 64; ++r) q[r] = col_update_ring(q[r], own, cl, cr);
     } else {
         const bool lower = odd;                              // pairs (2k+1, 2k+2); lanes 0 and 63 idle
         const bool idle = (lane == 0) || (lane == 63);
@@ -234,6 +282,46 @@ __device__ __forceinline__ void evdw_identity(float (&q)[64], const int lane) {
     for (int r = 0; r < 64; ++r) q[r] = (lane == r) ? 1.0f : 0.0f;
 }
 
+// ---- cross-only visits on a ring (round 5) ----------------------------------------------------------------------------------------------
+// A solve of the two-level sweeps pairs two 32-column panels S, T whose own Gram blocks arrive (nearly) diagonal: what the visit has to
+// annihilate are the 1024 CROSS couplings; the 2 x 496 pairs inside the panels belong to the internal step of the sweep.  With the positions
+// INTERLEAVED (position 2k = column k of S, 2k + 1 = column k of T) and phase B closed to a ring (position 63 pairs with position 0), the
+// odd-even transposition with swap moves the S columns one way round and the T columns the other: after 32 phases — half a full cycle —
+// every S column has met every T column exactly once and no two columns of the same panel have met (tools/proto_cross_only.py: one more
+// sparse sweep at the end of the outer iteration, half the phases per visit).
+//   ring position of natural index x:  pos(x) = 2 x (x < 32),  2 (x - 32) + 1 (x >= 32);   natural index of position p:  nat(p) = (p & 1) * 32 + (p >> 1)
+__device__ __forceinline__ constexpr int ring_pos(int x) { return x < 32 ? 2 * x : 2 * (x - 32) + 1; }
+// image natural -> ring, rows (registers, a renaming) and columns (lanes: one ds_bpermute per register)
+__device__ __forceinline__ void ring_image(float (&g)[64], const int lane) {
+    const int src = (((lane & 1) << 5) + (lane >> 1)) << 2;   // byte address of the lane that holds natural column nat(lane)
+    float t[64];
+#pragma unroll
+    for (int r = 0; r < 64; ++r) t[ring_pos(r)] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(g[r])));
+#pragma unroll
+    for (int r = 0; r < 64; ++r) g[r] = t[r];
+}
+// rows of Q back to natural order (its columns = positions stay: every consumer places them by their sorted rank)
+__device__ __forceinline__ void ring_rows_to_natural(float (&q)[64]) {
+    float t[64];
+#pragma unroll
+    for (int r = 0; r < 64; ++r) t[r] = q[ring_pos(r)];
+#pragma unroll
+    for (int r = 0; r < 64; ++r) q[r] = t[r];
+}
+// `loops` cross-only visits (16 phase pairs each).  In: the natural image in g, q = identity.  Out: g = the image in RING positions (rows and
+// lanes: what evdw_store_diag_blocks / evdw_finish address by position), q = eigenvector matrix with natural rows, diag per position.
+__device__ __forceinline__ void evdw_sweep_ring(float (&g)[64], float (&q)[64], float& diag, float& bpiv, const int lane, const int loops,
+                                                float* __restrict__ cslds) {
+    ring_image(g, lane);
+    evdw_init_state(g, lane, diag, bpiv);
+#pragma unroll 1
+    for (int ph2 = 0; ph2 < 16 * loops; ++ph2) {
+        evdw_phase<0, true>(g, q, diag, bpiv, lane, cslds);
+        evdw_phase<1, true>(g, q, diag, bpiv, lane, cslds);
+    }
+    ring_rows_to_natural(q);
+}
+
 // After the sweeps: cs = 1 / |q_c| (fp64 norm: the accumulated rounding of ~64 rotations per column must not drift the norms of the
 // updated panels) and rnk = position of column `lane` in the descending order of the eigenvalues (ties by index).  A solve that did not
 // rotate keeps everything in place (cs = 1, rnk = lane).
@@ -286,7 +374,7 @@ template <int NW> struct Coop {
     static constexpr int FLOATS = FLAG + 4;
 };
 
-template <int NW>
+template <int NW, bool RING = false>
 __device__ __forceinline__ void coop_phase_a(float (&gl)[64 / NW], float (&ql)[64 / NW], float& diag, const float bpiv, const int lane, const int r0,
                                              const int h, float* __restrict__ L) {
     constexpr int RB = 64 / NW;
@@ -319,8 +407,9 @@ __device__ __forceinline__ void coop_phase_a(float (&gl)[64 / NW], float (&ql)[6
         gl[2 * kp] = z0;
         gl[2 * kp + 1] = z1;
         if (kp > 0 || h > 0) bn = put_lane_s(bn, z0, r0 + 2 * kp - 1, one);   // phase B: lower lanes are odd L, their pivot is row L + 1 (row 0 has none)
+        else if (RING) bn = put_lane_s(bn, z0, 63, one);                       // ring: position 63 pairs with position 0
     }
-    if (odd && lane + 1 >= r0 && lane + 1 < r0 + RB) L[Coop<NW>::PIV + lane] = bn;           // pivots of phase B (parity buffer 0)
+    if (odd && ((lane + 1) & (RING ? 63 : 127)) >= r0 && ((lane + 1) & (RING ? 63 : 127)) < r0 + RB) L[Coop<NW>::PIV + lane] = bn;   // pivots of phase B (parity buffer 0)
     L[Coop<NW>::BROW + (2 * h) * 64 + lane] = gl[0];                                           // boundary rows as phase B will find them
     L[Coop<NW>::BROW + (2 * h + 1) * 64 + lane] = gl[RB - 1];
 #pragma unroll
@@ -395,21 +484,82 @@ __device__ __forceinline__ void coop_phase_b(float (&gl)[64 / NW], float (&ql)[6
     for (int i = 0; i < RB; ++i) ql[i] = col_update_b(ql[i], own, cl, cr);
 }
 
+// phase B on the ring (cross-only visits): every row pair (2k + 1, (2k + 2) & 63) exists, the pair at EVERY block boundary — the one between the
+// last and the first wave included — takes its other member from the neighbour's published boundary row
+template <int NW>
+__device__ __forceinline__ void coop_phase_b_ring(float (&gl)[64 / NW], float (&ql)[64 / NW], float& diag, const float bpiv, const int lane, const int r0,
+                                                  const int h, float* __restrict__ L) {
+    constexpr int RB = 64 / NW;
+    float* __restrict__ cslds = L + Coop<NW>::CS + h * 128;
+    const bool lower = (lane & 1) != 0;
+    const float d_up = dppf<DPP_ROL1>(diag), d_dn = dppf<DPP_ROR1>(diag), b_dn = dppf<DPP_ROR1>(bpiv);
+    const float b = lower ? bpiv : b_dn;
+    const float a_ = lower ? diag : d_dn, d_ = lower ? d_up : diag;
+    float c, s, t;
+    jacobi_rot(a_, d_, b, c, s, t);
+    diag = fmaf(lower ? t : -t, b, lower ? d_ : a_);
+    const float own = lower ? s : -s;
+    const float cl = lower ? c : 0.0f;
+    const float cr = lower ? 0.0f : c;
+    *(float2*)(cslds + 2 * lane) = make_float2(c, s);
+    float bn = 0.0f;
+    unsigned long long one = 1ull;
+    asm volatile("" : "+s"(one));
+    float2 csb[RB / 2 + 1];
+    csb[0] = *(const float2*)(cslds + 2 * ((r0 + 63) & 63));                 // pair (r0 - 1, r0): coefficients at position r0 - 1
+#pragma unroll
+    for (int j = 0; j < RB / 2 - 1; ++j) csb[1 + j] = *(const float2*)(cslds + 2 * (r0 + 2 * j + 1));
+    csb[RB / 2] = *(const float2*)(cslds + 2 * (r0 + RB - 1));                // pair (r0 + RB - 1, r0 + RB)
+    const float xp_n = L[Coop<NW>::BROW + (2 * ((h + NW - 1) % NW) + 1) * 64 + lane];   // last row of the previous wave (as phase A left it)
+    const float xq_n = L[Coop<NW>::BROW + (2 * ((h + 1) % NW)) * 64 + lane];            // first row of the next wave
+    __builtin_amdgcn_sched_barrier(0);
+    {   // upper member of the pair (r0 - 1, r0)
+        const float2 cs2 = csb[0];
+        gl[0] = col_update_ring(fmaf(-cs2.y, gl[0], cs2.x * xp_n), own, cl, cr);
+    }
+#pragma unroll
+    for (int j = 0; j < RB / 2 - 1; ++j) {
+        const int pl = 2 * j + 1;
+        const float2 cs2 = csb[1 + j];
+        const float ck = cs2.x, sk = cs2.y;
+        const float x0 = gl[pl], x1 = gl[pl + 1];
+        const float y0 = fmaf(ck, x1, sk * x0);
+        const float y1 = fmaf(-sk, x1, ck * x0);
+        const float z0 = col_update_ring(y0, own, cl, cr);
+        const float z1 = col_update_ring(y1, own, cl, cr);
+        gl[pl] = z0;
+        gl[pl + 1] = z1;
+        bn = put_lane_s(bn, z0, r0 + pl - 1, one);
+    }
+    {   // lower member of the pair (r0 + RB - 1, r0 + RB)
+        const float2 cs2 = csb[RB / 2];
+        const float z0 = col_update_ring(fmaf(cs2.x, xq_n, cs2.y * gl[RB - 1]), own, cl, cr);
+        gl[RB - 1] = z0;
+        bn = put_lane_s(bn, z0, r0 + RB - 2, one);
+    }
+    if (!lower && lane + 1 >= r0 && lane + 1 < r0 + RB) L[Coop<NW>::PIV + 64 + lane] = bn;      // pivots of phase A (parity buffer 1)
+#pragma unroll
+    for (int i = 0; i < RB; ++i) ql[i] = col_update_ring(ql[i], own, cl, cr);
+}
+
 // One full inner sweep (32 phase pairs) of the solve whose LDS block is L.  MAIN (h == 0) enters with the image in g, the state in
 // diag / bpiv and `rotate`; it leaves with g, q, diag as evdw_sweep would (q = identity when the solve does not rotate).  Helpers pass
 // dummies.  Every wave of the workgroup executes the same 66 barriers whether its solve rotates or not.
-template <int NW>
+// RING: the cross-only visit (evdw_sweep_ring): the scatter of the image puts rows AND columns at their ring positions, 16 phase pairs, the gather
+// returns the image in ring positions and Q with natural rows — element for element what the wave-local ring sweep computes.
+template <int NW, bool RING = false>
 __device__ __forceinline__ void coop_sweep(float (&g)[64], float (&q)[64], float& diag, const float bpiv_in, const bool rotate, const int lane, const int h,
                                            float* __restrict__ L) {
     constexpr int RB = 64 / NW;
     const int r0 = h * RB;
+    const int plane = RING ? (lane < 32 ? 2 * lane : 2 * (lane - 32) + 1) : lane;   // ring position of this lane's natural column
     if (h == 0) {
         if (rotate) {
 #pragma unroll
-            for (int r = 0; r < 64; ++r) L[Coop<NW>::XG + r * 64 + lane] = g[r];
+            for (int r = 0; r < 64; ++r) L[Coop<NW>::XG + (RING ? ring_pos(r) : r) * 64 + plane] = g[r];
         }
-        L[Coop<NW>::DIAG + lane] = diag;
-        L[Coop<NW>::PIV + 64 + lane] = bpiv_in;   // first phase is A: parity buffer 1
+        L[Coop<NW>::DIAG + plane] = diag;
+        L[Coop<NW>::PIV + 64 + lane] = bpiv_in;   // first phase is A: parity buffer 1 (RING: replaced below, the natural pivots mean nothing there)
         L[Coop<NW>::PIV + lane] = 0.0f;
         if (lane == 0) ((int*)L)[Coop<NW>::FLAG] = rotate ? 1 : 0;
     }
@@ -422,11 +572,16 @@ __device__ __forceinline__ void coop_sweep(float (&g)[64], float (&q)[64], float
         gl[i] = live ? L[Coop<NW>::XG + (r0 + i) * 64 + lane] : 0.0f;
         ql[i] = (lane == r0 + i) ? 1.0f : 0.0f;
     }
+    // RING: first pivots in ring positions, G'[lane + 1][lane] (only the even lanes' values are used); lane 63 gets 0 like evdw_init_state
+    const float bp0 = (RING && live && lane < 63) ? L[Coop<NW>::XG + (lane + 1) * 64 + lane] : 0.0f;
 #pragma unroll 1
-    for (int ph2 = 0; ph2 < 32; ++ph2) {
-        if (live) coop_phase_a<NW>(gl, ql, dg, L[Coop<NW>::PIV + 64 + lane], lane, r0, h, L);
+    for (int ph2 = 0; ph2 < (RING ? 16 : 32); ++ph2) {
+        if (live) coop_phase_a<NW, RING>(gl, ql, dg, (RING && ph2 == 0) ? bp0 : L[Coop<NW>::PIV + 64 + lane], lane, r0, h, L);
         __syncthreads();
-        if (live) coop_phase_b<NW>(gl, ql, dg, L[Coop<NW>::PIV + lane], lane, r0, h, L);
+        if (live) {
+            if constexpr (RING) coop_phase_b_ring<NW>(gl, ql, dg, L[Coop<NW>::PIV + lane], lane, r0, h, L);
+            else coop_phase_b<NW>(gl, ql, dg, L[Coop<NW>::PIV + lane], lane, r0, h, L);
+        }
         __syncthreads();
     }
     if (live) {
@@ -441,7 +596,7 @@ __device__ __forceinline__ void coop_sweep(float (&g)[64], float (&q)[64], float
 #pragma unroll
         for (int r = 0; r < 64; ++r) {
             g[r] = L[Coop<NW>::XG + r * 64 + lane];
-            q[r] = L[Coop<NW>::XQ + r * 64 + lane];
+            q[r] = L[Coop<NW>::XQ + (RING ? ring_pos(r) : r) * 64 + lane];
         }
         diag = dg;
     }
@@ -581,11 +736,13 @@ __device__ __forceinline__ int mfma_row(int reg, int h) { return (reg & 3) + 8 *
 // NW = 1: two waves per super-pair, each solve wave-local (throughput form).  NW = 4: eight waves, waves 0 / 1 are the MAIN waves of the two
 // solves and run exactly the code of the NW = 1 form except that their sweeps are cooperative (coop_sweep) with the helper waves
 // 2 h + sp, h = 1..3, which only take part in the sweeps and the workgroup barriers (latency form: one workgroup per CU).
-template <int NW>
+// RING: both inner steps are cross-only visits on the ring (evdw_sweep_ring / coop_sweep<NW, true>): half the phases per solve.
+template <int NW, int RINGM>   // RINGM: 0 full visits, 1 cross-only ring visits in both inner steps, 2 in step 1 only
 __global__ __launch_bounds__(128 * NW, NW == 1 ? 2 : 1) void evdw12_kernel(Sched sc, unsigned* __restrict__ maxoff_bits, int* __restrict__ nrot,
                                                         const int* __restrict__ done, float tol, int inner_sweeps, int nb, int step, int kb,
                                                         EvdV3 v3, long long* __restrict__ trace) {
     extern __shared__ __attribute__((aligned(16))) float e12_smem[];
+    constexpr bool RING0 = RINGM == 1, RING1 = RINGM >= 1;
     // stage trace (ASVD_EVDW_TRACE=1): shader-clock stamps of workgroup (0, 0), one row of 16 per wave
     int tstage = 0;
     auto stamp = [&]() {
@@ -621,10 +778,10 @@ __global__ __launch_bounds__(128 * NW, NW == 1 ? 2 : 1) void evdw12_kernel(Sched
     if constexpr (NW > 1) {
         if (hw > 0) {   // helper wave: the two cooperative sweeps and the barriers of the main waves in between, nothing else
             float dd = 0.0f;
-            coop_sweep<NW>(g, q, dd, 0.0f, false, lane, hw, LC);
+            coop_sweep<NW, RING0>(g, q, dd, 0.0f, false, lane, hw, LC);
             __syncthreads(); __syncthreads();                       // end of step 0
             __syncthreads(); __syncthreads(); __syncthreads();      // step-1 image assembly
-            coop_sweep<NW>(g, q, dd, 0.0f, false, lane, hw, LC);
+            coop_sweep<NW, RING1>(g, q, dd, 0.0f, false, lane, hw, LC);
             return;
         }
     }
@@ -680,8 +837,12 @@ __global__ __launch_bounds__(128 * NW, NW == 1 ? 2 : 1) void evdw12_kernel(Sched
         evdw_identity(q, lane);
         stamp();  // 2: measured
         asm volatile("" ::: "memory");
-        if constexpr (NW > 1) coop_sweep<NW>(g, q, diag, bpiv, rotate, lane, 0, LC);
-        else if (rotate) evdw_sweep(g, q, diag, bpiv, lane, ((off0 > 0.05f) ? inner_sweeps : min(1, inner_sweeps)) * EVD_PHASE_PAIRS, e12_smem + E12_CS + sp * 128);
+        if constexpr (NW > 1) coop_sweep<NW, RING0>(g, q, diag, bpiv, rotate, lane, 0, LC);
+        else if (rotate) {
+            const int nsw = (off0 > 0.05f) ? inner_sweeps : min(1, inner_sweeps);
+            if constexpr (RING0) evdw_sweep_ring(g, q, diag, bpiv, lane, nsw, e12_smem + E12_CS + sp * 128);
+            else evdw_sweep(g, q, diag, bpiv, lane, nsw * EVD_PHASE_PAIRS, e12_smem + E12_CS + sp * 128);
+        }
         asm volatile("" ::: "memory");   // no load of a later stage is hoisted above the sweep (its registers would be spilled across it)
         stamp();  // 3: swept
         evdw_finish(q, diag, lane, rotate, cs, rnk);
@@ -807,8 +968,12 @@ __global__ __launch_bounds__(128 * NW, NW == 1 ? 2 : 1) void evdw12_kernel(Sched
             }
         }
         evdw_identity(q, lane1);
-        if constexpr (NW > 1) coop_sweep<NW>(g, q, diag, bpiv, rotate, lane1, 0, LC);
-        else if (rotate) evdw_sweep(g, q, diag, bpiv, lane1, ((off0 > 0.05f) ? inner_sweeps : min(1, inner_sweeps)) * EVD_PHASE_PAIRS, e12_smem + E12_CS + sp * 128);
+        if constexpr (NW > 1) coop_sweep<NW, RING1>(g, q, diag, bpiv, rotate, lane1, 0, LC);
+        else if (rotate) {
+            const int nsw = (off0 > 0.05f) ? inner_sweeps : min(1, inner_sweeps);
+            if constexpr (RING1) evdw_sweep_ring(g, q, diag, bpiv, lane1, nsw, e12_smem + E12_CS + sp * 128);
+            else evdw_sweep(g, q, diag, bpiv, lane1, nsw * EVD_PHASE_PAIRS, e12_smem + E12_CS + sp * 128);
+        }
         asm volatile("" ::: "memory");
         stamp();  // 10: swept
         evdw_finish(q, diag, lane1, rotate, cs, rnk);
@@ -878,6 +1043,7 @@ __global__ __launch_bounds__(128 * NW, NW == 1 ? 2 : 1) void evdw12_kernel(Sched
 
 // Test hook kernel: one wave per 64x64 symmetric matrix (row-major), `sweeps` full inner sweeps, outputs the UNSORTED eigenvector
 // matrix Q [64][64] (row r, position c), the closed-form diagonal, the sort ranks, the column scales and the final image.
+template <bool RING>
 __global__ __launch_bounds__(64, 2) void evdw_test_kernel(const float* __restrict__ Gin, int sweeps, float* __restrict__ Qout,
                                                        float* __restrict__ diag_out, int* __restrict__ rnk_out, float* __restrict__ cs_out,
                                                        float* __restrict__ Gout, float* __restrict__ meas_out) {
@@ -892,7 +1058,8 @@ __global__ __launch_bounds__(64, 2) void evdw_test_kernel(const float* __restric
     evdw_measure(g, diag, lane, true, false, off0, offt);
     if (lane == 0) { meas_out[2 * b] = off0; meas_out[2 * b + 1] = offt; }
     evdw_identity(q, lane);
-    evdw_sweep(g, q, diag, bpiv, lane, sweeps * 32, csbuf);
+    if constexpr (RING) evdw_sweep_ring(g, q, diag, bpiv, lane, sweeps, csbuf);      // cross-only visits on the ring (image returned in ring positions)
+    else evdw_sweep(g, q, diag, bpiv, lane, sweeps * 32, csbuf);
     float cs;
     int rnk;
     evdw_finish(q, diag, lane, true, cs, rnk);
@@ -944,15 +1111,20 @@ constexpr int EVDQ_NW = 4;
 static int evdq12_lds_bytes() { return (int)((E12_SMEM_FLOATS + 2 * Coop<EVDQ_NW>::FLOATS) * sizeof(float)); }
 
 void launch_evdw12(int npairs_s, int batch, hipStream_t st, const Sched& sc, unsigned* maxoff_bits, int* nrot, const int* done, float tol,
-                   int inner_sweeps, int nb, int step, int kb, const EvdV3& v3) {
+                   int inner_sweeps, int nb, int step, int kb, const EvdV3& v3, int sweep, int ring_default) {
     // the > 64 KB dynamic-LDS opt-in is per device: one flag per device the process drives (idempotent; a race only repeats the calls)
     static bool attr_done[64] = {};
     int devid = 0;
     (void)hipGetDevice(&devid);
     if (devid < 0 || devid >= 64 || !attr_done[devid]) {
-        const hipError_t e1 = hipFuncSetAttribute((const void*)evdw12_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, evdw12_lds_bytes());
-        const hipError_t e2 = hipFuncSetAttribute((const void*)evdw12_kernel<EVDQ_NW>, hipFuncAttributeMaxDynamicSharedMemorySize, evdq12_lds_bytes());
-        if (e1 == hipSuccess && e2 == hipSuccess && devid >= 0 && devid < 64) attr_done[devid] = true;
+        bool ok = true;
+        ok = ok && hipFuncSetAttribute((const void*)evdw12_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, evdw12_lds_bytes()) == hipSuccess;
+        ok = ok && hipFuncSetAttribute((const void*)evdw12_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, evdw12_lds_bytes()) == hipSuccess;
+        ok = ok && hipFuncSetAttribute((const void*)evdw12_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, evdw12_lds_bytes()) == hipSuccess;
+        ok = ok && hipFuncSetAttribute((const void*)evdw12_kernel<EVDQ_NW, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, evdq12_lds_bytes()) == hipSuccess;
+        ok = ok && hipFuncSetAttribute((const void*)evdw12_kernel<EVDQ_NW, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, evdq12_lds_bytes()) == hipSuccess;
+        ok = ok && hipFuncSetAttribute((const void*)evdw12_kernel<EVDQ_NW, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, evdq12_lds_bytes()) == hipSuccess;
+        if (ok && devid >= 0 && devid < 64) attr_done[devid] = true;
     }
     // latency form when the launch cannot even give every CU one workgroup: four waves per solve (bit-identical results).  It needs one
     // full inner sweep per visit (the default) and the standard 32 phase pairs.  ASVD_EVDQ=0 / 1 forces the choice.
@@ -961,11 +1133,27 @@ void launch_evdw12(int npairs_s, int batch, hipStream_t st, const Sched& sc, uns
     static int traced = 0;
     if (getenv("ASVD_EVDW_TRACE") && !trace) (void)hipMalloc(&trace, 16 * 16 * sizeof(long long));
     long long* tr = traced < 3 ? trace : nullptr;
-    if (coop)
-        evdw12_kernel<EVDQ_NW><<<dim3((unsigned)npairs_s, (unsigned)batch), 128 * EVDQ_NW, evdq12_lds_bytes(), st>>>(sc, maxoff_bits, nrot, done, tol, inner_sweeps, nb,
-                                                                                                              step, kb, v3, tr);
-    else
-        evdw12_kernel<1><<<dim3((unsigned)npairs_s, (unsigned)batch), 128, evdw12_lds_bytes(), st>>>(sc, maxoff_bits, nrot, done, tol, inner_sweeps, nb, step, kb, v3, tr);
+    // cross-only visits on the ring (evdw_sweep_ring).  ring_default (the driver's choice): 2 = inner step 1 cross-only — its two panels arrive with
+    // exactly diagonal Gram blocks, step 0 has just diagonalised them, so the visit loses nothing at its start — for problems of >= 2048 columns:
+    // measured +2 % at 32 x 4096^2 (eigen-solves 108 -> 91.5 ms per step, a tiny ninth sweep for some problems), +5 % at 32 x 2048^2, -10 % on the
+    // latency of a lone 4096^2 (95.5 -> 86.3 ms); 768-column problems lose 7 % (one more sweep of 12 super-panels) and keep full visits.  Cross-only
+    // in BOTH steps (mode 1) does not converge in reasonable time: 10-11 sweeps, 8 of them dense (profiles/r5_ring.txt).
+    // Measurement knobs: ASVD_RING=0 / 1 / 2 forces the mode, ASVD_RING_FROM=k applies it from dense sweep k on.
+    const char* er = getenv("ASVD_RING");
+    const char* ef = getenv("ASVD_RING_FROM");
+    const int ring = er ? ((sweep >= (ef ? atoi(ef) : 0)) ? atoi(er) : 0) : ring_default;
+    const dim3 grid((unsigned)npairs_s, (unsigned)batch);
+#define ASVD_E12(NWV, RM, THREADS, LDS) evdw12_kernel<NWV, RM><<<grid, THREADS, LDS, st>>>(sc, maxoff_bits, nrot, done, tol, inner_sweeps, nb, step, kb, v3, tr)
+    if (coop) {
+        if (ring == 1) ASVD_E12(EVDQ_NW, 1, 128 * EVDQ_NW, evdq12_lds_bytes());
+        else if (ring == 2) ASVD_E12(EVDQ_NW, 2, 128 * EVDQ_NW, evdq12_lds_bytes());
+        else ASVD_E12(EVDQ_NW, 0, 128 * EVDQ_NW, evdq12_lds_bytes());
+    } else {
+        if (ring == 1) ASVD_E12(1, 1, 128, evdw12_lds_bytes());
+        else if (ring == 2) ASVD_E12(1, 2, 128, evdw12_lds_bytes());
+        else ASVD_E12(1, 0, 128, evdw12_lds_bytes());
+    }
+#undef ASVD_E12
     if (tr) {
         long long h[32];
         (void)hipStreamSynchronize(st);
@@ -980,7 +1168,9 @@ void launch_evdw12(int npairs_s, int batch, hipStream_t st, const Sched& sc, uns
 }
 
 void launch_evdw_test(int batch, hipStream_t st, const float* G, int sweeps, float* Q, float* diag, int* rnk, float* cs, float* Gout, float* meas) {
-    evdw_test_kernel<<<batch, 64, 0, st>>>(G, sweeps, Q, diag, rnk, cs, Gout, meas);
+    // sweeps < 0: |sweeps| cross-only visits on the ring
+    if (sweeps < 0) evdw_test_kernel<true><<<batch, 64, 0, st>>>(G, -sweeps, Q, diag, rnk, cs, Gout, meas);
+    else evdw_test_kernel<false><<<batch, 64, 0, st>>>(G, sweeps, Q, diag, rnk, cs, Gout, meas);
 }
 
 }  // namespace asvdk

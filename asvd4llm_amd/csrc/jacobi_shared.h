@@ -150,7 +150,7 @@ void launch_evdw0(bool keepg, int npairs, int batch, hipStream_t st, const Sched
                   int list_stride, const EvdV3& v3);
 // both inner steps of every super-pair of super-step `step` (the work of evd_kernel<1,1> + evd_kernel<2,1>), two waves per super-pair
 void launch_evdw12(int npairs_s, int batch, hipStream_t st, const Sched& sc, unsigned* maxoff_bits, int* nrot, const int* done, float tol,
-                   int inner_sweeps, int nb, int step, int kb, const EvdV3& v3);
+                   int inner_sweeps, int nb, int step, int kb, const EvdV3& v3, int sweep = 0, int ring_default = 0);
 int evdw12_lds_bytes();
 // test hook
 void launch_evdw_test(int batch, hipStream_t st, const float* G, int sweeps, float* Q, float* diag, int* rnk, float* cs, float* Gout, float* meas);

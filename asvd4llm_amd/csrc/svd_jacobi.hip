@@ -721,7 +721,7 @@ static int svd_direct_run(int batch, const void* const* a_host, int a_dtype, int
                 }
                 {
                     ProfScope ps(2, st);  // both inner steps of every super-pair in one launch, one wave per 64x64 solve (evd_wave.hip)
-                    launch_evdw12(p.npairs_s, batch, st, sc, maxoff, nrot, done, tol, inner_sweeps, p.nb, D - 1, kb, v3);
+                    launch_evdw12(p.npairs_s, batch, st, sc, maxoff, nrot, done, tol, inner_sweeps, p.nb, D - 1, kb, v3, sweep, p.cols >= 2048 ? 2 : 0);
                 }
                 {
                     ProfScope ps(gram_out ? 8 : 3, st);
@@ -1109,7 +1109,7 @@ int asvd_test_sg_timing(unsigned long long* out_host) {  // [2][10] per-stage sh
 // Test hook (tests/test_gpu_evd_wave.py): the wave-local 64x64 eigen-solver alone.  G: [batch][64][64] symmetric (device); outputs
 // Q [batch][64][64] (unsorted, unscaled), diag / rnk / cs [batch][64], Gout [batch][64][64] (the image the sweeps leave), meas [batch][2].
 int asvd_test_evd_wave(const float* G, int batch, int sweeps, float* Q, float* diag, int* rnk, float* cs, float* Gout, float* meas, void* stream) {
-    if (!G || !Q || !diag || !rnk || !cs || !Gout || !meas || batch < 1 || sweeps < 0) return ASVD_E_BADARG;
+    if (!G || !Q || !diag || !rnk || !cs || !Gout || !meas || batch < 1) return ASVD_E_BADARG;   // sweeps < 0: |sweeps| cross-only visits on the ring
     launch_evdw_test(batch, (hipStream_t)stream, G, sweeps, Q, diag, rnk, cs, Gout, meas);
     ASVD_HIP_CHECK(hipGetLastError());
     return ASVD_OK;

@@ -112,7 +112,8 @@ int asvd_scale_cols(const void* w, int w_dtype, int64_t m, int64_t n, int64_t ld
  * by fp64 MFMA, columns ordered by norm), then one-sided block Jacobi runs on R^T: XOR pair schedule over 32-column panels
  * (panel counts that are not a power of two: a grouped schedule — XOR inside groups of 2..16 super-panels, round-robin over
  * the groups); dense sweeps work on 64-column super-panels, TWO launches per super-step: the wave-local 64x64 eigen-solves
- * (one wave per solve, the matrix in registers, both inner steps of a super-pair) and one 128-wide update pass fused with the
+ * (one wave per solve, the matrix in registers, both inner steps of a super-pair; from 2048 columns on the second inner step visits
+ * only the cross pairs of its two panels, on a ring of interleaved positions: half the phases) and one 128-wide update pass fused with the
  * Gram tiles of the next step, in split-fp16 arithmetic (three products per fp32 product, power-of-two column scales from the
  * carried column norms; a problem that turns NaN on that path is repeated with the separate fp32 Gram / split-bf16 update
  * passes); tail sweeps rotate only the pairs a blocked X^T X snapshot marks.  Right vectors are the rotated columns, left
@@ -145,7 +146,8 @@ int asvd_scale_cols(const void* w, int w_dtype, int64_t m, int64_t n, int64_t ld
  * ASVD_TWOLEVEL=0, ASVD_SUPGRAM=0 (separate Gram / update passes), ASVD_SPARSE=0, ASVD_NO_REDUCE (skip the Cholesky-QR),
  * ASVD_EVDQ=0/1 (force the throughput / latency form of the eigen-solver), ASVD_EVDW_TRACE (stage stamps of the solver),
  * ASVD_SPREAD_FROM=<sweep> (line-spread order of the XOR distances from that dense sweep on: a measurement knob),
- * ASVD_SPLIT=0 (never split a batch over the two halves of the chip).
+ * ASVD_SPLIT=0 (never split a batch over the two halves of the chip), ASVD_RING=0/1/2 + ASVD_RING_FROM=<sweep> (cross-only ring visits of the
+ * eigen-solves: off / both inner steps / inner step 1 only — the default for >= 2048 columns is 2).
  * Returns worst status over the batch.
  */
 int asvd_svd_worksize(int batch, int64_t m, int64_t n, int want_vectors, size_t* bytes);

@@ -134,3 +134,93 @@ def test_cooperative_launch_is_bit_identical(gpu, tmp_path, n, batch):
     assert (res["0"]["status"] == 0).all() and np.array_equal(res["0"]["sweeps"], res["1"]["sweeps"])
     for k in ("S", "U", "V"):
         assert np.array_equal(res["0"][k].view(np.uint32), res["1"][k].view(np.uint32)), k
+
+
+def _ring_emulation(G, visits=1):
+    """fp64 emulation of the cross-only visit on the ring (evd_wave.hip, evdw_sweep_ring): positions interleaved (2k = column k of the first panel,
+    2k + 1 = column k of the second), phase A pairs (2k, 2k + 1), phase B pairs (2k + 1, (2k + 2) % 64), the rotated pair swaps places
+    (J = [[s, c], [c, -s]]), 16 phase pairs per visit.  Returns (Q with natural rows and position columns, diagonal per position, image in
+    ring positions, the set of natural column pairs that met)."""
+    nat = np.array([(p & 1) * 32 + (p >> 1) for p in range(64)])
+    g = G.astype(np.float64)[np.ix_(nat, nat)]
+    q = np.eye(64)
+    who = list(nat)          # natural column sitting at every position
+    met = set()
+    for _ in range(16 * visits):
+        for par in (0, 1):
+            for k in range(32):
+                p, r = (2 * k + par) % 64, (2 * k + par + 1) % 64
+                a, d, b = g[p, p], g[r, r], g[r, p]
+                met.add((min(who[p], who[r]), max(who[p], who[r])))
+                if not (abs(b) > 1e-8 * np.sqrt(a * d)):
+                    c, s = 1.0, 0.0
+                else:
+                    zeta = (d - a) / (2 * b)
+                    t = np.sign(zeta) / (abs(zeta) + np.sqrt(zeta * zeta + 1)) if zeta != 0 else 1.0
+                    c = 1 / np.sqrt(1 + t * t)
+                    s = t * c
+                M = np.array([[s, c], [c, -s]])
+                g[[p, r], :] = M @ g[[p, r], :]
+                g[:, [p, r]] = g[:, [p, r]] @ M
+                q[:, [p, r]] = q[:, [p, r]] @ M
+                who[p], who[r] = who[r], who[p]
+    pos = np.array([2 * x if x < 32 else 2 * (x - 32) + 1 for x in range(64)])
+    return q[pos, :], np.diag(g).copy(), g, met
+
+
+def test_ring_visit_meets_every_cross_pair_once_and_follows_the_fp64_emulation(gpu):
+    """the cross-only visit of the two-level sweeps (ASVD_RING): 32 phases on the ring of interleaved positions — every column of the first panel
+    meets every column of the second exactly once, no two columns of one panel meet — against its fp64 emulation (same rotations up to the
+    hardware rcp / rsq in the angles)"""
+    rng = np.random.default_rng(5)
+    G = np.stack([_gram(rng, c) for c in (1e1, 1e3, 1e5)])
+    qe, de, ge, met = _ring_emulation(G[0])
+    assert met == {(i, 32 + j) for i in range(32) for j in range(32)}     # 1024 cross pairs, nothing else
+    Q, diag, rnk, cs, Gout, meas = _run(gpu, G, sweeps=-1)
+    for b in range(G.shape[0]):
+        qe, de, ge, _ = _ring_emulation(G[b])
+        scale = float(np.abs(de).max())
+        qd = Q[b].astype(np.float64)
+        assert np.abs(qd.T @ qd - np.eye(64)).max() <= 3e-6
+        assert np.abs(diag[b] - de).max() <= 2e-4 * scale
+        assert np.abs(Q[b] - qe).max() <= 2e-3
+        # the image it leaves (ring positions) is Q^T G Q of the rotations it made, off the diagonal
+        nat = np.array([(p & 1) * 32 + (p >> 1) for p in range(64)])
+        T = qd.T @ G[b].astype(np.float64) @ qd
+        off = Gout[b].astype(np.float64) - np.diag(np.diag(Gout[b].astype(np.float64)))
+        assert np.abs(off - (T - np.diag(np.diag(T)))).max() <= 3e-5 * scale
+        assert np.abs(np.diag(T) - diag[b]).max() <= 3e-5 * scale
+        # and the visit did its job: the cross couplings shrank (the couplings inside the panels are not its business)
+        where = np.array([(nat[p] < 32) for p in range(64)])
+        cross = np.outer(where, ~where)
+        g0 = G[b].astype(np.float64)[np.ix_(nat, nat)]
+        assert np.abs(off[cross]).max() < 0.5 * np.abs((g0 - np.diag(np.diag(g0)))[cross]).max()
+
+
+@pytest.mark.parametrize("n,batch", [(768, 3), (2048, 2)])
+def test_ring_visits_whole_svd_parity_and_forms_bit_identical(gpu, tmp_path, n, batch):
+    """ASVD_RING=1: the two-level sweeps visit their sub-pairs cross-only.  The SVD must still meet the contract against LAPACK, and the wave-local and
+    the cooperative form of the ring visit must agree bit for bit (ASVD_EVDQ=0 / 1)."""
+    import subprocess
+    import sys
+    res = {}
+    for mode in ("0", "1"):
+        out = str(tmp_path / f"ring_evdq{mode}.npz")
+        env = dict(os.environ, ASVD_EVDQ=mode, ASVD_RING="1")
+        subprocess.run([sys.executable, "-c", _COOP_SNIPPET.format(root=ROOT, n=n, batch=batch, out=out)], check=True, env=env, timeout=600)
+        res[mode] = np.load(out)
+    assert (res["0"]["status"] == 0).all() and np.array_equal(res["0"]["sweeps"], res["1"]["sweeps"])
+    for k in ("S", "U", "V"):
+        assert np.array_equal(res["0"][k].view(np.uint32), res["1"][k].view(np.uint32)), k
+    g = torch.Generator().manual_seed(11)
+    mats = [(torch.randn(n, n, generator=g) / n ** 0.5) for _ in range(batch)]
+    scales = [torch.rand(n, generator=g).add_(0.5) for _ in range(batch)]
+    for b in range(batch):
+        So = torch.linalg.svdvals(mats[b] * scales[b][None, :]).numpy()
+        S = res["0"]["S"][b]
+        assert np.abs(S - So).max() <= 1e-4 * So[0] and (np.abs(S - So) / So)[: n // 2].max() <= 1e-4
+        U, V = res["0"]["U"][b].astype(np.float64), res["0"]["V"][b].astype(np.float64)
+        k = n // 2
+        assert np.abs(U[:, :k].T @ U[:, :k] - np.eye(k)).max() <= 2e-5 and np.abs(V[:, :k].T @ V[:, :k] - np.eye(k)).max() <= 2e-5
+        W = (mats[b] * scales[b][None, :]).double().numpy()
+        assert np.linalg.norm(W - (U * S[None, :]) @ V.T) <= 1e-4 * np.linalg.norm(W)
