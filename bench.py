@@ -494,7 +494,8 @@ def main():
                                           "per wave and tile), removing the panel stores is the only ablation that shortens a launch (DESIGN.md 3.10).  Clock: in this bench, "
                                           "with lighter kernels between its launches, the kernel runs at 2.2-2.3 GHz (877-881 us; the PMC passes read 2.20-2.31 GHz); launched back "
                                           "to back it holds the socket at its 1400 W cap at 1.87-1.95 GHz and takes 957-968 us (profiles/r4_supgram_micro.jsonl, r4_power.jsonl): "
-                                          "20 % of clock are worth 9 % of time",
+                                          "20 % of clock are worth 9 % of time.  Round 5 (DESIGN.md 3.11): on CU-masked streams the kernel delivers its full-chip throughput with "
+                                          "~190 of the 256 CUs and 72 % of it with 128 — it saturates the HBM path, not the CUs",
                         "note": "dominant streaming kernel by total time; bytes from the library's own counters of the profiled step, duration = HIP "
                                 "events around every launch on the launch stream, averaged over ALL its launches (one stream: nothing else runs beside it)"}
         else:
@@ -525,7 +526,7 @@ def main():
                        "split_note": "asvd_svd_batched runs a batch of >= 4 problems with >= 3072 columns as two halves on CU-masked streams (128 CUs each, one host "
                                      "thread each; DESIGN.md 3.11): the timed steps run that way.  The profiled step behind `roofline` runs UNSPLIT (a profiled call "
                                      "is never split), so `roofline.avg_launch_us` and the class times describe every kernel alone on the whole chip; ASVD_SPLIT=0 "
-                                     "runs the timed steps unsplit too (profiles/r5_bench_nosplit.json: 55.9 vs 59.2 SVD/s)"},
+                                     "runs the timed steps unsplit too (profiles/r5_bench_nosplit.json: 56.8 vs 60.5 SVD/s)"},
             "roofline": roofline,
         }
         if per_rank is not None:
