@@ -23,6 +23,9 @@
 //                           four independent pairs per workgroup;
 //           evdw12_kernel — BOTH inner steps of a super-pair in one launch (two waves: sub-pairs (0,2) (1,3), then (0,3) (1,2)); the
 //                           step-0 eigenvectors and diagonal blocks stay in LDS, the epilogue emits Qfin and the carried blocks.
+//                           Template RINGM: which inner steps visit only the 1024 CROSS pairs of their two panels, on a ring of interleaved
+//                           positions in 32 phases instead of 64 (evdw_sweep_ring; round 5).  Default from 2048 columns on: step 1 (its panels
+//                           arrive with exactly diagonal Gram blocks — step 0 has just diagonalised them — so the visit gives up nothing).
 
 #include "common.h"
 #include "jacobi_shared.h"

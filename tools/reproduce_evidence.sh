@@ -7,12 +7,18 @@
 #                                               # as roofline.traffic only when it was collected from the SAME libasvd_hip.so (sha256)
 set -u
 mkdir -p gpurun_out
-export ASVD_STRICT=1
+export ASVD_STRICT=1   # (the K10 wrapper reads its give-up word every 64th launch under STRICT since round 5: bench_aux.py is not distorted by it any more)
 python -c "import __graft_entry__ as g; g.build(); g.smoke()" 2>&1 | tail -1
 [ "${1:-all}" = prof ] || python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed" | tail -2
 [ "${1:-all}" = prof ] || { python bench.py > gpurun_out/bench.json 2> gpurun_out/bench.err && tail -c 600 gpurun_out/bench.json; }
 [ "${1:-all}" = quick ] && exit 0
-PMC_BATCH=32 bash tools/prof_final.sh repro > gpurun_out/prof_repro.log 2>&1   # rocprofv3 kernel stats + FETCH/WRITE/MFMA counter passes
+# rocprofv3 kernel stats + FETCH/WRITE/MFMA counter passes of the bench workload alone (no model leg), UNSPLIT: every kernel alone on the chip — what
+# bench.py's `roofline` quotes (its profiled step is never split); then the kernel trace of the product default (two half-batch streams): overlap factor
+BENCH_ARGS="--sharded_model none" ASVD_SPLIT=0 PMC_BATCH=32 bash tools/prof_final.sh repro > gpurun_out/prof_repro.log 2>&1
+( cd /tmp; export TMPDIR=/tmp; R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; rm -rf gpurun_out/kt_split
+  rocprofv3 --kernel-trace --stats -d gpurun_out/kt_split -- python bench.py --no_cpu_baseline --no_latency --sharded_model none --steps 3 --warmup 1 --prewarm_s 2 > /dev/null 2> gpurun_out/kt_split.log
+  DB=$(find gpurun_out/kt_split -name "*.db" | head -1)
+  python tools/rocpd_stats.py $DB | head -24 > gpurun_out/kernel_stats_split.txt; python tools/rocpd_overlap.py $DB | tail -2 >> gpurun_out/kernel_stats_split.txt; rm -rf gpurun_out/kt_split )
 for w in idle mfma supgram supgram_ni bench; do python tools/power_probe.py --workload $w --seconds 6 --out gpurun_out/power.jsonl > /dev/null 2>&1; done   # socket power / clock / cap
 python tools/bench_supgram.py > gpurun_out/supgram_micro.jsonl 2> /dev/null
 [ "${1:-all}" = prof ] && exit 0
