@@ -152,3 +152,21 @@ def test_split_batch_on_two_chip_halves_matches_the_unsplit_call(gpu, monkeypatc
     ops.svd_profile(False)
     assert prof["supgram"]["launches"] > 0
     assert all(torch.equal(a, b) for a, b in zip(S3, S0))
+
+
+@pytest.mark.timeout(600)
+def test_split_batch_with_an_odd_number_of_problems(gpu, monkeypatch):
+    """5 problems = halves of 3 and 2 (the info blocks, outputs and workspace slices of the second half start behind the first's)"""
+    from asvd4llm_amd import ops
+    n = 3072
+    mats = _problems(gpu, 5, n, n, seed=91)
+    monkeypatch.setenv("ASVD_SPLIT", "0")
+    _, S0, _, i0 = ops.svd_batched(mats, k=256, want_vectors=False)
+    monkeypatch.setenv("ASVD_SPLIT", "1")
+    U1, S1, V1, i1 = ops.svd_batched(mats, k=256)
+    assert all(i.status == 0 and 0 < i.sweeps <= 12 for i in i0 + i1)
+    for b in range(5):
+        assert ((S1[b].double() - S0[b].double()).abs() / S0[b].double()).max().item() <= 2e-5
+        W = mats[b].double()
+        r = (W @ V1[b].double() - U1[b].double() * S1[b].double()[None, :]).norm() / S1[b].double().norm()     # triplet residual |W V - U S|
+        assert r.item() <= 2e-5, (b, r.item())
