@@ -172,3 +172,26 @@ def test_bench_two_ranks_on_one_gpu_run_the_whole_multi_gpu_leg(tmp_path):
     assert sm["collective_world_size"] == 2 and sm["plan_identical_on_all_ranks"]
     assert sm["gather_factors_s"] > 0 and sm["gather_factors_bytes_into_rank0"] > 1e6     # rank 1's factors reached rank 0
     assert sm["decompose_s"] > 0 and sm["load_flops_max_over_mean"] < 1.3
+
+
+@pytest.mark.timeout(900)
+def test_bench_watchdog_keeps_the_line_when_the_sharded_leg_does_not_come_back(tmp_path):
+    """N > 1: the untimed sharded-model leg runs collectives that may never have run on the node; if it does not finish within --sharded_timeout_s the
+    bench line — complete before the leg starts — is printed by rank 0 with the reason, every rank ends with exit code 0 (here: a timeout far
+    below the leg's run time)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from tests.conftest import ROOT
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist_backend", "gloo", "--same_gpu", "--batch", "4", "--steps", "1", "--warmup", "0",
+           "--prewarm_s", "0", "--sharded_model", "llama-7b-2layers", "--sharded_timeout_s", "0.05"]
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=800, env=env, cwd=str(tmp_path))
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and len(d["per_rank_svds_per_s"]) == 2
+    assert "did not finish" in d["sharded_model"]["error"]
