@@ -11,6 +11,7 @@ LIB_PATH = os.environ.get("ASVD_HIP_LIB") or os.path.join(_HERE, "libasvd_hip.so
 F32, F16, BF16 = 0, 1, 2
 FUSE = {"UV": 0, "U": 1, "V": 2}
 STAT_ABS_MEAN, STAT_ABS_MAX, STAT_SQ_MEAN = 0, 1, 2
+PATH_REDUCED, PATH_REDUCE_FALLBACK, PATH_PLAIN_RETRY, PATH_SPLIT, PATH_SPLIT_REFUSED = 1, 2, 4, 8, 16
 OK, E_BADARG, E_WORKSPACE, E_HIP, E_NODEVICE, N_NOCONV, N_NAN = 0, -1, -2, -3, -4, 1, 2
 
 _c = ctypes
@@ -52,8 +53,11 @@ SIGNATURES = {
     "asvd_test_supgram": (_i, [_vp, _i64, _i64, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "asvd_test_super_schedule": (_i, [_i, _i, _vp, _i, _c.POINTER(_i), _c.POINTER(_i)]),
     "asvd_test_evd_wave": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "asvd_svd_get_last_path": (_i, []),
     "asvd_svd_set_profiling": (None, [_i]),
     "asvd_svd_set_call_cus": (None, [_i]),
+    "asvd_svd_set_split": (None, [_i]),
+    "asvd_svd_get_split_profile": (_i, [_c.POINTER(_f), _c.POINTER(_i), _c.POINTER(_f)]),
     "asvd_svd_get_profile": (_i, [_c.POINTER(_f), _c.POINTER(_i)]),
     "asvd_svd_get_pair_counts": (_i, [_c.POINTER(_c.c_longlong)]),
     "asvd_svd_get_sweep_times": (_i, [_c.POINTER(_f), _c.POINTER(_c.c_longlong), _i]),

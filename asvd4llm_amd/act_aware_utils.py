@@ -65,7 +65,7 @@ def _allreduce_statistics(model, method):
         if not torch.is_tensor(m.scaling_diag_matrix):
             m.scaling_diag_matrix = torch.zeros(m.in_features, dtype=m.weight.dtype, device=m.weight.device)
     flat = torch.cat([m.scaling_diag_matrix.float().reshape(-1) for m in mods]).to(dev)
-    dist.all_reduce(flat, op=dist.ReduceOp.MAX if "abs_max" in method else dist.ReduceOp.SUM)
+    dist.all_reduce(flat, op=dist.ReduceOp.MAX if "abs_max" in method else dist.ReduceOp.SUM, group=parallel.GROUP)
     off = 0
     for m in mods:
         n = m.scaling_diag_matrix.numel()

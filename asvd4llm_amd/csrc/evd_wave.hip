@@ -1089,7 +1089,7 @@ void launch_evdw0(bool keepg, int npairs, int batch, hipStream_t st, const Sched
                   unsigned* maxoff_bits, int* nrot, const int* done, float tol, int inner_sweeps, int nb, int step, int kb, const int* plist,
                   int list_stride, const EvdV3& v3) {
     // latency form (one pair per workgroup, four waves per solve; bit-identical) when the pairs of the launch would leave most SIMDs idle
-    const bool coop = inner_sweeps == 1 && (evdq_env() == 1 || (evdq_env() != 0 && (long long)npairs * batch <= 2 * (g_call_cus > 0 ? g_call_cus : 256)));
+    const bool coop = inner_sweeps == 1 && (evdq_env() == 1 || (evdq_env() != 0 && (long long)npairs * batch <= 2 * call_cus_now()));
     if (coop) {
         const dim3 grid((unsigned)npairs, (unsigned)batch);
         if (keepg)
@@ -1131,7 +1131,7 @@ void launch_evdw12(int npairs_s, int batch, hipStream_t st, const Sched& sc, uns
     }
     // latency form when the launch cannot even give every CU one workgroup: four waves per solve (bit-identical results).  It needs one
     // full inner sweep per visit (the default) and the standard 32 phase pairs.  ASVD_EVDQ=0 / 1 forces the choice.
-    const bool coop = inner_sweeps == 1 && (evdq_env() == 1 || (evdq_env() != 0 && (long long)npairs_s * batch <= (g_call_cus > 0 ? g_call_cus : 256)));
+    const bool coop = inner_sweeps == 1 && (evdq_env() == 1 || (evdq_env() != 0 && (long long)npairs_s * batch <= call_cus_now()));
     static long long* trace = nullptr;
     static int traced = 0;
     if (getenv("ASVD_EVDW_TRACE") && !trace) (void)hipMalloc(&trace, 16 * 16 * sizeof(long long));

@@ -142,6 +142,8 @@ struct EvdV3 {
 // CUs the current call may use (0 = the whole device, 256): set by asvd_svd_batched per host thread when it runs a batch as two halves on
 // CU-masked streams; the launch-form switches of the eigen-solver follow it
 extern thread_local int g_call_cus;
+int device_cus();     // CUs of the current device (256 when none is visible)
+int call_cus_now();   // g_call_cus, or device_cus() when the call owns the whole device
 
 // ---- launchers of the wave-local eigen-solver (evd_wave.hip) -------------------------------------------------------------------
 // single-level solves: the work of evd_kernel<0, KEEPG> (grid: npairs x batch), one wave per pair

@@ -26,9 +26,29 @@
 #include <type_traits>
 #include <thread>
 #include <mutex>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <memory>
+#include <fcntl.h>
+#include <unistd.h>
 
 namespace asvdk {
 thread_local int g_call_cus = 0;   // see call_cus(): set per host thread for the duration of a half-batch call (0: the whole device)
+// CUs of the current device (hipDeviceAttributeMultiprocessorCount, cached per device).  256 — the MI355X — when no device is visible: the
+// host-side size queries (asvd_svd_worksize) answer on a CPU-only box too.
+int device_cus() {
+    static std::atomic<int> cache[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    const int c = cache[dev].load(std::memory_order_relaxed);
+    if (c > 0) return c;
+    int ncu = 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) return 256;
+    cache[dev].store(ncu, std::memory_order_relaxed);
+    return ncu;
+}
+int call_cus_now() { return g_call_cus > 0 ? g_call_cus : device_cus(); }
 }
 namespace {
 using namespace asvdk;
@@ -59,9 +79,9 @@ struct Plan {
     size_t off_x, off_xorig, off_gpart, off_q, off_active, off_sig, off_ina, off_inv, off_perm, off_flags, off_pflag, off_plist, total;
 };
 
-// CUs the launches of the current call may use: 256 (the device), or the 128 of one half when asvd_svd_batched runs a batch as two halves on
-// CU-masked streams (below).  The launch geometry of a plan (row splits, chunk counts) is sized for this many.
-static int64_t call_cus() { return g_call_cus > 0 ? g_call_cus : 256; }
+// CUs the launches of the current call may use: those of the device (256 on the MI355X), or those of one half when asvd_svd_batched runs a batch
+// as two halves on CU-masked streams (below).  The launch geometry of a plan (row splits, chunk counts) is sized for this many.
+static int64_t call_cus() { return call_cus_now(); }
 
 int make_plan(int batch, int64_t m, int64_t n, int want_u, int want_vv, Plan& p) {
     if (batch < 1 || m < 1 || n < 1 || m > (1 << 24) || n > (1 << 24)) return ASVD_E_BADARG;
@@ -241,6 +261,7 @@ static bool super_grouped_for(const Plan& p) {
 // ---- optional per-class timing with HIP events on the call's stream ------------------------------
 // profiling state is per host thread: concurrent calls from different threads (on their own streams and workspaces) do not share it
 thread_local bool g_prof_enabled = false;
+thread_local int g_prof_mode = 0;   // asvd_svd_set_profiling: 0 off, 1 profile (the call runs UNSPLIT: every kernel alone on the chip), 2 profile and keep the split
 // classes: 0 pack / reduce, 1 two-level Gram pass, 2 eigen-solves, 3 two-level update pass, 4 finalize, 5 coupling snapshot,
 //          6 single-level Gram, 7 single-level update
 constexpr int NPROF = 9;
@@ -251,6 +272,17 @@ thread_local std::vector<float> g_prof_sweep_ms;       // wall time of every swe
 thread_local std::vector<long long> g_prof_sweep_rot;  // pairs rotated in it  // {pair visits (gram), rotated pairs (evd + update)} of the last profiled call
 struct ProfRec { int cls; hipEvent_t a, b; };
 thread_local std::vector<ProfRec> g_prof_recs;
+// split-mode profile (mode 2): both halves time their own launches with events on their own stream; `g_prof_base` is an event recorded on the
+// caller's stream before the halves start, so that the [start, end] of every fused update + Gram launch (class 8) of both halves can be placed
+// on ONE time axis — the union / overlap of the two halves' HBM-bound launches is what the combined streaming rate of a split step follows from
+thread_local hipEvent_t g_prof_base = nullptr;
+thread_local std::vector<std::pair<float, float>> g_prof_iv8;
+thread_local bool g_prof_last_split = false;
+thread_local float g_prof_half_ms[2][9] = {{0}};
+thread_local int g_prof_half_launches[2][9] = {{0}};
+thread_local float g_prof_overlap[4] = {0, 0, 0, 0};   // class 8: summed ms of half 0, of half 1, union of both, time BOTH were in it
+// which path the last asvd_svd_batched call of this host thread took (asvd_svd_get_last_path): ASVD_PATH_* bits of include/asvd_hip.h
+thread_local int g_last_path = 0;
 
 struct ProfScope {
     int cls; hipStream_t st; hipEvent_t a = nullptr, b = nullptr; bool on;
@@ -267,6 +299,7 @@ void prof_begin() {
     g_prof_sweep_ms.clear();
     g_prof_sweep_rot.clear();
     g_prof_recs.clear();
+    g_prof_iv8.clear();
 }
 void prof_end() {
     for (auto& r : g_prof_recs) {
@@ -275,6 +308,10 @@ void prof_end() {
         (void)hipEventElapsedTime(&ms, r.a, r.b);
         g_prof_ms[r.cls] += ms;
         g_prof_launches[r.cls] += 1;
+        if (r.cls == 8 && g_prof_base) {
+            float t0 = 0;
+            if (hipEventElapsedTime(&t0, g_prof_base, r.a) == hipSuccess) g_prof_iv8.emplace_back(t0, t0 + ms);
+        }
         (void)hipEventDestroy(r.a);
         (void)hipEventDestroy(r.b);
     }
@@ -298,7 +335,14 @@ int launch_pack(const void* src, int64_t ld, const void* s, int cs_dtype, const 
 
 extern "C" {
 
-void asvd_svd_set_profiling(int enabled) { g_prof_enabled = enabled != 0; }
+void asvd_svd_set_profiling(int enabled) { g_prof_enabled = enabled != 0; g_prof_mode = enabled < 0 ? 0 : (enabled > 2 ? 1 : enabled); }
+int asvd_svd_get_split_profile(float* ms_host, int* launches_host, float* overlap_host) {
+    if (!ms_host || !launches_host || !overlap_host) return ASVD_E_BADARG;
+    for (int h = 0; h < 2; ++h)
+        for (int i = 0; i < NPROF; ++i) { ms_host[h * NPROF + i] = g_prof_half_ms[h][i]; launches_host[h * NPROF + i] = g_prof_half_launches[h][i]; }
+    for (int i = 0; i < 4; ++i) overlap_host[i] = g_prof_overlap[i];
+    return g_prof_last_split ? 1 : 0;
+}
 // CUs the calls of THIS host thread may use (0 = the whole device): a caller that runs asvd_svd_batched on a CU-masked stream of its own says so
 // here, so that the launch geometry (row splits, chunk counts, launch forms) is sized for those CUs; such calls are never split again.
 void asvd_svd_set_call_cus(int cus) { g_call_cus = cus > 0 ? cus : 0; }
@@ -310,6 +354,8 @@ int asvd_svd_get_sweep_times(float* ms_host, long long* rotated_host, int cap) {
     }
     return n;
 }
+
+int asvd_svd_get_last_path(void) { return g_last_path; }
 
 int asvd_svd_get_pair_counts(long long* counts_host) {
     if (!counts_host) return ASVD_E_BADARG;
@@ -355,36 +401,135 @@ static int worksize_one(int batch, int64_t m, int64_t n, int want_vectors, size_
 // >= 3072 columns are split unless ASVD_SPLIT=0; a profiled call (asvd_svd_set_profiling) runs unsplit, so that the per-class
 // durations describe each kernel alone on the chip.  The halves are ordinary calls with disjoint workspaces and outputs (the
 // concurrency contract of the library), sized for 128 CUs; results are those of two half-batch calls.
-struct SplitStreams { hipStream_t s[2] = {nullptr, nullptr}; int cus = 0; bool tried = false, ok = false; };
-static SplitStreams g_split_streams[64];
+// What the split owns (include/asvd_hip.h, "Ownership"): per CALLING HOST THREAD and device, created at that thread's first split call and
+// released when the thread ends — two CU-masked streams and ONE worker thread (the second half runs on it; the first half on the calling
+// thread).  Per thread, not per process: two host threads that make split calls at the same time each have their own pair of streams, so their
+// calls stay independent and — what tests/test_gpu_concurrency.py holds the library to — whether a call is split never depends on timing.
+struct SplitCtx {
+    hipStream_t s[2] = {nullptr, nullptr};
+    int dev = -1;
+    int cus = 0;            // CUs of one half
+    bool ok = false;
+    std::mutex m;
+    std::condition_variable cv;
+    std::function<void()> job;
+    bool has_job = false, job_done = false, stop = false;
+    std::thread worker;
+    ~SplitCtx() {
+        if (worker.joinable()) {
+            { std::lock_guard<std::mutex> lk(m); stop = true; }
+            cv.notify_all();
+            worker.join();
+        }
+        for (int h = 0; h < 2; ++h)
+            if (s[h]) (void)hipStreamDestroy(s[h]);
+    }
+};
+struct SplitTls { std::vector<std::unique_ptr<SplitCtx>> v; };
+static thread_local SplitTls g_split_tls;
 static std::mutex g_split_mutex;
+static std::atomic<int> g_split_mode{-1};   // asvd_svd_set_split: -1 environment / automatic, 0 never, 1 automatic
 
-static SplitStreams* split_streams() {
+static void split_worker(SplitCtx* c) {
+    (void)hipSetDevice(c->dev);
+    std::unique_lock<std::mutex> lk(c->m);
+    for (;;) {
+        c->cv.wait(lk, [&] { return c->has_job || c->stop; });
+        if (c->stop) return;
+        std::function<void()> job = std::move(c->job);
+        c->has_job = false;
+        lk.unlock();
+        try { job(); } catch (...) {}   // the job reports through the variables it captured; nothing may cross the thread boundary
+        lk.lock();
+        c->job_done = true;
+        c->cv.notify_all();
+    }
+}
+
+static SplitCtx* split_ctx() {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    std::lock_guard<std::mutex> lk(g_split_mutex);
-    SplitStreams& ss = g_split_streams[dev];
-    if (!ss.tried) {
-        ss.tried = true;
-        int ncu = 0;
-        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 64 || (ncu & 1)) return nullptr;
-        const int words = (ncu + 31) / 32;
-        bool ok = true;
-        for (int h = 0; h < 2 && ok; ++h) {
-            std::vector<uint32_t> mask((size_t)words, 0u);
-            for (int c = h * (ncu / 2); c < (h + 1) * (ncu / 2); ++c) mask[c >> 5] |= 1u << (c & 31);
-            ok = hipExtStreamCreateWithCUMask(&ss.s[h], (uint32_t)words, mask.data()) == hipSuccess;
-        }
-        ss.ok = ok;
-        ss.cus = ncu / 2;
+    for (auto& c : g_split_tls.v)
+        if (c->dev == dev) return c->ok ? c.get() : nullptr;
+    g_split_tls.v.emplace_back(new SplitCtx());
+    SplitCtx* c = g_split_tls.v.back().get();
+    c->dev = dev;
+    const int ncu = device_cus();
+    if (ncu < 64 || (ncu & 1)) return nullptr;
+    const int words = (ncu + 31) / 32;
+    bool ok = true;
+    for (int h = 0; h < 2 && ok; ++h) {
+        std::vector<uint32_t> mask((size_t)words, 0u);
+        for (int cu = h * (ncu / 2); cu < (h + 1) * (ncu / 2); ++cu) mask[cu >> 5] |= 1u << (cu & 31);
+        ok = hipExtStreamCreateWithCUMask(&c->s[h], (uint32_t)words, mask.data()) == hipSuccess;
     }
-    return ss.ok ? &ss : nullptr;
+    c->cus = ncu / 2;
+    if (ok) {
+        try { c->worker = std::thread(split_worker, c); } catch (...) { ok = false; }
+    }
+    c->ok = ok;
+    return ok ? c : nullptr;
+}
+
+// Presence of this process on a device: one byte of /dev/shm/asvd_hip_split.<pci bus id>, taken as a POSIX record lock at the first
+// asvd_svd_batched call on that device (the lock is gone when the process exits, however it exits; the descriptor stays open for the life of the
+// process).  F_GETLK reports only locks of OTHER processes: that is how two ranks on one GPU (`--same_gpu`) see each other — both would otherwise
+// claim "the first half + the second half" of the CUs and oversubscribe every one of them.
+static int g_presence_fd[64];
+static std::atomic<int> g_presence_state[64];   // 0 not tried, 1 registered, 2 unavailable (no /dev/shm, no bus id): treated as alone
+static void presence_register(int dev) {
+    if (dev < 0 || dev >= 64 || g_presence_state[dev].load(std::memory_order_acquire) != 0) return;
+    std::lock_guard<std::mutex> lk(g_split_mutex);
+    if (g_presence_state[dev].load(std::memory_order_relaxed) != 0) return;
+    int state = 2;
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus) - 1, dev) == hipSuccess) {
+        for (char* q = bus; *q; ++q) if (*q == ':' || *q == '/') *q = '_';
+        char path[128];
+        snprintf(path, sizeof(path), "/dev/shm/asvd_hip_split.%s", bus);
+        const int fd = open(path, O_CREAT | O_RDWR | O_CLOEXEC, 0666);
+        if (fd >= 0) {
+            bool mine = false;
+            for (int slot = 0; slot < 256 && !mine; ++slot) {
+                struct flock fl {};
+                fl.l_type = F_WRLCK; fl.l_whence = SEEK_SET; fl.l_start = slot; fl.l_len = 1;
+                mine = fcntl(fd, F_SETLK, &fl) == 0;
+            }
+            if (mine) { g_presence_fd[dev] = fd; state = 1; } else close(fd);
+        }
+    } else (void)hipGetLastError();
+    g_presence_state[dev].store(state, std::memory_order_release);
+}
+static bool split_device_shared(int dev) {
+    if (dev < 0 || dev >= 64 || g_presence_state[dev].load(std::memory_order_acquire) != 1) return false;
+    struct flock fl {};
+    fl.l_type = F_WRLCK; fl.l_whence = SEEK_SET; fl.l_start = 0; fl.l_len = 256;
+    if (fcntl(g_presence_fd[dev], F_GETLK, &fl) != 0) return false;
+    return fl.l_type != F_UNLCK;
+}
+
+// a caller whose own stream is already restricted to a subset of the CUs has partitioned the chip itself: its calls are not split again
+static bool stream_is_cu_masked(hipStream_t st) {
+    const int ncu = device_cus();
+    uint32_t mask[16] = {0};
+    const int words = std::min(16, (ncu + 31) / 32);
+    if (hipExtStreamGetCUMask(st, (uint32_t)words, mask) != hipSuccess) { (void)hipGetLastError(); return false; }
+    int bits = 0;
+    for (int w = 0; w < words; ++w) bits += __builtin_popcount(mask[w]);
+    return bits > 0 && bits < ncu;
 }
 
 static bool split_applies(int batch, int64_t m, int64_t n) {
-    const char* e = getenv("ASVD_SPLIT");   // read per call: tests and A/B runs toggle it inside one process
-    return !(e && atoi(e) == 0) && batch >= 4 && std::min(m, n) >= 3072;   // measured: 4 x 4096^2 -3 %, 8: -8 %, 12: -6 %, 16: -9 %, 32: -6 %; 2048 columns: nothing
+    const int mode = g_split_mode.load(std::memory_order_relaxed);
+    if (mode == 0) return false;
+    if (mode < 0) {
+        const char* e = getenv("ASVD_SPLIT");   // read per call: tests and A/B runs toggle it inside one process
+        if (e && atoi(e) == 0) return false;
+    }
+    return batch >= 4 && std::min(m, n) >= 3072;   // measured: 4 x 4096^2 -3 %, 8: -8 %, 12: -6 %, 16: -9 %, 32: -6 %; 2048 columns: nothing
 }
+
+void asvd_svd_set_split(int mode) { g_split_mode.store(mode < 0 ? -1 : (mode ? 1 : 0), std::memory_order_relaxed); }
 
 int asvd_svd_worksize(int batch, int64_t m, int64_t n, int want_vectors, size_t* bytes) {
     if (!bytes) return ASVD_E_BADARG;
@@ -393,7 +538,7 @@ int asvd_svd_worksize(int batch, int64_t m, int64_t n, int want_vectors, size_t*
     if (rc) return rc;
     if (split_applies(batch, m, n)) {   // room for the two halves, each planned for half of the CUs
         const int saved = g_call_cus;
-        g_call_cus = 128;
+        g_call_cus = std::max(1, device_cus() / 2);
         size_t h0 = 0, h1 = 0;
         rc = worksize_one((batch + 1) / 2, m, n, want_vectors, &h0);
         if (!rc) rc = worksize_one(batch / 2, m, n, want_vectors, &h1);
@@ -850,6 +995,7 @@ static int svd_direct(int batch, const void* const* a_host, int a_dtype, int64_t
     bool retry = false;
     int rc = svd_direct_run(batch, a_host, a_dtype, m, n, lda, cs_host, cs_dtype, U_host, S_host, V_host, k, max_sweeps, tol, work, work_bytes, info_host,
                             stream, manage_profile, true, &retry);
+    if (rc >= 0 && retry) g_last_path |= ASVD_PATH_PLAIN_RETRY;
     if (rc >= 0 && retry)
         rc = svd_direct_run(batch, a_host, a_dtype, m, n, lda, cs_host, cs_dtype, U_host, S_host, V_host, k, max_sweeps, tol, work, work_bytes, info_host,
                             stream, manage_profile, false, nullptr);
@@ -1124,9 +1270,12 @@ static int svd_batched_one(int batch, const void* const* a_host, int a_dtype, in
     if (rc) return rc;
     if (g_prof_enabled) prof_begin();
     rc = -100;
-    if (tall_wanted(p))
+    g_last_path = 0;
+    if (tall_wanted(p)) {
         rc = svd_tall(batch, a_host, a_dtype, m, n, lda, cs_host, cs_dtype, U_host, S_host, V_host, k, max_sweeps, tol, work, work_bytes,
                       info_host, stream);
+        g_last_path |= (rc == -100) ? ASVD_PATH_REDUCE_FALLBACK : ASVD_PATH_REDUCED;
+    }
     if (rc == -100)
         rc = svd_direct(batch, a_host, a_dtype, m, n, lda, cs_host, cs_dtype, U_host, S_host, V_host, k, max_sweeps, tol, work, work_bytes,
                         info_host, stream, false);
@@ -1134,19 +1283,24 @@ static int svd_batched_one(int batch, const void* const* a_host, int a_dtype, in
     return rc;
 }
 
-int asvd_svd_batched(int batch, const void* const* a_host, int a_dtype, int64_t m, int64_t n, int64_t lda,
-                     const void* const* cs_host, int cs_dtype, float* const* U_host, float* const* S_host,
-                     float* const* V_host, int64_t k, int max_sweeps, float tol, void* work, size_t work_bytes,
-                     int* info_host, void* stream) {
+static int svd_batched_entry(int batch, const void* const* a_host, int a_dtype, int64_t m, int64_t n, int64_t lda,
+                             const void* const* cs_host, int cs_dtype, float* const* U_host, float* const* S_host,
+                             float* const* V_host, int64_t k, int max_sweeps, float tol, void* work, size_t work_bytes,
+                             int* info_host, void* stream) {
     if (!a_host || !S_host || !work || !dtype_ok(a_dtype) || lda < n) return ASVD_E_BADARG;
     if (cs_host && !dtype_ok(cs_dtype)) return ASVD_E_BADARG;
     if (batch < 1 || m < 1 || n < 1) return ASVD_E_BADARG;
     if (k < 1 || k > std::min(m, n)) return ASVD_E_BADARG;
     for (int b = 0; b < batch; ++b)
         if (!a_host[b] || !S_host[b]) return ASVD_E_BADARG;
-    // two halves on disjoint halves of the chip (see split_streams above)
-    if (split_applies(batch, m, n) && !g_prof_enabled && g_call_cus == 0) {
-        SplitStreams* ss = split_streams();
+    {
+        int dev0 = 0;
+        if (hipGetDevice(&dev0) == hipSuccess) presence_register(dev0);
+    }
+    // two halves on disjoint halves of the chip (see SplitCtx above)
+    g_prof_last_split = false;
+    if (split_applies(batch, m, n) && (!g_prof_enabled || g_prof_mode == 2) && g_call_cus == 0) {
+        SplitCtx* ss = split_ctx();
         const int want_vectors = (U_host || V_host) ? 1 : 0;
         const int nb0 = (batch + 1) / 2, nb1 = batch / 2;
         size_t h0 = 0, h1 = 0;
@@ -1158,40 +1312,118 @@ int asvd_svd_batched(int batch, const void* const* a_host, int a_dtype, int64_t 
             g_call_cus = 0;
         }
         const size_t off1 = (h0 + 255) & ~(size_t)255;
+        bool refused = !ss;
         if (ss && !rcw && work_bytes >= off1 + h1) {
+            // not when another process computes on this device, not on a caller's CU-masked stream: such a call runs as ONE call on the caller's stream
             int dev = 0;
             ASVD_HIP_CHECK(hipGetDevice(&dev));
-            // everything the caller queued on its stream (weights, scale vectors) is visible to both halves
-            hipEvent_t ev;
-            ASVD_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-            ASVD_HIP_CHECK(hipEventRecord(ev, (hipStream_t)stream));
-            ASVD_HIP_CHECK(hipStreamWaitEvent(ss->s[0], ev, 0));
-            ASVD_HIP_CHECK(hipStreamWaitEvent(ss->s[1], ev, 0));
-            const int cus = ss->cus;
-            int rc1 = ASVD_OK;
-            std::thread t1([&]() {
-                if (hipSetDevice(dev) != hipSuccess) { rc1 = ASVD_E_HIP; return; }
+            if (split_device_shared(dev) || stream_is_cu_masked((hipStream_t)stream)) refused = true;
+            else {
+                const bool prof = g_prof_enabled;
+                // everything the caller queued on its stream (weights, scale vectors) is visible to both halves
+                hipEvent_t ev;
+                ASVD_HIP_CHECK(hipEventCreateWithFlags(&ev, prof ? hipEventDefault : hipEventDisableTiming));
+                ASVD_HIP_CHECK(hipEventRecord(ev, (hipStream_t)stream));
+                ASVD_HIP_CHECK(hipStreamWaitEvent(ss->s[0], ev, 0));
+                ASVD_HIP_CHECK(hipStreamWaitEvent(ss->s[1], ev, 0));
+                const int cus = ss->cus;
+                int rc1 = ASVD_E_HIP, path1 = 0;
+                float ms1[NPROF] = {0};
+                int ln1[NPROF] = {0};
+                long long pairs1[3] = {0, 0, 0};
+                std::vector<std::pair<float, float>> iv1;
+                {
+                    std::lock_guard<std::mutex> lk(ss->m);
+                    ss->job = [&]() {
+                        g_call_cus = cus;
+                        g_prof_enabled = prof;
+                        g_prof_base = prof ? ev : nullptr;
+                        try {
+                            rc1 = svd_batched_one(nb1, a_host + nb0, a_dtype, m, n, lda, cs_host ? cs_host + nb0 : nullptr, cs_dtype, U_host ? U_host + nb0 : nullptr,
+                                                  S_host + nb0, V_host ? V_host + nb0 : nullptr, k, max_sweeps, tol, (char*)work + off1, h1,
+                                                  info_host ? info_host + 4 * nb0 : nullptr, (void*)ss->s[1]);
+                        } catch (...) { rc1 = ASVD_E_HIP; }
+                        path1 = g_last_path;
+                        if (prof) {
+                            for (int i = 0; i < NPROF; ++i) { ms1[i] = g_prof_ms[i]; ln1[i] = g_prof_launches[i]; }
+                            for (int i = 0; i < 3; ++i) pairs1[i] = g_prof_pairs[i];
+                            iv1.swap(g_prof_iv8);
+                        }
+                        g_call_cus = 0;
+                        g_prof_enabled = false;
+                        g_prof_base = nullptr;
+                    };
+                    ss->has_job = true;
+                    ss->job_done = false;
+                }
+                ss->cv.notify_all();
+                int rc0 = ASVD_E_HIP;
                 g_call_cus = cus;
-                rc1 = svd_batched_one(nb1, a_host + nb0, a_dtype, m, n, lda, cs_host ? cs_host + nb0 : nullptr, cs_dtype, U_host ? U_host + nb0 : nullptr,
-                                      S_host + nb0, V_host ? V_host + nb0 : nullptr, k, max_sweeps, tol, (char*)work + off1, h1,
-                                      info_host ? info_host + 4 * nb0 : nullptr, (void*)ss->s[1]);
+                g_prof_base = prof ? ev : nullptr;
+                try {
+                    rc0 = svd_batched_one(nb0, a_host, a_dtype, m, n, lda, cs_host, cs_dtype, U_host, S_host, V_host, k, max_sweeps, tol, work, h0, info_host,
+                                          (void*)ss->s[0]);
+                } catch (...) { rc0 = ASVD_E_HIP; }
                 g_call_cus = 0;
-            });
-            g_call_cus = cus;
-            const int rc0 = svd_batched_one(nb0, a_host, a_dtype, m, n, lda, cs_host, cs_dtype, U_host, S_host, V_host, k, max_sweeps, tol, work, h0,
-                                            info_host, (void*)ss->s[0]);
-            g_call_cus = 0;
-            t1.join();
-            (void)hipStreamSynchronize(ss->s[0]);
-            (void)hipStreamSynchronize(ss->s[1]);
-            (void)hipEventDestroy(ev);
-            if (rc0 < 0) return rc0;
-            if (rc1 < 0) return rc1;
-            return std::max(rc0, rc1);
+                g_prof_base = nullptr;
+                {
+                    std::unique_lock<std::mutex> lk(ss->m);
+                    ss->cv.wait(lk, [&] { return ss->job_done; });
+                }
+                g_last_path |= path1 | ASVD_PATH_SPLIT;
+                (void)hipStreamSynchronize(ss->s[0]);
+                (void)hipStreamSynchronize(ss->s[1]);
+                if (prof) {
+                    g_prof_last_split = true;
+                    for (int i = 0; i < NPROF; ++i) {
+                        g_prof_half_ms[0][i] = g_prof_ms[i]; g_prof_half_launches[0][i] = g_prof_launches[i];
+                        g_prof_half_ms[1][i] = ms1[i]; g_prof_half_launches[1][i] = ln1[i];
+                        g_prof_ms[i] += ms1[i]; g_prof_launches[i] += ln1[i];
+                    }
+                    for (int i = 0; i < 3; ++i) g_prof_pairs[i] += pairs1[i];
+                    // class 8 of both halves on one time axis: summed durations, union, and the time both halves were inside such a launch
+                    std::vector<std::pair<float, int>> edges;
+                    float sum0 = 0, sum1 = 0;
+                    for (auto& iv : g_prof_iv8) { edges.emplace_back(iv.first, +1); edges.emplace_back(iv.second, -1); sum0 += iv.second - iv.first; }
+                    for (auto& iv : iv1) { edges.emplace_back(iv.first, +1); edges.emplace_back(iv.second, -1); sum1 += iv.second - iv.first; }
+                    std::sort(edges.begin(), edges.end());
+                    float uni = 0, both = 0, last = 0;
+                    int depth = 0;
+                    for (auto& e : edges) {
+                        if (depth >= 1) uni += e.first - last;
+                        if (depth >= 2) both += e.first - last;
+                        last = e.first;
+                        depth += e.second;
+                    }
+                    g_prof_overlap[0] = sum0; g_prof_overlap[1] = sum1; g_prof_overlap[2] = uni; g_prof_overlap[3] = both;
+                }
+                (void)hipEventDestroy(ev);
+                if (rc0 < 0) return rc0;
+                if (rc1 < 0) return rc1;
+                return std::max(rc0, rc1);
+            }
+        }
+        if (refused) {
+            const int rcu = svd_batched_one(batch, a_host, a_dtype, m, n, lda, cs_host, cs_dtype, U_host, S_host, V_host, k, max_sweeps, tol, work, work_bytes,
+                                            info_host, stream);
+            g_last_path |= ASVD_PATH_SPLIT_REFUSED;
+            return rcu;
         }
     }
     return svd_batched_one(batch, a_host, a_dtype, m, n, lda, cs_host, cs_dtype, U_host, S_host, V_host, k, max_sweeps, tol, work, work_bytes, info_host,
                            stream);
+}
+
+int asvd_svd_batched(int batch, const void* const* a_host, int a_dtype, int64_t m, int64_t n, int64_t lda,
+                     const void* const* cs_host, int cs_dtype, float* const* U_host, float* const* S_host,
+                     float* const* V_host, int64_t k, int max_sweeps, float tol, void* work, size_t work_bytes,
+                     int* info_host, void* stream) {
+    try {   // the host driver allocates (std::vector): nothing may be thrown across the C boundary
+        return svd_batched_entry(batch, a_host, a_dtype, m, n, lda, cs_host, cs_dtype, U_host, S_host, V_host, k, max_sweeps, tol, work, work_bytes, info_host,
+                                 stream);
+    } catch (...) {
+        return ASVD_E_HIP;
+    }
 }
 
 int asvd_svd(const void* a, int a_dtype, int64_t m, int64_t n, int64_t lda, const void* col_scale, int cs_dtype, float* U,

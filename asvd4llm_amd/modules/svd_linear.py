@@ -323,6 +323,15 @@ class SVDLinear(nn.Module):
         """drop the padded factor copies of the one-launch forward (rebuilt on the next decode-sized call)"""
         self._fused = None
 
+    def check_fused_forward(self):
+        """Read (one host sync per workspace) and clear the give-up flag of every one-launch-forward workspace of this module; raises AsvdHipError when
+        a launch since the last check left its in-kernel grid barrier (its output was NaN-poisoned).  The natural place is the end of a generate /
+        evaluation loop: `for m in model.modules(): isinstance(m, SVDLinear) and m.check_fused_forward()`."""
+        st = getattr(self, "_fused", None)
+        if st is not None:
+            for work in st[3].values():
+                ops.lowrank_check(work)
+
     def _fused_state(self, stream_id):
         """Padded copies of the two factors for the one-launch forward (ops.lowrank_pack), rebuilt when either Parameter is replaced or
         bumps its version, and ONE barrier/intermediate workspace PER STREAM (two launches in flight must not share barrier words)."""

@@ -148,11 +148,20 @@ def scale_cols(w, s=None):
 
 
 class SvdInfo:
-    def __init__(self, status, sweeps, last_rot):
-        self.status, self.sweeps, self.last_rotated_pairs = status, sweeps, last_rot
+    """per-problem {status, sweeps, pairs rotated in the last sweep} + the path bits of the CALL the problem was part of
+    (asvd_svd_get_last_path: reduced / reduce_fallback / plain_retry / split)"""
+
+    def __init__(self, status, sweeps, last_rot, path=0):
+        self.status, self.sweeps, self.last_rotated_pairs, self.path = status, sweeps, last_rot, path
+        self.reduced = bool(path & L.PATH_REDUCED)
+        self.reduce_fallback = bool(path & L.PATH_REDUCE_FALLBACK)
+        self.plain_retry = bool(path & L.PATH_PLAIN_RETRY)
+        self.split = bool(path & L.PATH_SPLIT)
+        self.split_refused = bool(path & L.PATH_SPLIT_REFUSED)
 
     def __repr__(self):
-        return f"SvdInfo(status={self.status}, sweeps={self.sweeps}, last_rotated_pairs={self.last_rotated_pairs})"
+        return (f"SvdInfo(status={self.status}, sweeps={self.sweeps}, last_rotated_pairs={self.last_rotated_pairs}, reduced={self.reduced}, "
+                f"reduce_fallback={self.reduce_fallback}, plain_retry={self.plain_retry}, split={self.split})")
 
 
 def svd_batched(mats, col_scales=None, k=None, want_vectors=True, max_sweeps=0, tol=0.0):
@@ -192,8 +201,9 @@ def svd_batched(mats, col_scales=None, k=None, want_vectors=True, max_sweeps=0, 
     with torch.cuda.device(dev):
         rc = lib.asvd_svd_batched(B, a_p, _dt(mats[0]), m, n, mats[0].stride(0), c_p, cdt, u_p, s_p, v_p, k, int(max_sweeps),
                                   float(tol), _ptr(work), work.numel(), info, _stream(mats[0]))
+        path = int(lib.asvd_svd_get_last_path())
     L.check(rc, "asvd_svd_batched")
-    infos = [SvdInfo(info[4 * b], info[4 * b + 1], info[4 * b + 2]) for b in range(B)]
+    infos = [SvdInfo(info[4 * b], info[4 * b + 1], info[4 * b + 2], path) for b in range(B)]
     return U, S, V, infos
 
 
@@ -307,11 +317,12 @@ def lowrank_pack(A, B):
     return Ap, Bp, work
 
 
-_LOWRANK_CALLS = 0
+_LOWRANK_CALLS = {}   # launches since the last give-up check, PER WORKSPACE (every SVDLinear owns one): data_ptr -> count
 
 
 def lowrank_check(work):
     """read (one host sync) and clear the give-up word of a fused-forward workspace; raises when a launch since the last check left its grid barrier"""
+    _LOWRANK_CALLS[work.data_ptr()] = 0
     flags = work[:16].view(torch.int32)
     if int(flags[2].item()) != 0:
         flags[2] = 0
@@ -333,11 +344,13 @@ def lowrank_forward(x2d, Ap, Bp, bias, work):
     # word 2 of the barrier state: some workgroup left the in-kernel grid barrier without its peers (the workgroups of the launch were not all
     # resident); the kernel has poisoned what it wrote of y with NaN in that case.  The word is STICKY (only the host clears it), so it does not
     # have to be read after every launch: reading it is a host sync of ~18 us on a 21 us call (round 4 measured the fused forward "slower than
-    # two GEMMs" under ASVD_STRICT for exactly that reason).  ASVD_STRICT checks every 64th launch of a workspace, ASVD_DEBUG every launch;
-    # lowrank_check(work) reads it on demand.
-    global _LOWRANK_CALLS
-    _LOWRANK_CALLS += 1
-    if os.environ.get("ASVD_DEBUG") or (os.environ.get("ASVD_STRICT") == "1" and (_LOWRANK_CALLS & 63) == 0):
+    # two GEMMs" under ASVD_STRICT for exactly that reason).  ASVD_STRICT checks every 64th launch OF EACH WORKSPACE (the counter is keyed by
+    # the workspace: with one global counter only the modules that happened to make a 64th call were ever checked — ADVICE r5), ASVD_DEBUG
+    # every launch; lowrank_check(work) reads it on demand (SVDLinear.check_fused_forward: call it at the end of a generate / eval loop).
+    key = work.data_ptr()
+    n = _LOWRANK_CALLS.get(key, 0) + 1
+    _LOWRANK_CALLS[key] = n
+    if os.environ.get("ASVD_DEBUG") or (os.environ.get("ASVD_STRICT") == "1" and n >= 64):
         lowrank_check(work)
     return y
 
@@ -374,13 +387,17 @@ def reconstruct_err(W, A, B):
     return out
 
 
-def svd_profile(enable=None):
-    """enable/disable HIP-event timing of the SVD kernel classes, or read the last call's totals"""
+PROFILE_CLASSES = ["pack", "sgram", "evd", "supdate", "finalize", "snapshot", "gram1", "update1", "supgram"]
+
+
+def svd_profile(enable=None, keep_split=False):
+    """enable/disable HIP-event timing of the SVD kernel classes, or read the last call's totals.  keep_split: the profiled call keeps the
+    two-halves split (asvd_svd_set_profiling mode 2; read the halves with svd_split_profile) instead of running every kernel alone on the chip"""
     lib = L.load(False)
     if enable is not None:
-        lib.asvd_svd_set_profiling(1 if enable else 0)
+        lib.asvd_svd_set_profiling((2 if keep_split else 1) if enable else 0)
         return None
-    names = ["pack", "sgram", "evd", "supdate", "finalize", "snapshot", "gram1", "update1", "supgram"]
+    names = PROFILE_CLASSES
     ms = (ctypes.c_float * len(names))()
     n = (ctypes.c_int * len(names))()
     lib.asvd_svd_get_profile(ms, n)
@@ -394,3 +411,22 @@ def svd_profile(enable=None):
     out["sweep_ms"] = [float(sms[i]) for i in range(ns)]
     out["sweep_rotated"] = [int(srot[i]) for i in range(ns)]
     return out
+
+
+def svd_split_profile():
+    """per-half class times of the last call profiled with keep_split (asvd_svd_get_split_profile), or None when that call did not split:
+    {"halves": [{class: {"ms", "launches"}} x 2], "supgram_ms": {"half0", "half1", "union", "both"}}"""
+    lib = L.load(False)
+    n = len(PROFILE_CLASSES)
+    ms = (ctypes.c_float * (2 * n))()
+    ln = (ctypes.c_int * (2 * n))()
+    ov = (ctypes.c_float * 4)()
+    if lib.asvd_svd_get_split_profile(ms, ln, ov) != 1:
+        return None
+    halves = [{PROFILE_CLASSES[i]: {"ms": ms[h * n + i], "launches": ln[h * n + i]} for i in range(n)} for h in range(2)]
+    return {"halves": halves, "supgram_ms": {"half0": ov[0], "half1": ov[1], "union": ov[2], "both": ov[3]}}
+
+
+def svd_set_split(mode):
+    """asvd_svd_set_split: 0 never split a batch over the two chip halves, 1 split when allowed, -1 default (as 1 unless ASVD_SPLIT=0)"""
+    L.load(False).asvd_svd_set_split(int(mode))

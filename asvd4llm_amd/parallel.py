@@ -17,9 +17,24 @@ def svd_flops(out_features, in_features):
     return 14.0 * m * n * n + 8.0 * n ** 3
 
 
+# The process group every collective of this module runs on.  None = the default group (what asvd.py initialises: "nccl" = RCCL on GPUs,
+# "gloo" in CPU tests).  bench.py keeps the DEFAULT group on gloo — rendezvous, timing barriers and the MAX-reduce of the weak-scaling number
+# never touch RCCL — and points GROUP at a separate RCCL group for the sharded-model leg only (set_group), inside that leg's watchdog.
+GROUP = None
+
+
+def set_group(group):
+    global GROUP
+    GROUP = group
+
+
+def backend():
+    return dist.get_backend(GROUP)
+
+
 def world():
     if dist.is_available() and dist.is_initialized():
-        return dist.get_rank(), dist.get_world_size()
+        return dist.get_rank(GROUP), dist.get_world_size(GROUP)
     return 0, 1
 
 
@@ -108,23 +123,22 @@ def load_balance(costs, owner, world_size):
 
 
 def _comm_device():
-    backend = dist.get_backend()
-    return torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    return torch.device("cuda", torch.cuda.current_device()) if backend() == "nccl" else torch.device("cpu")
 
 
 def barrier():
     if dist.is_available() and dist.is_initialized():
-        dist.barrier()
+        dist.barrier(group=GROUP)
 
 
 def cache_exists(path):
     """ONE answer for all ranks: rank 0 looks, every rank gets what it saw.  (With a shared working directory a rank that looks for itself
     can see a file another rank created a moment ago and take the load branch while its peers take the compute branch — and the compute
     branch may hold a collective.)"""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or world()[1] == 1:
         return os.path.exists(path)
-    flag = torch.tensor([1 if (dist.get_rank() == 0 and os.path.exists(path)) else 0], dtype=torch.int32, device=_comm_device())
-    dist.broadcast(flag, src=0)
+    flag = torch.tensor([1 if (world()[0] == 0 and os.path.exists(path)) else 0], dtype=torch.int32, device=_comm_device())
+    dist.broadcast(flag, src=0, group=GROUP)
     return bool(int(flag.item()))
 
 
@@ -146,7 +160,7 @@ def save_cache(obj, path):
             err = e
     if ws > 1:
         ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device=_comm_device())
-        dist.broadcast(ok, src=0)
+        dist.broadcast(ok, src=0, group=GROUP)
         if int(ok.item()) == 0 and err is None:
             err = RuntimeError(f"rank 0 could not write the cache file {path} (see its stderr)")
     if err is not None:
@@ -185,10 +199,10 @@ def allgather_sensitivities(local, names, ratios, owner):
                 host[stride + slot * len(ratios) + j] = 1.0
     buf = host.to(dev)
     out = torch.empty((ws, buf.numel()), dtype=torch.float64, device=dev)
-    if dist.get_backend() == "nccl":
-        dist.all_gather_into_tensor(out, buf)
+    if backend() == "nccl":
+        dist.all_gather_into_tensor(out, buf, group=GROUP)
     else:
-        dist.all_gather(list(out.unbind(0)), buf)
+        dist.all_gather(list(out.unbind(0)), buf, group=GROUP)
     out = out.cpu()
     full = {}
     for n in names:
@@ -246,7 +260,7 @@ def _p2p_all(ops):
         queues.setdefault(op[2], []).append(op)
     depth = max((len(q) for q in queues.values()), default=0)
     for c in range(depth):
-        batch = [dist.P2POp(q[c][0], q[c][1], q[c][2], tag=q[c][3]) for q in queues.values() if c < len(q)]
+        batch = [dist.P2POp(q[c][0], q[c][1], q[c][2], group=GROUP, tag=q[c][3]) for q in queues.values() if c < len(q)]
         for req in dist.batch_isend_irecv(batch):
             req.wait()
 
@@ -317,18 +331,18 @@ def exchange_factors(items, owner, mode="rank0"):
         dtype, wdev = raw.weight.dtype, raw.weight.device
         if rank == src:
             hdr, payload = _wire_of(getattr(father, child), raw)
-            dist.broadcast(torch.tensor(hdr, dtype=torch.int64, device=dev), src=src)
+            dist.broadcast(torch.tensor(hdr, dtype=torch.int64, device=dev), src=src, group=GROUP)
             for t in payload:
-                dist.broadcast(t.to(dev).contiguous(), src=src)
+                dist.broadcast(t.to(dev).contiguous(), src=src, group=GROUP)
             continue
         h = torch.empty(5, dtype=torch.int64, device=dev)
-        dist.broadcast(h, src=src)
+        dist.broadcast(h, src=src, group=GROUP)
         kind, r, has_bias, out_f, in_f = (int(v) for v in h.tolist())
         assert (out_f, in_f) == (raw.out_features, raw.in_features), f"factor exchange out of step at {full_name}"
         ts = []
         for shp in _wire_shapes(kind, r, has_bias, out_f, in_f):
             t = torch.empty(shp, dtype=dtype, device=dev)
-            dist.broadcast(t, src=src)
+            dist.broadcast(t, src=src, group=GROUP)
             ts.append(t.to(wdev) if wdev.type != "cpu" or dev.type == "cpu" else t)
         setattr(father, child, _module_from_wire(kind, r, has_bias, out_f, in_f, ts, dtype))
         received += 1

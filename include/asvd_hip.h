@@ -136,7 +136,8 @@ int asvd_scale_cols(const void* w, int w_dtype, int64_t m, int64_t n, int64_t ld
  * (the pair marks of the coupling snapshot go to the host, which packs them into rounds of disjoint pairs), one when a
  * problem finishes early (its `done` flag goes to the device), one at the end — 13 for a 4096 x 4096 call, 0.3 % of its time.
  * Everything is enqueued on `stream`; the one exception is the split of a large batch over two internal CU-masked streams
- * (asvd_svd_set_call_cus below; they wait for everything queued on `stream` before the call, and the call returns synchronised).  Concurrent calls from
+ * (asvd_svd_set_split below: what the library OWNS for it and when it refuses; the streams wait for everything queued on `stream` before the
+ * call, and the call returns synchronised).  Concurrent calls from
  * different host threads on different streams and workspaces are safe: no shared mutable state — schedule tables and modes
  * travel by value in the kernel arguments, not in __constant__ memory; the profiling counters are per thread — and no kernel
  * uses scratch.  tests/test_gpu_concurrency.py holds the library to it (two threads x 8 x 4096^2 next to a stream of foreign
@@ -155,6 +156,16 @@ int asvd_svd_batched(int batch, const void* const* a_host, int a_dtype, int64_t 
                      const void* const* cs_host, int cs_dtype,
                      float* const* U_host, float* const* S_host, float* const* V_host, int64_t k,
                      int max_sweeps, float tol, void* work, size_t work_bytes, int* info_host, void* stream);
+/* Which path the last asvd_svd_batched / asvd_svd call of THIS host thread took: an OR of the bits below over the problems of the batch (both
+ * halves of a split batch).  The results meet the same contract on every path; the bits are there so that a caller — and the parity tests —
+ * can tell a silent change of arithmetic from the default one. */
+#define ASVD_PATH_REDUCED 1          /* Cholesky-QR reduction + Jacobi on R^T (the default for >= 128 columns) ran to completion */
+#define ASVD_PATH_REDUCE_FALLBACK 2  /* the Cholesky broke down (pivot <= 1e-13: numerically rank-deficient) -> the whole call ran the direct path */
+#define ASVD_PATH_PLAIN_RETRY 4      /* a problem turned NaN in the split-fp16 fused kernel -> the sweeps were repeated with the separate passes */
+#define ASVD_PATH_SPLIT 8            /* the batch ran as two halves on two CU-masked streams */
+#define ASVD_PATH_SPLIT_REFUSED 16   /* the batch qualified for the split but ran as one call on the caller's stream: another process computes on the
+                                        device or the caller's stream carries a CU mask of its own */
+int asvd_svd_get_last_path(void);
 /* single-problem convenience wrapper (batch = 1) */
 int asvd_svd(const void* a, int a_dtype, int64_t m, int64_t n, int64_t lda, const void* col_scale, int cs_dtype,
              float* U, float* S, float* V, int64_t k, int max_sweeps, float tol,
@@ -259,13 +270,34 @@ int asvd_comm_destroy(void* comm);
  * 2 eigen-solves, 3 two-level update pass (supdate), 4 finalize, 5 snapshot (the blocked X^T X pass that opens a sparse sweep),
  * 6 single-level Gram, 7 single-level update, 8 fused two-level update + next-step Gram pass (supgram).
  * ms_host: float[9] total milliseconds; launches_host: int[9].  */
+/* enabled: 0 off; 1 on, and a profiled call is never split (every kernel alone on the whole chip: what a rocprofv3 pass with ASVD_SPLIT=0 sees);
+ * 2 on, and the call keeps the split of asvd_svd_set_split — both halves time their own launches on their own stream, asvd_svd_get_profile returns
+ * the sums over both halves, asvd_svd_get_split_profile the halves one by one. */
 void asvd_svd_set_profiling(int enabled);
 int asvd_svd_get_profile(float* ms_host, int* launches_host);
-/* CUs the asvd_svd_batched calls of THIS host thread may use (0 = the whole device, the default).  asvd_svd_batched itself runs a batch of
- * >= 4 problems with >= 3072 columns as two halves, each on its own host thread and on an internal stream masked to one half of the CUs
- * (hipExtStreamCreateWithCUMask; ASVD_SPLIT=0 disables it, a profiled call runs unsplit): the eigen-solve launches of one half (VALU-bound)
- * then overlap the HBM-bound update launches of the other, which two launches of one stream never do.  A caller that drives calls on
- * CU-masked streams of its own announces the CU count here so that the launch geometry is sized for it; such calls are not split again. */
+/* The last call profiled in mode 2, by half: ms_host float[2*9], launches_host int[2*9] (half h, class c at [h*9 + c]); overlap_host float[4] =
+ * {summed milliseconds inside the fused update + Gram launches (class 8) of half 0, of half 1, the UNION of those intervals on one time axis, the
+ * time BOTH halves were inside such a launch}.  Returns 1 when that call ran split, 0 when it did not (the arrays are then stale). */
+int asvd_svd_get_split_profile(float* ms_host, int* launches_host, float* overlap_host);
+/* The split of a batch over the two halves of the chip, and what the library owns for it.
+ * asvd_svd_batched runs a batch of >= 4 problems with >= 3072 columns as two halves, each on an internal stream masked to one half of the CUs
+ * (hipExtStreamCreateWithCUMask): the eigen-solve launches of one half (VALU-bound) then overlap the HBM-bound update launches of the other,
+ * which two launches of one stream never do.
+ * OWNERSHIP — the only entry point of this header that creates anything behind the caller's back.  Per CALLING HOST THREAD and device, at that
+ * thread's first split call, the library creates (a) two CU-masked streams (hipExtStreamCreateWithCUMask has no flags argument: they are
+ * ordinary blocking streams, i.e. they also order against the legacy NULL stream) and (b) ONE worker thread (it runs the second half; the
+ * first half runs on the calling thread); both are released when the calling thread ends.  Per thread, so that two host threads making split
+ * calls at once stay independent and the decision to split never depends on timing (results are those of the serial calls, bit for bit).
+ * Per process and device, from the first asvd_svd_batched call of any size, (c) one file descriptor on /dev/shm/asvd_hip_split.<pci bus id>
+ * holding a one-byte POSIX record lock: the presence of this process on the device.  No other call creates threads, streams or files;
+ * workspaces and outputs are always the caller's.
+ * REFUSALS — such a batch runs as ONE call on the caller's stream (ASVD_PATH_SPLIT_REFUSED) when another PROCESS that loaded this library
+ * computes on the same device (the lock file: two ranks on one GPU would otherwise both claim "the first half + the second half") or when the
+ * caller's stream is itself CU-masked (hipExtStreamGetCUMask).  A call profiled in mode 1 and a call under asvd_svd_set_call_cus are never split.
+ *   asvd_svd_set_split(mode)   process-wide: 0 never split; 1 split when the rules above allow; -1 (default) as 1 unless ASVD_SPLIT=0 is set.
+ *   asvd_svd_set_call_cus(cus) CUs the asvd_svd_batched calls of THIS host thread may use (0 = the whole device, the default): a caller that
+ *                              drives calls on CU-masked streams of its own announces the count so that the launch geometry is sized for it. */
+void asvd_svd_set_split(int mode);
 void asvd_svd_set_call_cus(int cus);
 /* Test hook: one launch of the two-level update kernel ([X_S X_T] <- [X_S X_T] Qfin for every super-pair of XOR step D) on
  * caller-built panels X [batch][nb][R][32]; Qfin [batch][npairs][128*128]; subact [batch][npairs][4] (pair updated when any flag is

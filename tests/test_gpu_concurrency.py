@@ -170,3 +170,49 @@ def test_split_batch_with_an_odd_number_of_problems(gpu, monkeypatch):
         W = mats[b].double()
         r = (W @ V1[b].double() - U1[b].double() * S1[b].double()[None, :]).norm() / S1[b].double().norm()     # triplet residual |W V - U S|
         assert r.item() <= 2e-5, (b, r.item())
+
+
+@pytest.mark.timeout(600)
+def test_split_controls_path_bits_and_split_mode_profile(gpu, monkeypatch):
+    """asvd_svd_set_split (the explicit switch next to the ASVD_SPLIT environment knob), the path bits a caller can read back
+    (asvd_svd_get_last_path) and the split-mode profile (asvd_svd_set_profiling(2) + asvd_svd_get_split_profile): the halves report their own
+    class times, the totals are their sums, the fused update + Gram launches of both halves lie on one time axis, and the bits of a call profiled
+    that way are those of the plain split call."""
+    from asvd4llm_amd import ops
+    monkeypatch.delenv("ASVD_SPLIT", raising=False)
+    n = 3072
+    mats = _problems(gpu, 6, n, n, seed=55)
+    U1, S1, V1, i1 = ops.svd_batched(mats, k=256)
+    assert all(i.split and not i.split_refused and i.reduced and not i.reduce_fallback and not i.plain_retry for i in i1)
+    try:
+        ops.svd_set_split(0)
+        _, S0, _, i0 = ops.svd_batched(mats, k=256)
+        assert not any(i.split or i.split_refused for i in i0)
+    finally:
+        ops.svd_set_split(-1)
+    _, _, _, ismall = ops.svd_batched(_problems(gpu, 4, 512, 512, seed=3))     # too small to qualify: neither split nor refused
+    assert not any(i.split or i.split_refused for i in ismall) and all(i.reduced for i in ismall)
+    ops.svd_profile(True, keep_split=True)
+    try:
+        U2, S2, V2, i2 = ops.svd_batched(mats, k=256)
+        tot = ops.svd_profile()
+        halves = ops.svd_split_profile()
+    finally:
+        ops.svd_profile(False)
+    assert halves is not None and all(i.split for i in i2)
+    assert all(torch.equal(a, b) for a, b in zip(S1, S2)) and all(torch.equal(a, b) for a, b in zip(U1, U2))   # profiling does not change the bits
+    for c in ops.PROFILE_CLASSES:
+        assert abs(tot[c]["ms"] - halves["halves"][0][c]["ms"] - halves["halves"][1][c]["ms"]) <= 1e-3 * max(1.0, tot[c]["ms"])
+        assert tot[c]["launches"] == halves["halves"][0][c]["launches"] + halves["halves"][1][c]["launches"]
+    assert halves["halves"][0]["supgram"]["launches"] > 0 and halves["halves"][1]["supgram"]["launches"] > 0
+    ov = halves["supgram_ms"]
+    assert abs(ov["half0"] - halves["halves"][0]["supgram"]["ms"]) <= 1e-2 * ov["half0"] and abs(ov["half1"] - halves["halves"][1]["supgram"]["ms"]) <= 1e-2 * ov["half1"]
+    assert max(ov["half0"], ov["half1"]) <= ov["union"] * 1.001 and ov["union"] <= (ov["half0"] + ov["half1"]) * 1.001
+    assert abs(ov["half0"] + ov["half1"] - ov["union"] - ov["both"]) <= 1e-2 * ov["union"]     # inclusion-exclusion on the common time axis
+    # mode 1 (the default profile) still runs unsplit, and says so
+    ops.svd_profile(True)
+    try:
+        _, _, _, i3 = ops.svd_batched(mats, k=256)
+    finally:
+        ops.svd_profile(False)
+    assert not any(i.split for i in i3) and ops.svd_split_profile() is None

@@ -1,0 +1,126 @@
+"""Whole-SVD parity on input families other than the flat-spectrum `llm_like` one (VERDICT r5 "Next round" 1a): constructed spectra
+W = P diag(sigma) Q^T — power laws i^-0.5 and i^-1, geometric 1 -> 1e-3, an eight-value clustered spectrum, rank n/4 + a 1e-4 noise floor —
+each under alpha in {0.5, 1} (svd_linear.py:33: the signature default is 1) and under `abs_mean`- and `abs_max`-shaped statistics
+(act_aware_utils.py:64-74; abs_max: 1 % of the channels x 300).  These are the inputs that stress what the flat family does not: the
+power-of-two column scales of the split-fp16 arithmetic (graded columns), the pivot threshold of the Cholesky-QR (numerical rank
+deficiency) and the sweep count (clustered / decaying spectra).  Oracle: CPU torch.linalg.svd on the same fp32 Ws (oracle/asvd_oracle.py);
+contract: sigma <= 1e-4 relative on the retained top-r, rank-r reconstruction <= 1e-3 |Ws|_F.  Every case also asserts which PATH ran
+(SvdInfo.reduce_fallback / plain_retry): a family that silently left the default arithmetic would otherwise look green."""
+import pytest
+import torch
+
+from oracle import asvd_oracle as O
+from tests import families as F
+from tests.test_gpu_svd import REC_TOL, SIG_TOL
+
+pytestmark = pytest.mark.gpu
+
+
+def family_case(kind, stat, alpha, m, n, seed):
+    W, st = F.make(kind, stat, m, n, seed=seed)
+    s = None if st is None else O.make_scale(st, alpha)
+    return W, s
+
+
+def retained_rank(m, n):
+    return max(1, min(O.rank_from_ratio(m, n, 0.9), min(m, n)))   # param ratio 0.9 (svd_linear.py:39-44)
+
+
+def check_family(gpu, kind, stat, alpha, m, n, seed, full_vectors, max_sweeps=10):
+    """What is asserted, and why it is not simply `check_svd` of tests/test_gpu_svd.py (measured on these families, round 6):
+    * sigma.  On a graded spectrum the fp32 LAPACK ORACLE is itself off: its absolute error is ~1e-7 sigma_1, i.e. 3e-4 ... 4e-3 RELATIVE on the
+      smallest retained values of pow1 / geo3 / cluster8 under alpha 1 (sigma_1 / sigma_r = 1e3 ... 1e4), 0.2 on rank-n/4 + noise — against
+      torch.linalg.svdvals of the SAME fp32 matrix in fp64.  The Jacobi path keeps relative accuracy (<= 3e-5 against fp64 everywhere).  So:
+      (1) |S - S64| <= 1e-4 S64 on the retained top-r (the contract's bar against the exact spectrum of the oracle's input), and
+      (2) |S - S32| <= 1e-4 S64 + |S32 - S64| — within the contract's bar of the oracle, up to the oracle's own distance from the exact answer.
+    * vectors.  V (short side: the rotated columns themselves) is orthonormal to 1e-5 whatever the grading.  U = Ws V / sigma (one GEMM) inherits
+      v_j's fp32-level contamination by the dominant directions amplified by sigma_1 / sigma_j: |U^T U - I| and the residual |Ws^T u_j - sigma_j v_j|
+      grow like 1e-7 ... 1e-6 x sigma_1 / sigma_j (LAPACK: 1e-6 flat).  The contract's quantities do not see it — a column's error enters the
+      reconstruction weighted by sigma_j — and the bounds below say so explicitly: flat bars + a term proportional to sigma_1 / sigma_j."""
+    from asvd4llm_amd import ops
+    W, s = family_case(kind, stat, alpha, m, n, seed)
+    U, S, V, info = ops.svd(W.to(gpu), None if s is None else s.to(gpu))
+    assert info.status == 0, info
+    assert info.reduced and not info.reduce_fallback, f"{kind}/{stat}/alpha {alpha}: the Cholesky-QR fell back to the direct path: {info}"
+    assert not info.plain_retry, f"{kind}/{stat}/alpha {alpha}: the split-fp16 path turned NaN and was repeated: {info}"
+    assert info.sweeps <= max_sweeps, info
+    Ws = O.scaled_weight(W, s)
+    r = retained_rank(m, n)
+    Sc = S.cpu()
+    assert bool((Sc[:-1] >= Sc[1:]).all())
+    if full_vectors:
+        Uo, So, Vo = O.exact_svd(Ws)
+    else:
+        So = torch.linalg.svdvals(Ws)
+    S64 = torch.linalg.svdvals(Ws.to(gpu).double()).cpu()   # fp64 spectrum of the oracle's fp32 input (torch on the device: a checker)
+    tag = (kind, stat, alpha)
+    e64 = ((Sc.double() - S64).abs() / S64)[:r].max().item()
+    assert e64 <= SIG_TOL, tag + ("vs fp64", e64)
+    slack = (So.double() - S64).abs()
+    excess = ((Sc.double() - So.double()).abs() - slack)[:r] / S64[:r]
+    assert excess.max().item() <= SIG_TOL, tag + ("vs the fp32 oracle beyond its own error", excess.max().item())
+    assert ((Sc.double() - So.double()).abs().max() / So[0].double()).item() <= SIG_TOL
+    Wsd = Ws.to(gpu).double()
+    Ud, Vd, Sd = U.double(), V.double(), S.double()
+    # size-independent properties (fp64 on the device as the CHECKER): orthonormal leading vectors, triplet residuals, Eckart-Young
+    idx = torch.arange(0, r, max(1, r // 192), device=gpu)
+    eye = torch.eye(idx.numel(), dtype=torch.float64, device=gpu)
+    amp = (Sd[0] / Sd[idx]).clamp(min=1.0)                                  # sigma_1 / sigma_j of the sampled columns
+    amp2 = torch.maximum(amp.unsqueeze(0), amp.unsqueeze(1))
+    assert (Vd[:, idx].T @ Vd[:, idx] - eye).abs().max().item() <= 1e-5, tag
+    assert bool(((Ud[:, idx].T @ Ud[:, idx] - eye).abs() <= 1e-4 + 2e-6 * amp2).all()), tag + ((Ud[:, idx].T @ Ud[:, idx] - eye).abs().max().item(), amp.max().item())
+    res_u = ((Wsd @ Vd[:, idx] - Ud[:, idx] * Sd[idx]).norm(dim=0) / Sd[0])
+    res_v = ((Wsd.T @ Ud[:, idx] - Vd[:, idx] * Sd[idx]).norm(dim=0) / Sd[0])
+    assert res_u.max().item() <= 2e-5, tag + (res_u.max().item(),)
+    assert bool((res_v <= 2e-5 + 1e-6 * amp).all()), tag + (res_v.max().item(), amp.max().item())
+    Rg = (Ud[:, :r] * Sd[:r]) @ Vd[:, :r].T
+    err2 = ((Wsd - Rg) ** 2).sum().item()
+    tot2 = (S64 ** 2).sum().item()
+    tail2 = (S64[r:] ** 2).sum().item()
+    assert abs(err2 - tail2) <= (REC_TOL ** 2) * tot2, tag + (err2, tail2, tot2)   # Eckart-Young: the rank-r error IS the discarded spectrum
+    if full_vectors:   # the contract's reconstruction bar against the oracle's OWN rank-r reconstruction
+        Ro = (Uo[:, :r].double() * So[:r].double()) @ Vo[:, :r].double().T
+        rec = ((Rg.cpu() - Ro).norm() / Ws.double().norm()).item()
+        assert rec <= REC_TOL, tag + ("reconstruction vs the oracle's", rec)
+    return info
+
+
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize("alpha", [0.5, 1.0])
+@pytest.mark.parametrize("stat", F.STATS)
+@pytest.mark.parametrize("kind", F.SPECTRA)
+def test_families_1024_full_vectors(gpu, kind, stat, alpha):
+    """1024^2: 16 super-panels, XOR schedule, Cholesky-QR + two-level sweeps with the fused split-fp16 kernel; oracle vectors compared"""
+    check_family(gpu, kind, stat, alpha, 1024, 1024, seed=101, full_vectors=True)
+
+
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize("kind,stat,alpha", [(k, "abs_max", 1.0) for k in F.SPECTRA] + [(k, "abs_mean", 0.5) for k in F.SPECTRA])
+def test_families_2048_full_vectors(gpu, kind, stat, alpha):
+    """2048^2: the size from which inner step 1 of the eigen-solves visits cross pairs only (ring)"""
+    check_family(gpu, kind, stat, alpha, 2048, 2048, seed=202, full_vectors=True)
+
+
+@pytest.mark.timeout(3000)
+@pytest.mark.parametrize("kind,stat,alpha", [(k, "abs_max", 1.0) for k in F.SPECTRA] + [(k, "abs_mean", 0.5) for k in F.SPECTRA])
+def test_families_4096_contract_size(gpu, kind, stat, alpha):
+    """BASELINE.json configs[1] size.  The oracle's full vectors cost minutes of CPU here: sigma against CPU svdvals + the size-independent
+    properties (orthonormality, triplet residuals, Eckart-Young) pin the vectors."""
+    check_family(gpu, kind, stat, alpha, 4096, 4096, seed=303, full_vectors=False)
+
+
+@pytest.mark.parametrize("kind", ["cluster8", "pow1"])
+def test_families_unscaled_exact_clusters(gpu, kind):
+    """act_aware off (s = None): the clustered spectrum keeps EXACTLY degenerate singular values (eight clusters of 128), where a rank-r cut
+    inside a cluster is not unique (so the oracle's own reconstruction is not compared there); sigma, orthogonality, triplet residuals and
+    Eckart-Young — which hold for any basis of a degenerate cluster — still pin the result"""
+    check_family(gpu, kind, None, 1.0, 1024, 1024, seed=404, full_vectors=(kind != "cluster8"))
+
+
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize("shape", [(2752, 1024), (1024, 2752)])
+@pytest.mark.parametrize("kind", ["pow1", "geo3"])
+def test_families_rectangular_abs_max_alpha1(gpu, kind, shape):
+    """gate/up- and down-shaped (x 1/4): the long-side GEMM and the row un-permutation on graded spectra, statistics on the short / long side"""
+    m, n = shape
+    check_family(gpu, kind, "abs_max", 1.0, m, n, seed=505, full_vectors=True)

@@ -118,3 +118,37 @@ def test_fused_forward_rejects_bad_arguments(gpu):
     assert rc == _lib.ASVD_E_WORKSPACE if hasattr(_lib, "ASVD_E_WORKSPACE") else rc == -2
     with pytest.raises(ValueError):
         ops.lowrank_pack(torch.zeros(64, 8, device="cuda").half(), torch.zeros(8, 72, device="cuda").half())
+
+
+def test_strict_check_counts_launches_per_workspace(gpu, monkeypatch):
+    """the ASVD_STRICT give-up check fired on a process-global launch counter, so with many SVDLinear modules only the few that
+    happened to make the global 64th call were ever checked.  The counter is per workspace now: EVERY module is checked at its own 64th launch,
+    and check_fused_forward() reads the flag on demand."""
+    import torch
+    from asvd4llm_amd import ops
+    from asvd4llm_amd.modules.svd_linear import SVDLinear
+    monkeypatch.setenv("ASVD_STRICT", "1")
+    monkeypatch.delenv("ASVD_DEBUG", raising=False)
+    g = torch.Generator().manual_seed(5)
+    mods = []
+    for _ in range(3):
+        A = (torch.randn(256, 64, generator=g) * 0.05).half().to(gpu)
+        B = (torch.randn(64, 128, generator=g) * 0.05).half().to(gpu)
+        m = SVDLinear._from_factors(A, B, None, 64)
+        m.fused_forward = True
+        mods.append(m)
+    checked = []
+    real = ops.lowrank_check
+    monkeypatch.setattr(ops, "lowrank_check", lambda w: (checked.append(w.data_ptr()), real(w))[1])
+    x = torch.randn(2, 128, generator=g).half().to(gpu)
+    with torch.no_grad():
+        for it in range(64):
+            for m in mods:       # interleaved: a global counter would have hit (it * 3 + k) & 63 == 0 for one module only
+                m(x)
+    works = [next(iter(m._fused[3].values())).data_ptr() for m in mods]
+    assert sorted(checked) == sorted(works), (checked, works)     # each workspace exactly once, at ITS 64th launch
+    checked.clear()
+    for m in mods:
+        m.check_fused_forward()
+    assert sorted(checked) == sorted(works)
+    assert all(ops._LOWRANK_CALLS[w] == 0 for w in works)

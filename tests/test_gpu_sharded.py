@@ -156,7 +156,7 @@ def test_bench_two_ranks_on_one_gpu_run_the_whole_multi_gpu_leg(tmp_path):
     import sys
     from tests.conftest import ROOT
     import os
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist_backend", "gloo", "--same_gpu", "--batch", "4", "--steps", "1", "--warmup", "0",
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist_backend", "gloo", "--same_gpu", "--batch", "4", "--steps", "1", "--warmup", "1",
            "--prewarm_s", "0", "--sharded_model", "llama-7b-2layers"]
     env = dict(os.environ, ASVD_STRICT="1")
     env.pop("WORLD_SIZE", None)
@@ -172,6 +172,38 @@ def test_bench_two_ranks_on_one_gpu_run_the_whole_multi_gpu_leg(tmp_path):
     assert sm["collective_world_size"] == 2 and sm["plan_identical_on_all_ranks"]
     assert sm["gather_factors_s"] > 0 and sm["gather_factors_bytes_into_rank0"] > 1e6     # rank 1's factors reached rank 0
     assert sm["decompose_s"] > 0 and sm["load_flops_max_over_mean"] < 1.3
+    # two processes on ONE device: the library sees the other rank (the lock file of include/asvd_hip.h, "REFUSALS") and does not split its
+    # batches over "the first half + the second half" of CUs both ranks would claim — detected, not configured
+    assert d["config"]["batch_split_over_chip_halves"] is False and d["config"]["split_refused_device_shared_or_masked"] is True, d["config"]
+    dv = d["devices"]
+    assert dv["visible_device_count"] >= 1 and len(dv["per_rank"]) == 2 and [x["rank"] for x in dv["per_rank"]] == [0, 1]
+    assert all(x["device_index"] == 0 and x["pci_bus_id"] for x in dv["per_rank"]) and dv["host_group_backend"] == "gloo"
+
+
+@pytest.mark.timeout(1200)
+def test_bench_keeps_the_line_when_the_rccl_group_cannot_be_created(tmp_path):
+    """The first multi-GPU run must not be able to lose the line (VERDICT r5 task 4): `--dist_backend nccl` with the creation of the RCCL group
+    forced to fail (ASVD_BENCH_FAIL_NCCL).  Rendezvous, the barriers around the timed region and the MAX-reduce run on the gloo host group, so
+    n_gpus, value and the per-rank rates are there; the sharded-model leg falls back to the host group and says so."""
+    import json
+    import subprocess
+    import sys
+    from tests.conftest import ROOT
+    import os
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist_backend", "nccl", "--same_gpu", "--batch", "4", "--steps", "1", "--warmup", "1",
+           "--prewarm_s", "0", "--sharded_model", "llama-7b-2layers"]
+    env = dict(os.environ, ASVD_STRICT="1", ASVD_BENCH_FAIL_NCCL="1")
+    env.pop("WORLD_SIZE", None)
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=1100, env=env, cwd=str(tmp_path))
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak" and len(d["per_rank_svds_per_s"]) == 2 and all(v > 0 for v in d["per_rank_svds_per_s"])
+    sm = d["sharded_model"]
+    assert "error" not in sm, sm
+    assert "RCCL group unavailable" in sm["collective_backend_note"] and sm["collective_backend"].startswith("gloo")
+    assert sm["collective_world_size"] == 2 and sm["plan_identical_on_all_ranks"] and sm["gather_factors_bytes_into_rank0"] > 1e6
 
 
 @pytest.mark.timeout(900)

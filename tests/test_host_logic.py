@@ -208,3 +208,20 @@ def test_sweep_costs_for_model_reads_the_block_structure():
     assert parallel.lpt_assign(costs, 2) == parallel.lpt_assign(list(costs), 2)
     flat = parallel.sweep_costs_for_model(model, linears, 6, 4, 128, prefix_cached=False)
     assert max(flat) / min(flat) < 1.5   # full forwards: every evaluation costs the same, only the factorisations differ
+
+
+def test_every_profile_path_a_bench_string_cites_exists():
+    """`roofline.traffic_source` pointed at profiles/r5f_pmc_*.txt, files that were committed under another name.  Every
+    `profiles/...` path (or glob) that bench.py can print, and the `source` of profiles/pmc_traffic.json, must resolve in the tree."""
+    import glob
+    import json
+    import os
+    import re
+    from tests.conftest import ROOT
+    cited = set(re.findall(r"profiles/[A-Za-z0-9_.*\-]+", open(os.path.join(ROOT, "bench.py")).read()))
+    pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    cited |= set(re.findall(r"profiles/[A-Za-z0-9_.*\-]+", pmc.get("source", "")))
+    cited = {c.rstrip(".") for c in cited}
+    assert cited, "bench.py cites its evidence"
+    missing = sorted(c for c in cited if not glob.glob(os.path.join(ROOT, c)))
+    assert not missing, f"bench.py / pmc_traffic.json cite files that are not in the tree: {missing}"

@@ -16,7 +16,7 @@ fetch, write = table(os.path.join(d, "pmc_FETCH_SIZE.txt")), table(os.path.join(
 names = {"supgram": "supgram_kernel", "supdate": "supdate_split_kernel", "sgram": "sgram6_kernel", "evd": "evdw12_kernel", "snapshot": "fullcheck_kernel"}
 import hashlib
 _lib_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "asvd4llm_amd", "libasvd_hip.so")
-res = {"batch": int(os.environ.get("PMC_BATCH", "32")), "lib_sha256": hashlib.sha256(open(_lib_path, "rb").read()).hexdigest() if os.path.exists(_lib_path) else None, "source": "profiles/" + os.path.basename(d).replace("prof_", "") + "_pmc_*.txt",
+res = {"batch": int(os.environ.get("PMC_BATCH", "32")), "lib_sha256": hashlib.sha256(open(_lib_path, "rb").read()).hexdigest() if os.path.exists(_lib_path) else None, "source": "profiles/" + os.environ.get("PMC_TAG", os.path.basename(d).replace("prof_", "")) + "_pmc_*.txt",
        "note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes of `python bench.py --no_cpu_baseline --no_latency --steps 1 --warmup 0 --prewarm_s 0` "
                "(" + os.environ.get("PMC_BATCH", "32") + " x 4096x4096 fp32, one stream); mean per dispatch over all launches of the run; FETCH doubled (gfx950 half-count), WRITE as reported",
        "kernels": {}}
@@ -45,4 +45,13 @@ for key, kn in names.items():
         gdur = sum(x["avg_dur_us"] * x["calls"] for x in ga) / max(1, sum(x["calls"] for x in ga))
         res["kernels"][key].update({"mfma_busy_cycles_avg": mbusy, "gui_active_cycles": gact, "mfma_busy_frac": (mbusy * 32 / 1024) / gact if gact else None,
                                     "shader_clock_GHz_under_pmc": gact / gdur / 1e3 if gdur else None})
+# HBM bytes of EVERY kernel of the pass (2 x FETCH + WRITE, KiB -> B): the pass runs `bench.py --steps 1 --warmup 0 --prewarm_s 0`, i.e. PMC_STEPS
+# identical steps of PMC_BATCH problems (the timed one + the profiled ones)
+steps = int(os.environ.get("PMC_STEPS", "3"))
+tot_f = sum(v["avg"] * v["calls"] for (n, c), v in fetch.items() if c == "FETCH_SIZE")
+tot_w = sum(v["avg"] * v["calls"] for (n, c), v in write.items() if c == "WRITE_SIZE")
+if tot_f and tot_w:
+    res["hbm_bytes_all_kernels_of_the_pass"] = int((2 * tot_f + tot_w) * 1024)
+    res["steps_in_the_pass"] = steps
+    res["hbm_bytes_per_svd_all_kernels"] = (2 * tot_f + tot_w) * 1024 / steps / res["batch"]
 print(json.dumps(res, indent=1))

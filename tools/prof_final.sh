@@ -12,7 +12,7 @@ python tools/rocpd_overlap.py $DB >> $OUT/kernel_stats.txt 2>/dev/null
 for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES" "SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES" "GRBM_GUI_ACTIVE GRBM_COUNT"; do
   N=$(echo $C | tr ' ' '_' | cut -c1-40)
   rocprofv3 --kernel-trace --pmc $C -d $OUT/pmc_$N -- python bench.py --no_cpu_baseline --no_latency --steps 1 --warmup 0 --prewarm_s 0 $BENCH_ARGS > /dev/null 2> $OUT/pmc_$N.log
-  python tools/rocpd_pmc.py $(find $OUT/pmc_$N -name "*.db" | head -1) > $OUT/pmc_$N.txt 2>&1
+  python tools/rocpd_pmc.py $(find $OUT/pmc_$N -name "*.db" | head -1) 400 > $OUT/pmc_$N.txt 2>&1
   rm -rf $OUT/pmc_$N
 done
 python tools/pmc_to_json.py $OUT > $OUT/pmc_traffic.json 2> $OUT/pmc_to_json.err
