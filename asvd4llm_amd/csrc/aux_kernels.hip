@@ -447,6 +447,136 @@ __global__ __launch_bounds__(256, 2) void recon_err16_kernel(const void* __restr
         part[2 * bid + 1] = ((red[0][1] + red[1][1]) + red[2][1]) + red[3][1];
     }
 }
+// K9, 16-bit factors, ONE GEMM launch (round 6): the same 128 x 128 tile and wave layout as recon_err16_kernel, but the operands are staged through
+// LDS straight from the factors AS SVDLinear HOLDS THEM — A [m][r] (K-contiguous, rows at ANY 2-byte alignment: r = 1843, 2686, ...) and B [r][n]
+// (K is the slow index) — so the pad and transpose launches and their (m + n) x rp x 2 bytes of workspace traffic are gone.
+//   A tile [128 rows][64 k]: thread t owns row t >> 1, k-half t & 1 = 32 consecutive values, fetched as 16 (+1) aligned dwords and shifted by one
+//     half-word with v_alignbyte when the row starts on an odd element; values with k >= r or row >= m are zeroed.
+//   B tile [64 k][128 cols]: thread t owns the k-pair t & 31 and the 16 columns 16 (t >> 5) .. +15 (two rows x 32 bytes, 16-byte loads: needs
+//     n % 8 == 0 and a 16-byte aligned pointer — the entry point takes the three-launch path otherwise), packs (k, k + 1) per column into one
+//     32-bit word with v_perm and writes it to the K-CONTIGUOUS image [col][k]: the transpose costs 16 ds_write_b32 per thread and chunk.
+//   Both images have a row stride of 72 half-words (144 B): the row-per-lane ds_read_b128 of a 16-lane group and the 32 word-writes of a
+//   half-wave fall on distinct banks.  Two image sets (2 x 36 KB): the loads of chunk it + 1 are issued before the 16 MFMAs of chunk it and written
+//   to the other set after them — one barrier per chunk.
+constexpr int R16_LD = 72;                       // half-words per image row
+constexpr int R16_IMG = 128 * R16_LD;            // half-words per image
+template <int WT, int BF>
+__global__ __launch_bounds__(256, 2) void recon_err16_fused_kernel(const void* __restrict__ W, int64_t ldw, const uint16_t* __restrict__ A,
+                                                                   const uint16_t* __restrict__ B, int64_t m, int64_t n, int64_t r, double* __restrict__ part) {
+    __shared__ __attribute__((aligned(16))) uint16_t img[2][2][R16_IMG];   // [set][A | B]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wr = w >> 1, wc = w & 1;
+    const int h = lane >> 5, c = lane & 31;
+    const int64_t R0 = (int64_t)blockIdx.y * 128, C0 = (int64_t)blockIdx.x * 128;
+    // ---- A fetch geometry ----
+    const int arow = tid >> 1, ahalf = tid & 1;
+    const int64_t grow = R0 + arow;
+    const bool arow_ok = grow < m;
+    const int64_t ebase = (arow_ok ? grow : m - 1) * r + 32 * ahalf;     // element index of k = k0 + 32 ahalf at k0 = 0
+    const uint32_t* __restrict__ A32 = (const uint32_t*)A;
+    const int64_t last_dw = (m * r - 1) >> 1;
+    // ---- B fetch geometry ----
+    const int bkp = tid & 31, bcg = tid >> 5;
+    const int64_t bcol = C0 + 16 * bcg;
+    uint32_t ra[17], rb[2][8];
+    auto fetch = [&](int64_t k0) {
+        const int64_t e = ebase + k0;
+        const int64_t d0 = e >> 1;
+#pragma unroll
+        for (int i = 0; i < 17; ++i) ra[i] = A32[min(d0 + i, last_dw)];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int64_t k = k0 + 2 * bkp + q;
+            const uint16_t* src = B + min(k, r - 1) * n + bcol;
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                u32x4 x = (u32x4){0u, 0u, 0u, 0u};
+                if (k < r && bcol + 8 * v < n) x = *(const u32x4*)(src + 8 * v);
+                rb[q][4 * v + 0] = x[0]; rb[q][4 * v + 1] = x[1]; rb[q][4 * v + 2] = x[2]; rb[q][4 * v + 3] = x[3];
+            }
+        }
+    };
+    auto stash = [&](int set, int64_t k0) {
+        // A: 32 values of one row -> 16 words at [row][32 ahalf ..]
+        const int par = (int)((ebase + k0) & 1);
+        uint32_t* da = (uint32_t*)(img[set][0] + arow * R16_LD + 32 * ahalf);
+        const int64_t kbase = k0 + 32 * ahalf;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            uint32_t v = __builtin_amdgcn_alignbyte(ra[i + 1], ra[i], 2 * par);
+            const int64_t k = kbase + 2 * i;
+            if (!arow_ok || k >= r) v = 0u;
+            else if (k + 1 >= r) v &= 0x0000ffffu;
+            da[i] = v;
+        }
+        // B: (k, k + 1) of 16 columns -> one word per column at [col][2 bkp]
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t lo = __builtin_amdgcn_perm(rb[1][j], rb[0][j], 0x05040100u);   // {row1.lo16 : row0.lo16} = column 2j
+            const uint32_t hi = __builtin_amdgcn_perm(rb[1][j], rb[0][j], 0x07060302u);   // {row1.hi16 : row0.hi16} = column 2j + 1
+            *(uint32_t*)(img[set][1] + (16 * bcg + 2 * j) * R16_LD + 2 * bkp) = lo;
+            *(uint32_t*)(img[set][1] + (16 * bcg + 2 * j + 1) * R16_LD + 2 * bkp) = hi;
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16){0};
+    const int64_t nit = (r + 63) / 64;
+    fetch(0);
+    stash(0, 0);
+    __syncthreads();
+    for (int64_t it = 0; it < nit; ++it) {
+        const int set = (int)(it & 1);
+        if (it + 1 < nit) fetch((it + 1) * 64);
+        const uint16_t* ia = img[set][0] + (64 * wr + c) * R16_LD + 8 * h;
+        const uint16_t* ib = img[set][1] + (64 * wc + c) * R16_LD + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            u32x4 a[2], b[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                a[t] = *(const u32x4*)(ia + 32 * t * R16_LD + 16 * ks);
+                b[t] = *(const u32x4*)(ib + 32 * t * R16_LD + 16 * ks);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if constexpr (BF) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b16x8, a[i]), __builtin_bit_cast(b16x8, b[j]), acc[i][j], 0, 0, 0);
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a[i]), __builtin_bit_cast(h16x8, b[j]), acc[i][j], 0, 0, 0);
+                }
+        }
+        if (it + 1 < nit) stash(set ^ 1, (it + 1) * 64);   // the other set: its last readers passed the barrier of the previous iteration
+        __syncthreads();
+    }
+    const int64_t r0 = R0 + wr * 64, c0 = C0 + wc * 64;
+    double e2 = 0.0, w2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int64_t row = r0 + 32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * h, col = c0 + 32 * j + c;
+                if (row < m && col < n) {
+                    const float wv = elem<WT>::ld(W, row * ldw + col);
+                    const double d = (double)wv - (double)acc[i][j][reg];
+                    e2 += d * d;
+                    w2 += (double)wv * (double)wv;
+                }
+            }
+    e2 = wave_reduce_sum_d(e2);
+    w2 = wave_reduce_sum_d(w2);
+    __shared__ double red[4][2];
+    if (lane == 0) { red[w][0] = e2; red[w][1] = w2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int64_t bid = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+        part[2 * bid + 0] = ((red[0][0] + red[1][0]) + red[2][0]) + red[3][0];
+        part[2 * bid + 1] = ((red[0][1] + red[1][1]) + red[2][1]) + red[3][1];
+    }
+}
 __global__ __launch_bounds__(256) void ordered_sum_d2_kernel(const double* __restrict__ part, int64_t np, double* __restrict__ out) {
     __shared__ double red[256][2];
     double a = 0.0, b = 0.0;
@@ -651,6 +781,19 @@ int asvd_reconstruct_err(const void* W, int w_dtype, int64_t ldw, const void* A,
         ASVD_HIP_CHECK(hipGetLastError());
         return ASVD_OK;
     }
+    const int64_t gx16 = ceil_div64(n, 128), gy16 = ceil_div64(m, 128);
+    if ((n % 8) == 0 && (((uintptr_t)B) & 15) == 0 && (((uintptr_t)A) & 3) == 0) {
+        // one GEMM launch straight from the factors as stored (recon_err16_fused_kernel) + the ordered sum of its partials
+        dim3 grid16((unsigned)gx16, (unsigned)gy16);
+        ASVD_DISPATCH_DTYPE(w_dtype, WT, {
+            if (ab_dtype == ASVD_BF16) recon_err16_fused_kernel<WT, 1><<<grid16, 256, 0, st>>>(W, ldw, (const uint16_t*)A, (const uint16_t*)B, m, n, r, part);
+            else recon_err16_fused_kernel<WT, 0><<<grid16, 256, 0, st>>>(W, ldw, (const uint16_t*)A, (const uint16_t*)B, m, n, r, part);
+        });
+        ordered_sum_d2_kernel<<<1, 256, 0, st>>>(part, gx16 * gy16, out);
+        ASVD_HIP_CHECK(hipGetLastError());
+        return ASVD_OK;
+    }
+    // in_features not a multiple of 8 (or an unaligned view): K-contiguous padded copies first, then the GEMM that reads them from global memory
     const int64_t rp = round_up64(r, 64);
     uint16_t* Ap = (uint16_t*)((char*)work + recon_part_bytes(m, n));
     uint16_t* Bt = Ap + m * rp;

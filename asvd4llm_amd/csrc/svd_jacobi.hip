@@ -635,7 +635,7 @@ static int svd_direct_run(int batch, const void* const* a_host, int a_dtype, int
     int sweep = 0;
     // Step schedule of a single-level dense sweep (XOR distances d, stored as step = d-1).  The local levels d = 1..L are run twice at the
     // start of every sweep: the strongest couplings of the sorted, preconditioned matrix sit between neighbouring panels, and a second pass
-    // over them is cheap (L extra steps of P-1) — DESIGN.md 7.1.  L = min(7, P/16 - 1): measured at 4096^2 (P = 128) 8 -> 7 sweeps, +2.4 %.
+    // over them is cheap (L extra steps of P-1) — docs/history.md (round 1).  L = min(7, P/16 - 1): measured at 4096^2 (P = 128) 8 -> 7 sweeps, +2.4 %.
     std::vector<int> sched;
     {
         const int P2 = nsteps + 1;

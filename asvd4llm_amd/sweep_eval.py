@@ -62,15 +62,20 @@ class MultiRankSVDLinear(nn.Module):
         rmax = B.shape[0]
         idx = torch.arange(rmax, device=B.device)
         self.mask = torch.stack([(idx < r) for r in self.ranks])  # [R, r_max] bool
+        self.group = 1          # calibration samples per pass: batch element b = j * group + s carries truncation j of sample s
+        self._gmask = {1: self.mask}
 
     def forward(self, x):
-        R = len(self.ranks)
+        R, g = len(self.ranks), self.group
         flat = x.dim() == 2
         if flat:
-            x = x.view(R, -1, x.shape[-1])
-        assert x.shape[0] == R, f"MultiRankSVDLinear expects batch {R}, got {tuple(x.shape)}"
-        z = nn.functional.linear(x, self.B)                       # [R, T, r_max]
-        y = nn.functional.linear(torch.where(self.mask[:, None, :], z, torch.zeros((), dtype=z.dtype, device=z.device)), self.A, self.bias)  # select, not multiply: an inf in a masked component must not become NaN
+            x = x.view(R * g, -1, x.shape[-1])
+        assert x.shape[0] == R * g, f"MultiRankSVDLinear expects batch {R} x {g}, got {tuple(x.shape)}"
+        mask = self._gmask.get(g)
+        if mask is None:
+            mask = self._gmask[g] = self.mask.repeat_interleave(g, dim=0)
+        z = nn.functional.linear(x, self.B)                       # [R g, T, r_max]
+        y = nn.functional.linear(torch.where(mask[:, None, :], z, torch.zeros((), dtype=z.dtype, device=z.device)), self.A, self.bias)  # select, not multiply: an inf in a masked component must not become NaN
         return y.view(-1, y.shape[-1]) if flat else y
 
 
@@ -235,30 +240,47 @@ class PrefixCachedEvaluator:
         return ppl.item()
 
     @torch.no_grad()
-    def perplexities(self, full_name, multi_module):
+    def perplexities(self, full_name, multi_module, samples_per_pass=1):
         """Calibration perplexities of the R rank truncations held by `multi_module` (a MultiRankSVDLinear already installed in place
-        of the Linear `full_name`): ONE suffix pass per calibration sample on a batch of R copies.  Returns a list of R floats, each
-        with the arithmetic of evaluate_perplexity (mean over T-1 tokens times seqlen, evaluate_utils.py:95-114).
-        Returns None when the layer sits in front of the decoder blocks (nothing to batch: use the per-ratio path)."""
+        of the Linear `full_name`): ONE suffix pass per `samples_per_pass` calibration samples on a batch of R x samples copies.  Returns a list of
+        R floats, each with the arithmetic of evaluate_perplexity (mean over T-1 tokens times seqlen, evaluate_utils.py:95-114).
+        Returns None when the layer sits in front of the decoder blocks (nothing to batch: use the per-ratio path).
+
+        samples_per_pass > 1 (round 6): the cached block inputs of g samples are stacked, each repeated R times — batch element b = j g + s is
+        truncation j of sample s — and the suffix runs once per g samples.  The forward is called with ONE sample's ids (everything in front of the
+        substituted block is skipped, position ids and the causal mask are batch-1 and broadcast, exactly as for g = 1); every (j, s) gets its own
+        CrossEntropyLoss against the labels of ITS sample, summed per truncation in sample order — the per-sample arithmetic, on GEMMs with g x
+        the rows (tools/sweep_gemm_ceiling.py: a Llama-2-7B block costs 0.419 / 0.371 / 0.361 us per token at g = 1 / 2 / 4)."""
         model = self.model
         R = len(multi_module.ranks)
-        cur = {"i": 0}
+        g_max = max(1, min(int(samples_per_pass), self.n))
+        cur = {"ids": [0]}
+
+        def stacked(get):
+            hs = [get(i) for i in cur["ids"]]
+            if hs[0].dim() == 3:      # [1, T, C] per sample -> [R g, T, C], b = j g + s
+                h = hs[0] if len(hs) == 1 else torch.cat(hs, 0)
+                return h.expand(R, *h.shape[1:]) if len(hs) == 1 else h.repeat(R, 1, 1)
+            h = hs[0] if len(hs) == 1 else torch.cat(hs, 0)       # OPT's flattened [T, C] inputs -> [R g T, C]
+            return h.repeat(R, 1)
+
         undo, handle = [], None
         if full_name in self.block_index:
             start = (self.block_index[full_name] // self.stride) * self.stride
             undo = self._skip_blocks(start)
 
             def sub(mod, args, kwargs):
-                h = self.cached[cur["i"]][start] if start in self.cached[cur["i"]] else _hidden_of(args, kwargs)
-                return _with_hidden(args, kwargs, h.expand(R, *h.shape[1:]) if h.dim() == 3 else h.repeat(R, 1))
+                if start not in self.cached[cur["ids"][0]]:   # (cannot happen: start is a multiple of the caching stride)
+                    h = _hidden_of(args, kwargs)
+                    return _with_hidden(args, kwargs, h.expand(R, *h.shape[1:]) if h.dim() == 3 else h.repeat(R, 1))
+                return _with_hidden(args, kwargs, stacked(lambda i: self.cached[i][start]))
 
             handle = self.blocks[start].register_forward_pre_hook(sub, with_kwargs=True)
         elif full_name in self.after_blocks:
             undo = self._skip_blocks(self.nblocks)
 
             def sub(mod, args):
-                x = self.tail_inputs[cur["i"]][full_name]
-                return (x.expand(R, *x.shape[1:]) if x.dim() == 3 else x.repeat(R, 1),) + tuple(args[1:])
+                return (stacked(lambda i: self.tail_inputs[i][full_name]),) + tuple(args[1:])
 
             handle = multi_module.register_forward_pre_hook(sub)
         else:
@@ -266,16 +288,22 @@ class PrefixCachedEvaluator:
         nll = torch.zeros(R, dtype=torch.float32, device=model.device)
         seqlen = self.seqlen
         try:
-            for i in range(self.n):
-                cur["i"] = i
-                input_ids = self.input_ids[i:i + 1, :-1].to(model.device)
-                labels = self.input_ids[i:i + 1, 1:].contiguous().to(model.device).view(-1)
-                logits = model(input_ids=input_ids, use_cache=False)[0]      # [R, T-1, V]
-                assert logits.shape[0] == R, f"batched suffix returned batch {logits.shape[0]}, expected {R}"
-                for j in range(R):  # one CrossEntropyLoss per truncation, exactly the per-sample arithmetic
-                    loss = nn.CrossEntropyLoss()(logits[j].view(-1, logits.size(-1)), labels)
-                    nll[j] += loss.float() * seqlen
+            for i0 in range(0, self.n, g_max):
+                ids = list(range(i0, min(self.n, i0 + g_max)))
+                g = len(ids)
+                cur["ids"] = ids
+                multi_module.group = g
+                input_ids = self.input_ids[i0:i0 + 1, :-1].to(model.device)
+                logits = model(input_ids=input_ids, use_cache=False)[0]      # [R g, T-1, V]
+                assert logits.shape[0] == R * g, f"batched suffix returned batch {logits.shape[0]}, expected {R} x {g}"
+                for s, i in enumerate(ids):
+                    labels = self.input_ids[i:i + 1, 1:].contiguous().to(model.device).view(-1)
+                    for j in range(R):  # one CrossEntropyLoss per (truncation, sample), exactly the per-sample arithmetic
+                        loss = nn.CrossEntropyLoss()(logits[j * g + s].view(-1, logits.size(-1)), labels)
+                        nll[j] += loss.float() * seqlen
+                del logits
         finally:
+            multi_module.group = 1
             if handle is not None:
                 handle.remove()
             self._restore(undo)

@@ -769,7 +769,13 @@ def main():
                 So_, Ao_, Bo_, _, _, _, Wb_, sb_ = refb
                 A_b, B_b, _ = outs[b]
                 rerr, rerr_scaled = O.recon_parity(A_b, B_b, Ao_, Bo_, Wb_, sb_)
+                # the same spectrum in fp64 (CPU LAPACK on the oracle's own fp32 input): separates the path's distance from the exact answer from the fp32
+                # oracle's (gesdd in fp32 is itself 1e-5 ... 7e-5 off on the smallest retained values of this family)
+                S64_ = torch.linalg.svdvals(refb[5].double())
+                e64 = float(((S[b].cpu().double() - S64_).abs() / S64_)[:r9].max())
+                o64 = float(((So_.double() - S64_).abs() / S64_)[:r9].max())
                 return {"problem": b, "half": 0 if b < (B + 1) // 2 else 1, "sigma_rel_err_top_r": O.sigma_rel_err(S[b].cpu(), So_, r9),
+                        "sigma_rel_err_top_r_vs_fp64_svdvals": e64, "oracle_fp32_own_rel_err_vs_fp64": o64,
                         "recon_fro_err_rank%d_vs_oracle" % r: rerr, "recon_fro_err_scaled_norm": rerr_scaled, "sweeps": timed_infos[b].sweeps}
 
             p0 = parity_of(0, ref)

@@ -48,7 +48,7 @@ def test_llama2_13b_shaped_model_ratio_095_decomposes_with_parity(gpu):
     rec = bench.sharded_model_leg("llama-2-13b", 0, 1, gpu, ratio=0.95, samples=samples)
     assert "error" not in rec, rec
     assert rec["linears"] == 281 and rec["layers_per_rank"] == [281]
-    assert rec["plan_identical_on_all_ranks"] and 0.9 < rec["plan_param_ratio"] <= 0.9501
+    assert rec["plan_identical_on_all_ranks"] and 0.9 < rec["plan_param_ratio"] <= 0.951   # the search stops at the first cut whose ratio exceeds the target (binary_search.py:29-110)
     assert rec["sweeps_min_max_rank0"][1] <= 12
     assert 0 < rec["decompose_s"] < 60.0                      # 10.8-11.6 s measured (round 5)
     assert sorted(tuple(s["shape"]) for s in samples) == [(5120, 5120), (5120, 13824), (13824, 5120), (32000, 5120)]

@@ -177,7 +177,10 @@ def test_fro_and_reconstruct(gpu, dtype):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("shape", [(4096, 4096, 512), (11008, 4096, 2686), (1000, 777, 345), (70016, 160, 40)])   # the last: more rows than a grid dimension holds (a 128256-row lm_head)
+# (70016, 160, 40): more rows than a grid dimension holds (a 128256-row lm_head); (1000, 777, 345): in_features not a multiple of 8 -> the three-launch
+# path with padded copies; (4096, 4096, 1843) and (520, 264, 77): ODD ranks through the one-launch kernel (rows of A at odd 2-byte offsets, a K tail in
+# the last chunk, ragged row / column tiles, a half-filled 16-column group)
+@pytest.mark.parametrize("shape", [(4096, 4096, 512), (11008, 4096, 2686), (1000, 777, 345), (70016, 160, 40), (4096, 4096, 1843), (520, 264, 77)])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_reconstruct_err_at_contract_shapes(gpu, shape, dtype):
     """K9 at the BASELINE shapes (4096^2 rank 512, Llama-2-7B gate/up rank 2686 = ratio 0.9; a ragged shape for the padding paths): the

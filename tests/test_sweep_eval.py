@@ -112,6 +112,14 @@ def _check_multi(model, vocab, n=3, T=20, tol=2e-6):
         setattr(meta["father"], meta["name"], multi)
         try:
             got = ev.perplexities(name, multi)
+            # several calibration samples per suffix pass (round 6): 2 (an uneven last chunk: n = 3) and all 3 at once — the same per-sample arithmetic
+            for g_ in (2, 3):
+                got_g = ev.perplexities(name, multi, samples_per_pass=g_)
+                assert (got is None) == (got_g is None)
+                if got is not None:
+                    for a_, b_ in zip(got, got_g):
+                        assert abs(a_ - b_) <= tol * abs(a_), (name, g_, a_, b_)
+            assert multi.group == 1
         finally:
             setattr(meta["father"], meta["name"], lin)
         if got is None:
