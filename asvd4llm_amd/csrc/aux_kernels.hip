@@ -450,13 +450,14 @@ __global__ __launch_bounds__(256, 2) void recon_err16_kernel(const void* __restr
 // K9, 16-bit factors, ONE GEMM launch (round 6): the same 128 x 128 tile and wave layout as recon_err16_kernel, but the operands are staged through
 // LDS straight from the factors AS SVDLinear HOLDS THEM — A [m][r] (K-contiguous, rows at ANY 2-byte alignment: r = 1843, 2686, ...) and B [r][n]
 // (K is the slow index) — so the pad and transpose launches and their (m + n) x rp x 2 bytes of workspace traffic are gone.
-//   A tile [128 rows][64 k]: thread t owns row t >> 1, k-half t & 1 = 32 consecutive values, fetched as 16 (+1) aligned dwords and shifted by one
-//     half-word with v_alignbyte when the row starts on an odd element; values with k >= r or row >= m are zeroed.
-//   B tile [64 k][128 cols]: thread t owns the k-pair t & 31 and the 16 columns 16 (t >> 5) .. +15 (two rows x 32 bytes, 16-byte loads: needs
-//     n % 8 == 0 and a 16-byte aligned pointer — the entry point takes the three-launch path otherwise), packs (k, k + 1) per column into one
-//     32-bit word with v_perm and writes it to the K-CONTIGUOUS image [col][k]: the transpose costs 16 ds_write_b32 per thread and chunk.
-//   Both images have a row stride of 72 half-words (144 B): the row-per-lane ds_read_b128 of a 16-lane group and the 32 word-writes of a
-//   half-wave fall on distinct banks.  Two image sets (2 x 36 KB): the loads of chunk it + 1 are issued before the 16 MFMAs of chunk it and written
+//   A tile [128 rows][64 k]: a half-wave reads the 32 aligned dwords that hold one row's 64 values (one coalesced 128-byte segment per load;
+//     thread (t >> 5, t & 31) owns dword t & 31 of the rows (t >> 5) + 8 j); a row that starts on an odd element (r odd) is shifted by one half-word
+//     with v_alignbyte against the following dword (a second, overlapping load); values with k >= r or row >= m are zeroed.
+//   B tile [64 k][128 cols]: 16 lanes read the 256 contiguous bytes of one k row (16-byte loads: needs n % 8 == 0 and a 16-byte aligned pointer —
+//     the entry point takes the three-launch path otherwise); a thread holds rows (2 p, 2 p + 1) of its 8 columns, packs (k, k + 1) per column into
+//     one 32-bit word with v_perm and writes it to the K-CONTIGUOUS image [col][k]: the transpose costs 16 ds_write_b32 per thread and chunk (their
+//     bank conflicts — the row stride must keep ds_read_b128 aligned — cost LDS cycles the matrix pipe does not wait for).
+//   Both images have a row stride of 72 half-words (144 B): the row-per-lane ds_read_b128 of a 16-lane group falls on distinct banks.  Two image sets (2 x 36 KB): the loads of chunk it + 1 are issued before the 16 MFMAs of chunk it and written
 //   to the other set after them — one barrier per chunk.
 constexpr int R16_LD = 72;                       // half-words per image row
 constexpr int R16_IMG = 128 * R16_LD;            // half-words per image
@@ -467,54 +468,67 @@ __global__ __launch_bounds__(256, 2) void recon_err16_fused_kernel(const void* _
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wr = w >> 1, wc = w & 1;
     const int h = lane >> 5, c = lane & 31;
     const int64_t R0 = (int64_t)blockIdx.y * 128, C0 = (int64_t)blockIdx.x * 128;
-    // ---- A fetch geometry ----
-    const int arow = tid >> 1, ahalf = tid & 1;
-    const int64_t grow = R0 + arow;
-    const bool arow_ok = grow < m;
-    const int64_t ebase = (arow_ok ? grow : m - 1) * r + 32 * ahalf;     // element index of k = k0 + 32 ahalf at k0 = 0
+    // ---- A fetch geometry: the 32 lanes of a half-wave read ONE row's 32 dwords (a whole 128-byte segment per load instruction); thread
+    // (rg = tid >> 5, l = tid & 31) owns dword l of rows rg + 8 j, j = 0..15.  A row that starts on an odd element needs the following dword too
+    // (second, overlapping load: L1 hits) — only when r is odd ----
+    const int arg = tid >> 5, al = tid & 31;
     const uint32_t* __restrict__ A32 = (const uint32_t*)A;
     const int64_t last_dw = (m * r - 1) >> 1;
-    // ---- B fetch geometry ----
-    const int bkp = tid & 31, bcg = tid >> 5;
-    const int64_t bcol = C0 + 16 * bcg;
-    uint32_t ra[17], rb[2][8];
+    const bool r_odd = (r & 1) != 0;
+    // ---- B fetch geometry: 16 lanes read 256 contiguous bytes (128 columns) of one k row; thread (p4 = tid >> 4, cl = tid & 15) owns the 8 columns
+    // 8 cl .. + 7 of the row pairs (2 p, 2 p + 1), p = p4 + 16 jj ----
+    const int bp4 = tid >> 4, bcl = tid & 15;
+    const int64_t bcol = C0 + 8 * bcl;
+    const bool bcol_ok = bcol < n;
+    // (Measured, round 6: 104 us per launch at 4096^2, r = 512 = 165 TFLOP/s — every chunk iteration runs at the memory latency, the loads have the
+    // 16 MFMAs of one chunk to arrive.  A second register set with the loads issued two chunks ahead needs 256 VGPRs + 3.8 KB of scratch per lane
+    // as written here — the per-row clamped 64-bit addresses — and was taken out again: no kernel of this library uses scratch.)
+    uint32_t ra[16], ra2[16], rb[2][2][4];
     auto fetch = [&](int64_t k0) {
-        const int64_t e = ebase + k0;
-        const int64_t d0 = e >> 1;
 #pragma unroll
-        for (int i = 0; i < 17; ++i) ra[i] = A32[min(d0 + i, last_dw)];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int64_t k = k0 + 2 * bkp + q;
-            const uint16_t* src = B + min(k, r - 1) * n + bcol;
-#pragma unroll
-            for (int v = 0; v < 2; ++v) {
-                u32x4 x = (u32x4){0u, 0u, 0u, 0u};
-                if (k < r && bcol + 8 * v < n) x = *(const u32x4*)(src + 8 * v);
-                rb[q][4 * v + 0] = x[0]; rb[q][4 * v + 1] = x[1]; rb[q][4 * v + 2] = x[2]; rb[q][4 * v + 3] = x[3];
-            }
+        for (int j = 0; j < 16; ++j) {
+            const int64_t grow = min(R0 + arg + 8 * j, m - 1);
+            const int64_t d0 = ((grow * r + k0) >> 1) + al;
+            ra[j] = A32[min(d0, last_dw)];
+            if (r_odd) ra2[j] = A32[min(d0 + 1, last_dw)];
         }
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int64_t k = k0 + 2 * (bp4 + 16 * jj) + q;
+                u32x4 x = (u32x4){0u, 0u, 0u, 0u};
+                if (k < r && bcol_ok) x = *(const u32x4*)(B + k * n + bcol);
+                rb[jj][q][0] = x[0]; rb[jj][q][1] = x[1]; rb[jj][q][2] = x[2]; rb[jj][q][3] = x[3];
+            }
     };
     auto stash = [&](int set, int64_t k0) {
-        // A: 32 values of one row -> 16 words at [row][32 ahalf ..]
-        const int par = (int)((ebase + k0) & 1);
-        uint32_t* da = (uint32_t*)(img[set][0] + arow * R16_LD + 32 * ahalf);
-        const int64_t kbase = k0 + 32 * ahalf;
+        // A: one word (k = k0 + 2 l, + 1) of 16 rows -> [row][2 l]; consecutive lanes write consecutive words
+        const int64_t k = k0 + 2 * al;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            uint32_t v = __builtin_amdgcn_alignbyte(ra[i + 1], ra[i], 2 * par);
-            const int64_t k = kbase + 2 * i;
-            if (!arow_ok || k >= r) v = 0u;
+        for (int j = 0; j < 16; ++j) {
+            const int row = arg + 8 * j;
+            const int64_t grow = R0 + row;
+            uint32_t v = ra[j];
+            if (r_odd) {
+                const int par = (int)((min(grow, m - 1) * r + k0) & 1);
+                v = __builtin_amdgcn_alignbyte(ra2[j], ra[j], 2 * par);
+            }
+            if (grow >= m || k >= r) v = 0u;
             else if (k + 1 >= r) v &= 0x0000ffffu;
-            da[i] = v;
+            *(uint32_t*)(img[set][0] + row * R16_LD + 2 * al) = v;
         }
-        // B: (k, k + 1) of 16 columns -> one word per column at [col][2 bkp]
+        // B: (k, k + 1) of 8 columns -> one word per column at [col][2 p]
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const uint32_t lo = __builtin_amdgcn_perm(rb[1][j], rb[0][j], 0x05040100u);   // {row1.lo16 : row0.lo16} = column 2j
-            const uint32_t hi = __builtin_amdgcn_perm(rb[1][j], rb[0][j], 0x07060302u);   // {row1.hi16 : row0.hi16} = column 2j + 1
-            *(uint32_t*)(img[set][1] + (16 * bcg + 2 * j) * R16_LD + 2 * bkp) = lo;
-            *(uint32_t*)(img[set][1] + (16 * bcg + 2 * j + 1) * R16_LD + 2 * bkp) = hi;
+        for (int jj = 0; jj < 2; ++jj) {
+            const int p_ = bp4 + 16 * jj;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t lo = __builtin_amdgcn_perm(rb[jj][1][j], rb[jj][0][j], 0x05040100u);   // {row1.lo16 : row0.lo16} = column 2j
+                const uint32_t hi = __builtin_amdgcn_perm(rb[jj][1][j], rb[jj][0][j], 0x07060302u);   // {row1.hi16 : row0.hi16} = column 2j + 1
+                *(uint32_t*)(img[set][1] + (8 * bcl + 2 * j) * R16_LD + 2 * p_) = lo;
+                *(uint32_t*)(img[set][1] + (8 * bcl + 2 * j + 1) * R16_LD + 2 * p_) = hi;
+            }
         }
     };
     f32x16 acc[2][2];
@@ -523,12 +537,7 @@ __global__ __launch_bounds__(256, 2) void recon_err16_fused_kernel(const void* _
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16){0};
     const int64_t nit = (r + 63) / 64;
-    fetch(0);
-    stash(0, 0);
-    __syncthreads();
-    for (int64_t it = 0; it < nit; ++it) {
-        const int set = (int)(it & 1);
-        if (it + 1 < nit) fetch((it + 1) * 64);
+    auto mma = [&](int set) __attribute__((always_inline)) {
         const uint16_t* ia = img[set][0] + (64 * wr + c) * R16_LD + 8 * h;
         const uint16_t* ib = img[set][1] + (64 * wc + c) * R16_LD + 8 * h;
 #pragma unroll
@@ -547,6 +556,14 @@ __global__ __launch_bounds__(256, 2) void recon_err16_fused_kernel(const void* _
                     else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a[i]), __builtin_bit_cast(h16x8, b[j]), acc[i][j], 0, 0, 0);
                 }
         }
+    };
+    fetch(0);
+    stash(0, 0);
+    __syncthreads();
+    for (int64_t it = 0; it < nit; ++it) {
+        const int set = (int)(it & 1);
+        if (it + 1 < nit) fetch((it + 1) * 64);
+        mma(set);
         if (it + 1 < nit) stash(set ^ 1, (it + 1) * 64);   // the other set: its last readers passed the barrier of the previous iteration
         __syncthreads();
     }

@@ -224,9 +224,12 @@ int asvd_fro_norm_sq(const void* w, int w_dtype, int64_t m, int64_t n, int64_t l
  * K9  parity evidence (new; no reference counterpart — BASELINE.json north_star "reconstructed W <= 1e-3 Frobenius"):
  *        err2 = |W - A*B|_F^2 , w2 = |W|_F^2      (A, B = ALinear.weight, BLinear.weight of an SVDLinear: svd_linear.py:8-24)
  *   W [m, n] in w_dtype (ldw), A [m, r], B [r, n] contiguous in ab_dtype.  F16 / BF16 factors: tiled GEMM on the fp16 / bf16 matrix pipe
- *   (products of 16-bit factors are exact there, fp32 accumulation) fused with the squared-difference reduction in fp64, 2 m n r flop;
- *   F32 factors: fp32 MFMA, one wave per 32x32 tile.  out: device double[2] = {err2, w2}.  work: asvd_reconstruct_worksize(m, n, r)
- *   bytes (partial sums + zero-padded K-contiguous copies of 16-bit factors).  Asynchronous. */
+ *   (products of 16-bit factors are exact there, fp32 accumulation) fused with the squared-difference reduction in fp64, 2 m n r flop.  When
+ *   n % 8 == 0 and B is 16-byte aligned (every Linear of the models this path serves) the GEMM reads the factors AS STORED — A rows at any 2-byte
+ *   alignment (odd ranks), B transposed on its way into LDS: ONE GEMM launch + the ordered sum of its partials; A is read in aligned 4-byte words, so
+ *   its allocation must be readable up to the next 4-byte boundary.  Otherwise: zero-padded K-contiguous copies in the workspace first (two more
+ *   launches).  F32 factors: fp32 MFMA, one wave per 32x32 tile.  out: device double[2] = {err2, w2}.  work: asvd_reconstruct_worksize(m, n, r)
+ *   bytes (partial sums + room for the padded copies).  Asynchronous. */
 int asvd_reconstruct_worksize(int64_t m, int64_t n, int64_t r, size_t* bytes);
 int asvd_reconstruct_err(const void* W, int w_dtype, int64_t ldw, const void* A, const void* B, int ab_dtype,
                          int64_t m, int64_t n, int64_t r, double* out, void* work, size_t work_bytes, void* stream);
