@@ -128,9 +128,11 @@ def build_parser():
     parser.add_argument("--no_fused_ratios", dest="fused_ratios", action="store_false",
                         help="evaluate every candidate ratio of a layer in its own suffix pass (default: all ratios as one batched pass; "
                              "same search trace, perplexities equal to ~1e-4 relative in fp16)")
-    parser.add_argument("--sweep_samples_per_pass", type=int, default=4,
-                        help="calibration samples per batched suffix pass of the sensitivity sweep (ratios x samples rows per GEMM; 1 = one sample per "
-                             "pass as in rounds 2-5; perplexities equal to ~1e-4 relative in fp16, same per-sample arithmetic)")
+    parser.add_argument("--sweep_samples_per_pass", type=int, default=1,
+                        help="calibration samples per batched suffix pass of the sensitivity sweep (ratios x samples rows per GEMM).  1 (default) keeps the "
+                             "perplexities and the search trace of rounds 2-5 bit for bit; 4 shortens the Llama-2-7B-shaped sweep by 6.5 %% (712 vs 762 s, "
+                             "profiles/r6_e2e_llama2_7b_ncalib32_*.json) with the same per-sample arithmetic on 4x taller GEMMs: perplexities equal to "
+                             "<= 5e-4 relative in fp16, which can reorder near-tied layers in the search")
     parser.add_argument("--gather_factors", type=str, default="rank0", choices=["rank0", "all", "none"],
                         help="--dist: after the sharded decomposition send every layer's A/B factors to rank 0 (point-to-point), to all ranks "
                              "(broadcast), or nowhere")

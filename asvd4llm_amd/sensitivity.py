@@ -120,7 +120,7 @@ def calib_sensitivity_ppl(model, calib_loader, args, use_cache=True):
             if multi is not None:
                 setattr(info["father"], info["name"], multi)
                 try:
-                    ppls = evaluator.perplexities(info["full_name"], multi, samples_per_pass=getattr(args, "sweep_samples_per_pass", 4))
+                    ppls = evaluator.perplexities(info["full_name"], multi, samples_per_pass=getattr(args, "sweep_samples_per_pass", 1))
                 except (RuntimeError, AssertionError, ValueError, TypeError) as e:
                     # a model that rejects the R-fold batch (attention-mask batch checks of older architectures, out of memory on the
                     # R x T x V logits of the 19-ratio kv sweep): the evaluator has restored its hooks and blocks; use the per-ratio path
