@@ -134,10 +134,9 @@ def binary_search_truncation_rank(model, sensitivity_dict, calib_loader, args):
     model._asvd_layers_min_ratio = layers_min_ratio
 
 
-def _decompose(model, modules, linear_info, layers_min_ratio, default_ratio, from_linear_kw, args, rank, ws):
-    """Swap in the factorised layers of the chosen plan (reference: binary_search.py:111-131, which also times this stage)."""
+def _decompose_owner_map(model, linear_info, args, ws, shard):
+    """{full_name: owning rank} of the final decomposition — identical on every rank."""
     # ownership under the same LPT map as the sweep (all Linears in traversal order)
-    shard = ws > 1 and getattr(args, "shard_decompose", True)
     linears = list(linear_info.items())
     owner_list = parallel.lpt_assign([parallel.svd_flops(l.out_features, l.in_features) for l, _ in linears], ws)
     owner = {info["full_name"]: o for (_, info), o in zip(linears, owner_list)}
@@ -145,9 +144,22 @@ def _decompose(model, modules, linear_info, layers_min_ratio, default_ratio, fro
     # with those owners: follow that map (slicing a cached factorisation is ~1 ms; the map above would re-factorise on another rank).  The map
     # is a deterministic function of the model and the arguments, so it is identical on every rank; a sensitivity dict that came from a
     # cache file or from the stable-rank metric has no such map and the decomposition is balanced on its own cost, the SVD flops.
+    # Followed ONLY while those caches exist: the sweep's map is balanced on suffix-forward seconds — ranks that own late-block layers hold
+    # many more layers — so with keep_svd_cache off, or on a model object whose arguments changed since the sweep, every layer would be re-factorised
+    # under a shard that is badly unbalanced for SVD flops.  The test uses what the sweep recorded (identical on every rank), not rank-local state.
     sweep_owner = getattr(model, "_asvd_sweep_owner", None)
-    if shard and sweep_owner is not None and set(sweep_owner) == set(owner) and max(sweep_owner.values()) < ws:
+    meta = getattr(model, "_asvd_sweep_owner_meta", None) or {}
+    caches_live = (meta.get("factors_kept") is True and meta.get("alpha") == getattr(args, "alpha", None)
+                   and meta.get("scaling_method") == getattr(args, "scaling_method", None) and meta.get("world_size") == ws)
+    if shard and sweep_owner is not None and caches_live and set(sweep_owner) == set(owner) and max(sweep_owner.values()) < ws:
         owner = dict(sweep_owner)
+    return owner
+
+
+def _decompose(model, modules, linear_info, layers_min_ratio, default_ratio, from_linear_kw, args, rank, ws):
+    """Swap in the factorised layers of the chosen plan (reference: binary_search.py:111-131, which also times this stage)."""
+    shard = ws > 1 and getattr(args, "shard_decompose", True)
+    owner = _decompose_owner_map(model, linear_info, args, ws, shard)
     # tied weights (OPT: lm_head.weight IS embed_tokens.weight): the reference's `raw_linear.to("cpu")` would drag the embedding to the
     # CPU with it and break the next forward; only weights no other module shares are offloaded
     uses = {}

@@ -91,6 +91,9 @@ def calib_sensitivity_ppl(model, calib_loader, args, use_cache=True):
     model._asvd_sweep_owner = {n: o for n, o in zip(names, owner)}   # the factor caches live with these owners: the final decomposition follows them
     model._asvd_sweep_balance = {"predicted_seconds_per_rank_max_over_mean": parallel.load_balance(costs, owner, ws), "world_size": ws}
     keep_cache = getattr(args, "keep_svd_cache", True)
+    # what the final decomposition needs to know before it follows this map (binary_search._decompose): the factorisations stay cached with their
+    # owners only under keep_svd_cache, and only for these arguments — the same values on every rank, so every rank decides alike
+    model._asvd_sweep_owner_meta = {"factors_kept": bool(keep_cache), "alpha": args.alpha, "scaling_method": args.scaling_method, "world_size": ws}
 
     local = {}
     n_mine = sum(1 for o in owner if o == rank)

@@ -564,7 +564,7 @@ def main():
                                         "frac_of_8TBps": (sum(bytes8) / (ov["union"] * 1e-3) / 8e12) if ov["union"] else None,
                                         "note": "all fused update + Gram launches of both halves placed on one time axis (events against a common base event): "
                                                 "bytes of both halves / the time AT LEAST ONE half was inside such a launch"},
-                "kernel_trace": "profiles/r5_bench_kernel_stats_batch32_split_default.txt"}
+                "kernel_trace": "profiles/r6_bench_kernel_stats_batch32_split_default.txt"}
         roofline["dominant_by_total_time"] = dom_all
         roofline["pairs"] = pairs_cnt
         roofline["sweep_wall_ms"] = sweep_ms

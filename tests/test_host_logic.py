@@ -225,3 +225,31 @@ def test_every_profile_path_a_bench_string_cites_exists():
     assert cited, "bench.py cites its evidence"
     missing = sorted(c for c in cited if not glob.glob(os.path.join(ROOT, c)))
     assert not missing, f"bench.py / pmc_traffic.json cite files that are not in the tree: {missing}"
+
+
+def test_decomposition_follows_the_sweep_owner_map_only_while_the_factor_caches_exist():
+    """the sweep's shard is balanced on suffix-forward seconds (late-block layers are cheap: their owners hold many more layers), which
+    is the right map for the final decomposition only while the sweep's factorisations are still cached with those owners.  With keep_svd_cache
+    off, other arguments, or another world size the decomposition is balanced on its own cost, the SVD flops."""
+    import types
+    import torch.nn as nn
+    from asvd4llm_amd import parallel
+    from asvd4llm_amd.binary_search import _decompose_owner_map
+    lins = [nn.Linear(64, 64, bias=False) for _ in range(6)] + [nn.Linear(64, 176, bias=False) for _ in range(3)]
+    info = {l: {"full_name": f"l{i}"} for i, l in enumerate(lins)}
+    flops_map = {f"l{i}": o for i, o in enumerate(parallel.lpt_assign([parallel.svd_flops(l.out_features, l.in_features) for l in lins], 2))}
+    sweep_map = {f"l{i}": (0 if i < 2 else 1) for i in range(9)}      # deliberately lopsided
+    assert sweep_map != flops_map
+    args = types.SimpleNamespace(alpha=0.5, scaling_method="abs_mean", shard_decompose=True)
+    model = types.SimpleNamespace()
+    assert _decompose_owner_map(model, info, args, 2, True) == flops_map                       # no sweep ran in this process
+    model._asvd_sweep_owner = dict(sweep_map)
+    assert _decompose_owner_map(model, info, args, 2, True) == flops_map                       # a map without the record of what was kept: not trusted
+    model._asvd_sweep_owner_meta = {"factors_kept": True, "alpha": 0.5, "scaling_method": "abs_mean", "world_size": 2}
+    assert _decompose_owner_map(model, info, args, 2, True) == sweep_map                       # caches live: follow the sweep's owners
+    model._asvd_sweep_owner_meta["factors_kept"] = False
+    assert _decompose_owner_map(model, info, args, 2, True) == flops_map                       # --no keep_svd_cache: every layer is re-factorised
+    model._asvd_sweep_owner_meta = {"factors_kept": True, "alpha": 1.0, "scaling_method": "abs_mean", "world_size": 2}
+    assert _decompose_owner_map(model, info, args, 2, True) == flops_map                       # stale: the model was swept with another alpha
+    model._asvd_sweep_owner_meta = {"factors_kept": True, "alpha": 0.5, "scaling_method": "abs_mean", "world_size": 4}
+    assert _decompose_owner_map(model, info, args, 2, True) == flops_map                       # stale: another world size
