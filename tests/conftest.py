@@ -48,4 +48,7 @@ def gpu(built_lib):
     assert torch.cuda.is_available(), "GPU test selected but torch sees no device"
     _lib.load(require_device=True)
     os.environ["ASVD_STRICT"] = "1"
+    # the CPU oracle (LAPACK gesdd through torch) is fastest at ~16 threads on the GPU boxes' 256-thread hosts: 2.4 s per 4096^2 SVD against 13.8 s
+    # at 128 threads (bench.py's thread sweep, every round) — torch's default there is one thread per core
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
     return torch.device("cuda", 0)
