@@ -576,6 +576,11 @@ def main():
             "warmup": args.warmup, "prewarm_steps": prewarm_steps, "ms_per_step": 1e3 * dt / args.steps,
             "step_wall_ms": [1e3 * (b - a) for a, b in zip([t0] + step_marks[:-1], step_marks)], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "arithmetic": "fp32 in, fp32 U / S / V out (the rank-r factors are emitted in fp16); inside: fp64 MFMA for the Gram matrix and the Cholesky-QR, fp32 VALU for the "
+                          "64x64 eigen-solves, and the streaming products (dense-sweep update + Gram, coupling snapshot) as THREE fp16 MFMA products per fp32 product with "
+                          "power-of-two column scales (2^-22 relative per product), the long-side GEMM as six bf16 products (2^-24): fp32-equivalent by measurement, not by "
+                          "construction — per-column error against fp64 in tests/test_gpu_twolevel.py, whole-SVD parity on flat AND graded / clustered inputs in "
+                          "tests/test_gpu_svd.py / test_gpu_families.py",
             "config": {"workload": f"{B} synthetic {m}x{n} fp32 Linears per GPU per step, abs_mean scaling (alpha 0.5), full SVD + rank-{r} truncation, factors emitted in fp16 (SURVEY 8d; the reference would emit the Linear's own dtype, svd_linear.py:102 - the cast is <0.1% of a step)",
                        "batch_per_gpu": B, "m": m, "n": n, "rank": r, "parallelism": f"independent matrices x{world}",
                        "batch_split_over_chip_halves": bool(any(i.split for i in timed_infos)),
