@@ -122,7 +122,7 @@ def test_mixed_schedules_concurrently(gpu):
 @pytest.mark.timeout(900)
 def test_split_batch_on_two_chip_halves_matches_the_unsplit_call(gpu, monkeypatch):
     """asvd_svd_batched runs a batch of >= 4 problems with >= 3072 columns as two halves, each on its own host thread and on a stream masked
-    to one half of the CUs (csrc/svd_jacobi.hip, split_streams).  Same singular values and vectors as the unsplit call up to fp32 rounding
+    to one half of the CUs (csrc/svd_jacobi.hip, SplitCtx: the second half on the persistent worker thread of the calling thread).  Same singular values and vectors as the unsplit call up to fp32 rounding
     (the halves are planned for 128 CUs: other row splits, other summation orders), every problem converged, run-to-run deterministic,
     the info block of every problem filled, and ASVD_SPLIT=0 restores the one-stream call."""
     from asvd4llm_amd import ops
