@@ -421,6 +421,51 @@ def test_rccl_world1_allgather_and_exchange():
 
 
 @pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_rccl_subgroup_under_a_gloo_default_group():
+    """bench.py's arrangement at N > 1 (round 6): the DEFAULT group is gloo (timing barriers, MAX-reduce, bookkeeping on host tensors) and the path's
+    collectives run on a separate RCCL group that parallel.GROUP points at.  World size 1 on the one GPU there is: host collectives on the default
+    group, the probe all-reduce + the sensitivity all-gather + the factor broadcast on the RCCL group, then back to the default group."""
+    import torch.distributed as dist
+    from asvd4llm_amd import parallel
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(31000 + os.getpid() % 2000)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        assert parallel.backend() == "gloo" and parallel._comm_device().type == "cpu"
+        t = torch.tensor([3.5], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)          # the timing reduction of bench.py: a host tensor on the default group
+        dist.barrier()
+        grp = dist.new_group(backend="nccl")
+        probe = torch.ones(1, device="cuda")
+        dist.all_reduce(probe, group=grp)
+        torch.cuda.synchronize()
+        assert int(probe.item()) == 1
+        parallel.set_group(grp)
+        assert parallel.backend() == "nccl" and parallel._comm_device().type == "cuda" and parallel.world() == (0, 1)
+        names, ratios = ["a", "b"], [0.4, 0.9]
+        local = {"a": {0.4: 1.25, 0.9: float("nan")}, "b": {0.4: float("inf"), 0.9: 3.000000123}}
+        full = parallel.allgather_sensitivities(local, names, ratios, [0, 0])
+        for n in names:
+            for r in ratios:
+                a, b = full[n][r], local[n][r]
+                assert (a != a and b != b) or a == b
+        lin = torch.nn.Linear(64, 48, bias=True).half().cuda()
+        from asvd4llm_amd.modules.svd_linear import SVDLinear
+        father = torch.nn.Module()
+        father.x = SVDLinear._from_factors(torch.randn(48, 8, device="cuda").half(), torch.randn(8, 64, device="cuda").half(), lin.bias.data, 8)
+        assert parallel.exchange_factors([("x", father, "x", lin)], {"x": 0}, mode="all") == 0
+        torch.cuda.synchronize()
+        parallel.set_group(None)
+        assert parallel.backend() == "gloo"
+        dist.barrier()
+    finally:
+        parallel.set_group(None)
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
 def test_fisher_calibration_vs_reference_fixture(gpu, golden, tmp_path, monkeypatch):
     """calib_fisher_info (backward in torch, per-channel statistic in asvd_absstat_accum sq_mean) against the fisher_info the imported
     reference computed for the same weights and token ids (tests/golden/fisher.npz).  fp32 model; tolerance 1e-5 relative (the kernel

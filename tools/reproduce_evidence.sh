@@ -14,13 +14,17 @@ python -c "import __graft_entry__ as g; g.build(); g.smoke()" 2>&1 | tail -1
 [ "${1:-all}" = quick ] && exit 0
 # rocprofv3 kernel stats + FETCH/WRITE/MFMA counter passes of the bench workload alone (no model leg), UNSPLIT: every kernel alone on the chip — what
 # bench.py's `roofline` quotes (its profiled step is never split); then the kernel trace of the product default (two half-batch streams): overlap factor
-BENCH_ARGS="--sharded_model none" ASVD_SPLIT=0 PMC_BATCH=32 bash tools/prof_final.sh repro > gpurun_out/prof_repro.log 2>&1
+# PMC_STEPS: steps of the workload inside one counter pass (`bench.py --steps 1 --warmup 0 --prewarm_s 0` under ASVD_SPLIT=0 = the timed step + the unsplit profiled
+# step); PMC_TAG: the name the pmc_*.txt files get under profiles/ (pmc_traffic.json:source points there; tests/test_host_logic.py checks that it resolves)
+BENCH_ARGS="--sharded_model none" ASVD_SPLIT=0 PMC_BATCH=32 PMC_STEPS=2 PMC_TAG=${PMC_TAG:-repro} bash tools/prof_final.sh repro > gpurun_out/prof_repro.log 2>&1
 ( cd /tmp; export TMPDIR=/tmp; R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; rm -rf gpurun_out/kt_split
   rocprofv3 --kernel-trace --stats -d gpurun_out/kt_split -- python bench.py --no_cpu_baseline --no_latency --sharded_model none --steps 3 --warmup 1 --prewarm_s 2 > /dev/null 2> gpurun_out/kt_split.log
   DB=$(find gpurun_out/kt_split -name "*.db" | head -1)
   python tools/rocpd_stats.py $DB | head -24 > gpurun_out/kernel_stats_split.txt; python tools/rocpd_overlap.py $DB | tail -2 >> gpurun_out/kernel_stats_split.txt; rm -rf gpurun_out/kt_split )
 for w in idle mfma supgram supgram_ni bench; do python tools/power_probe.py --workload $w --seconds 6 --out gpurun_out/power.jsonl > /dev/null 2>&1; done   # socket power / clock / cap
 python tools/bench_supgram.py > gpurun_out/supgram_micro.jsonl 2> /dev/null
+python tools/bench_families.py > gpurun_out/families.txt 2> /dev/null          # sweeps and SVD/s per input family (round 6)
+python tools/sweep_gemm_ceiling.py > gpurun_out/sweep_gemm_ceiling.txt 2> /dev/null
 [ "${1:-all}" = prof ] && exit 0
 python tools/full_model_bench.py --model llama-2-7b 2>/dev/null | tail -1 > gpurun_out/full_7b.json
 python tools/full_model_bench.py --model llama-2-13b 2>/dev/null | tail -1 > gpurun_out/full_13b.json
