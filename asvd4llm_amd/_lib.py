@@ -51,6 +51,7 @@ SIGNATURES = {
     "asvd_reconstruct_err": (_i, [_vp, _i, _i64, _vp, _vp, _i, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
     "asvd_test_supdate": (_i, [_vp, _i64, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "asvd_test_supgram": (_i, [_vp, _i64, _i64, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "asvd_test_gram": (_i, [_vp, _i64, _i64, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp, _vp]),
     "asvd_test_super_schedule": (_i, [_i, _i, _vp, _i, _c.POINTER(_i), _c.POINTER(_i)]),
     "asvd_test_evd_wave": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "asvd_svd_get_last_path": (_i, []),

@@ -56,6 +56,7 @@ using namespace asvdk;
 
 #include "jacobi_kernels.h"
 #include "tall_kernels.h"
+#include "gram_i8.h"
 
 // --------------------------------------------------------------------------------------------------
 // ASVD_ORDER=rr: round-robin tournament instead of the XOR pair schedule (A/B measurements; single-level sweeps only)
@@ -1012,6 +1013,39 @@ static bool tall_wanted(const Plan& p) {
     return p.cols >= 128;
 }
 
+static bool gram_i8_wanted() {
+    const char* e = getenv("ASVD_GRAM_I8");   // read per call: tests and A/B runs toggle it inside one process
+    return !(e && atoi(e) == 0);
+}
+
+// G (upper 32-blocks) = X^T X of the packed panels through the int8 digit planes (gram_i8.h).  scratch: >= 3 * n_pad * 64 * batch bytes; the
+// rows go in segments of what fits (and of at most 32768 rows: the int32 accumulators), each added to G in fp64.  ex: n_pad ints per problem.
+static int launch_gram_i8(const float* Xp, int64_t panel_stride, int64_t batch_stride, int nb, int m_pad, int n_pad, int batch, double* G,
+                          int64_t ldg, int64_t gbs, signed char* scratch, size_t scratch_bytes, int* ex, int seg_rows_max, hipStream_t st) {
+    int64_t cap_rows = (int64_t)(scratch_bytes / ((size_t)3 * n_pad * batch)) / 64 * 64;
+    if (cap_rows > 32768) cap_rows = 32768;
+    if (seg_rows_max >= 64 && cap_rows > seg_rows_max / 64 * 64) cap_rows = seg_rows_max / 64 * 64;
+    if (cap_rows < 64) return ASVD_E_WORKSPACE;
+    const int64_t m64 = round_up64(m_pad, 64);
+    const int nseg = (int)ceil_div64(m64, cap_rows);
+    const int seg = (int)round_up64(ceil_div64(m64, nseg), 64);
+    ASVD_HIP_CHECK(hipFuncSetAttribute((const void*)gram_i8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GI_STAGE_BYTES));
+    colmaxexp_kernel<<<dim3(nb, batch), 256, 0, st>>>(Xp, panel_stride, batch_stride, m_pad, n_pad, ex);
+    const int nt = (nb + 3) / 4, ntri = nt * (nt + 1) / 2;
+    for (int s = 0; s < nseg; ++s) {
+        const int r0 = s * seg;
+        const int rows = (int)std::min<int64_t>(seg, m64 - r0);
+        if (rows <= 0) break;
+        const int kgs = rows / 16;
+        const int64_t plane_stride = (int64_t)nb * kgs * 512;
+        split_i8_kernel<<<dim3((unsigned)ceil_div64(kgs, 8), nb, batch), 256, 0, st>>>(Xp, panel_stride, batch_stride, nb, m_pad, n_pad, ex, r0, kgs,
+                                                                                       scratch, plane_stride);
+        gram_i8_kernel<<<dim3(ntri, batch), 512, 2 * GI_STAGE_BYTES, st>>>(scratch, plane_stride, nb, kgs, n_pad, ex, G, ldg, gbs, s > 0 ? 1 : 0, nt);
+    }
+    ASVD_HIP_CHECK(hipGetLastError());
+    return ASVD_OK;
+}
+
 struct TallLayout {
     size_t off_xp, off_g, off_gs, off_dp, off_df, off_perm, off_dg, off_d, off_fail, off_r, off_vr, off_part, off_inv, off_inner, inner_bytes, total;
     int n_pad64;
@@ -1097,7 +1131,15 @@ static int svd_tall(int batch, const void* const* a_host, int a_dtype, int64_t m
             }
             if (prc) return prc;
         }
-        gram64_kernel<<<dim3(p.nb, (unsigned)ceil_div64(p.nb, 4), batch), 256, 0, st>>>(Xp, p.panel_stride, p.batch_stride, p.nb, p.m_pad, G, ldg, gbs);
+        // G = X^T X: exact integer arithmetic on the int8 matrix pipe (gram_i8.h; the digit planes live in Gs and the exponents in cperm, both
+        // written only after the Gram matrix is complete), or the fp64 matrix instructions (ASVD_GRAM_I8=0)
+        if (gram_i8_wanted()) {
+            rc = launch_gram_i8(Xp, p.panel_stride, p.batch_stride, p.nb, p.m_pad, p.n_pad, batch, G, ldg, gbs, (signed char*)Gs,
+                                (size_t)gbs * batch * sizeof(double), cperm, 0, st);
+            if (rc) return rc;
+        } else {
+            gram64_kernel<<<dim3(p.nb, (unsigned)ceil_div64(p.nb, 4), batch), 256, 0, st>>>(Xp, p.panel_stride, p.batch_stride, p.nb, p.m_pad, G, ldg, gbs);
+        }
         chol_diag_kernel<<<dim3((unsigned)ceil_div64(p.n_pad, 256), batch), 256, 0, st>>>(G, ldg, gbs, p.n_pad, d);
         // sort columns by decreasing norm (stable, padding last; 14 -> 10 sweeps, unsorted saves nothing), permute + unit-scale the Gram matrix
         d_to_float_kernel<<<(unsigned)ceil_div64((int64_t)p.n_pad * batch, 256), 256, 0, st>>>(d, p.n_pad * batch, dF);
@@ -1188,6 +1230,23 @@ int asvd_test_supdate(float* X, int64_t panel_stride, int64_t batch_stride, int 
     supdate_split_kernel<<<dim3(nchunks, npairs, batch), 256, 0, st>>>(sc, X, panel_stride, batch_stride, ns, D, R, rows_per_wg, Qfin, subact, done, nupd);
     ASVD_HIP_CHECK(hipGetLastError());
     return ASVD_OK;
+}
+
+// Test hook: the Gram matrix of the reduction alone.  mode 0: gram64_kernel; 1: the int8 digit path (scratch / ex as launch_gram_i8, rows in
+// segments of at most seg_rows when >= 64).
+int asvd_test_gram(const float* Xp, int64_t panel_stride, int64_t batch_stride, int nb, int m_pad, int batch, int mode, int seg_rows, double* G,
+                   void* scratch, size_t scratch_bytes, int* ex, void* stream) {
+    if (!Xp || !G || nb < 1 || m_pad < 32 || (m_pad % 32) || batch < 1) return ASVD_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int n_pad = nb * PB;
+    if (mode == 0) {
+        gram64_kernel<<<dim3(nb, (unsigned)ceil_div64(nb, 4), batch), 256, 0, st>>>(Xp, panel_stride, batch_stride, nb, m_pad, G, n_pad, (int64_t)n_pad * n_pad);
+        ASVD_HIP_CHECK(hipGetLastError());
+        return ASVD_OK;
+    }
+    if (!scratch || !ex) return ASVD_E_BADARG;
+    return launch_gram_i8(Xp, panel_stride, batch_stride, nb, m_pad, n_pad, batch, G, n_pad, (int64_t)n_pad * n_pad, (signed char*)scratch, scratch_bytes, ex,
+                          seg_rows, st);
 }
 
 // Test hook: the super-panel pair schedule itself.  out[step * npairs + k] = (S << 16) | T of slot k of super-step `step`, or -1 for an empty

@@ -316,6 +316,13 @@ int asvd_test_supdate(float* X, int64_t panel_stride, int64_t batch_stride, int 
 int asvd_test_supgram(float* X, int64_t panel_stride, int64_t batch_stride, int ns, int D, int E, int R, int m_pad, int rows_per_wg,
                       const float* Qfin, const int* subact, const float* Din, float* Gx, const int* done, int* nupd, int nchunks, int npairs,
                       int batch, void* stream);
+/* Test hook: the Gram matrix G = X^T X of the Cholesky-QR reduction alone, on caller-built panels X [batch][nb][m_pad][32] (m_pad a multiple of
+ * 32).  G [batch][32 nb][32 nb] doubles, upper 32-blocks written.  mode 0: fp64 matrix instructions (gram64_kernel); mode 1: the exact int8
+ * digit path the library uses unless ASVD_GRAM_I8=0 (csrc/gram_i8.h): scratch >= 3 * 32 nb * 64 * batch bytes of device memory (digit planes:
+ * the rows go in segments of what fits, at most seg_rows when seg_rows >= 64), ex = 32 nb ints per problem (column exponents, left behind).
+ * tests/test_gpu_gram_i8.py only. */
+int asvd_test_gram(const float* Xp, int64_t panel_stride, int64_t batch_stride, int nb, int m_pad, int batch, int mode, int seg_rows, double* G,
+                   void* scratch, size_t scratch_bytes, int* ex, void* stream);
 /* Test hook: the super-panel pair schedule of the two-level sweeps for `ns` super-panels (grouped != 0: the grouped order where it applies,
  * else XOR).  out_dev: device int[out_capacity] >= nsteps * npairs; out[step * npairs + k] = (S << 16) | T or -1 (empty slot).
  * tests/test_gpu_twolevel.py only. */
