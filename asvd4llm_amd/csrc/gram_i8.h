@@ -24,24 +24,32 @@ typedef int i32x16 __attribute__((ext_vector_type(16)));
 constexpr int GI_BAD = 0x7fffffff;   // exponent sentinel: the column holds Inf / NaN
 constexpr int GI_ZERO = -0x40000000; // exponent of an all-zero column (digits are all zero, the scale does not matter)
 
-// ex[b][col] = E with  max_r |X[r][col]| 2^-E < 127/128  (grid: (nb, batch), 256 threads: lane = column, eight row lanes)
+// ex[b][col] = E with  max_r |X[r][col]| 2^-E < 127/128;  dn[b][col] (optional) = |x_col|_2 in fp64, fixed summation order
+// (grid: (nb, batch), 256 threads: lane = column, eight row lanes)
 __global__ __launch_bounds__(256) void colmaxexp_kernel(const float* __restrict__ X, int64_t panel_stride, int64_t batch_stride, int m_pad,
-                                                        int n_pad, int* __restrict__ ex) {
+                                                        int n_pad, int* __restrict__ ex, double* __restrict__ dn) {
     __shared__ unsigned smax[8][PB];
+    __shared__ double ssq[8][PB];
     const int P = blockIdx.x, b = blockIdx.y, c = threadIdx.x & 31, rl = threadIdx.x >> 5;
     const float* __restrict__ xp = X + (int64_t)b * batch_stride + (int64_t)P * panel_stride + c;
     unsigned mx = 0;
+    double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
     for (int r = rl; r < m_pad; r += 32) {  // m_pad is a multiple of 32: four independent loads per trip
-        const unsigned a0 = __float_as_uint(xp[(int64_t)r * PB]) & 0x7fffffffu, a1 = __float_as_uint(xp[(int64_t)(r + 8) * PB]) & 0x7fffffffu;
-        const unsigned a2 = __float_as_uint(xp[(int64_t)(r + 16) * PB]) & 0x7fffffffu, a3 = __float_as_uint(xp[(int64_t)(r + 24) * PB]) & 0x7fffffffu;
+        const float x0 = xp[(int64_t)r * PB], x1 = xp[(int64_t)(r + 8) * PB], x2 = xp[(int64_t)(r + 16) * PB], x3 = xp[(int64_t)(r + 24) * PB];
+        const unsigned a0 = __float_as_uint(x0) & 0x7fffffffu, a1 = __float_as_uint(x1) & 0x7fffffffu;
+        const unsigned a2 = __float_as_uint(x2) & 0x7fffffffu, a3 = __float_as_uint(x3) & 0x7fffffffu;
         const unsigned m01 = a0 > a1 ? a0 : a1, m23 = a2 > a3 ? a2 : a3, m4 = m01 > m23 ? m01 : m23;
         mx = mx > m4 ? mx : m4;  // magnitudes of finite floats order like their bit patterns; Inf / NaN patterns are above all of them
+        q0 = fma((double)x0, (double)x0, q0); q1 = fma((double)x1, (double)x1, q1);
+        q2 = fma((double)x2, (double)x2, q2); q3 = fma((double)x3, (double)x3, q3);
     }
     smax[rl][c] = mx;
+    ssq[rl][c] = (q0 + q1) + (q2 + q3);
     __syncthreads();
     if (rl == 0) {
+        double q = ssq[0][c];
 #pragma unroll
-        for (int i = 1; i < 8; ++i) mx = mx > smax[i][c] ? mx : smax[i][c];
+        for (int i = 1; i < 8; ++i) { mx = mx > smax[i][c] ? mx : smax[i][c]; q += ssq[i][c]; }
         int E;
         if (mx >= 0x7f800000u) E = GI_BAD;
         else if (mx == 0u) E = GI_ZERO;
@@ -51,21 +59,36 @@ __global__ __launch_bounds__(256) void colmaxexp_kernel(const float* __restrict_
             E = e2 + (f >= 127.0f / 128.0f ? 1 : 0);
         }
         ex[(int64_t)b * n_pad + P * PB + c] = E;
+        if (dn) dn[(int64_t)b * n_pad + P * PB + c] = sqrt(q);
     }
+}
+
+// exs[b][i] = ex[b][perm[b][i]], dp[b][i] = d[b][perm[b][i]]: exponents and norms in sorted-column order
+__global__ void perm_gather_kernel(const int* __restrict__ ex, const double* __restrict__ d, const int* __restrict__ perm, int n, int* __restrict__ exs,
+                                   double* __restrict__ dp) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int b = blockIdx.y;
+    const int q = perm[(int64_t)b * n + i];
+    exs[(int64_t)b * n + i] = ex[(int64_t)b * n + q];
+    dp[(int64_t)b * n + i] = d[(int64_t)b * n + q];
 }
 
 // Digit planes of the rows [r0, r0 + 16 kgs) of every problem:  planes[b][digit a][panel P][16-row group kg][column c][16 bytes = rows].
 // One (P, kg) piece of a digit is 512 contiguous bytes; two consecutive pieces are the A (or B) operand of one v_mfma_i32_32x32x32_i8 of a
 // wave: lane l = 32 (kg & 1) + c reads its 16 bytes at offset 16 l.  Rows >= m_pad are zero.
-// grid: (ceil(kgs / 8), nb, batch), 256 threads = 8 row groups x 32 columns.
+// grid: (nb, ceil(kgs / 8), batch), 256 threads = 8 row groups x 32 columns — panels fastest: with a column permutation every lane of a load reads
+// another panel's 128-byte row, and the workgroups that want the other 31 columns of those rows are the other panels of the SAME row range.
 __global__ __launch_bounds__(256) void split_i8_kernel(const float* __restrict__ X, int64_t panel_stride, int64_t batch_stride, int nb, int m_pad,
                                                        int n_pad, const int* __restrict__ ex, int r0, int kgs, signed char* __restrict__ planes,
-                                                       int64_t plane_stride /* bytes per digit and problem = nb kgs 512 */) {
-    const int P = blockIdx.y, b = blockIdx.z, c = threadIdx.x & 31;
-    const int kg = blockIdx.x * 8 + (threadIdx.x >> 5);
+                                                       int64_t plane_stride /* bytes per digit and problem = nb kgs 512 */,
+                                                       const int* __restrict__ perm /* nullable: plane column i holds column perm[i] of X; ex is in plane order */) {
+    const int P = blockIdx.x, b = blockIdx.z, c = threadIdx.x & 31;
+    const int kg = blockIdx.y * 8 + (threadIdx.x >> 5);
     if (kg >= kgs) return;
     const int E = ex[(int64_t)b * n_pad + P * PB + c];
-    const float* __restrict__ xp = X + (int64_t)b * batch_stride + (int64_t)P * panel_stride + c;
+    const int q = perm ? perm[(int64_t)b * n_pad + P * PB + c] : P * PB + c;
+    const float* __restrict__ xp = X + (int64_t)b * batch_stride + (int64_t)(q >> 5) * panel_stride + (q & 31);
     unsigned w0[4] = {0, 0, 0, 0}, w1[4] = {0, 0, 0, 0}, w2[4] = {0, 0, 0, 0};
     if (E != GI_BAD && E != GI_ZERO) {
 #pragma unroll
@@ -96,7 +119,8 @@ __global__ __launch_bounds__(256) void split_i8_kernel(const float* __restrict__
 constexpr int GI_STAGE_BYTES = 2 * 3 * 4 * 4 * 512;  // side, digit, panel, row group
 __global__ __launch_bounds__(512) void gram_i8_kernel(const signed char* __restrict__ planes, int64_t plane_stride, int nb, int kgs, int n_pad,
                                                       const int* __restrict__ ex, double* __restrict__ G, int64_t ldg, int64_t g_batch_stride,
-                                                      int accumulate, int nt) {
+                                                      int accumulate, int nt, const double* __restrict__ dp /* nullable: G_ij / (dp_i dp_j) is stored;
+                                                      a column with dp = 0 gets a unit diagonal and zeros */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char gi_lds[];  // 2 x GI_STAGE_BYTES
     // XCD-aware order: consecutive workgroup ids go round-robin over the 8 XCDs; give every XCD a contiguous run of blocks (they share I panels in its L2)
     // (a block count that is not a multiple of 8 keeps the plain order: correct, merely less local)
@@ -173,7 +197,8 @@ __global__ __launch_bounds__(512) void gram_i8_kernel(const signed char* __restr
     if (J >= nb) return;
     const int j = lane & 31;
     const int Ej = ex[(int64_t)b * n_pad + J * PB + j];
-    const double sj = Ej == GI_BAD ? __builtin_nan("") : (Ej == GI_ZERO ? 0.0 : ldexp(1.0, Ej - 23));
+    double sj = Ej == GI_BAD ? __builtin_nan("") : (Ej == GI_ZERO ? 0.0 : ldexp(1.0, Ej - 23));
+    if (dp) { const double dj = dp[(int64_t)b * n_pad + J * PB + j]; sj = dj > 0.0 ? sj / dj : (dj == 0.0 ? 0.0 : __builtin_nan("")); }
     double* __restrict__ out = G + (int64_t)b * g_batch_stride;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -183,7 +208,13 @@ __global__ __launch_bounds__(512) void gram_i8_kernel(const signed char* __restr
         for (int reg = 0; reg < 16; ++reg) {
             const int i = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
             const int Ei = ex[(int64_t)b * n_pad + I * PB + i];
-            const double si = Ei == GI_BAD ? __builtin_nan("") : (Ei == GI_ZERO ? 0.0 : ldexp(1.0, Ei - 23));
+            double si = Ei == GI_BAD ? __builtin_nan("") : (Ei == GI_ZERO ? 0.0 : ldexp(1.0, Ei - 23));
+            bool unit = false;
+            if (dp) {
+                const double di = dp[(int64_t)b * n_pad + I * PB + i];
+                si = di > 0.0 ? si / di : (di == 0.0 ? 0.0 : __builtin_nan(""));
+                unit = di == 0.0 && I == J && i == j;
+            }
             double v = (double)acc[t][4][reg];
             v += (double)acc[t][3][reg] * 256.0;
             v += (double)acc[t][2][reg] * 65536.0;
@@ -191,7 +222,8 @@ __global__ __launch_bounds__(512) void gram_i8_kernel(const signed char* __restr
             v += (double)acc[t][0][reg] * 4294967296.0;
             v = v * si * sj;
             const int64_t o = (int64_t)(I * PB + i) * ldg + J * PB + j;
-            out[o] = accumulate ? out[o] + v : v;
+            v = accumulate ? out[o] + v : v;
+            out[o] = unit ? 1.0 : v;
         }
     }
 }

@@ -57,6 +57,7 @@ using namespace asvdk;
 #include "jacobi_kernels.h"
 #include "tall_kernels.h"
 #include "gram_i8.h"
+#include "nn_gemm_i8.h"
 
 // --------------------------------------------------------------------------------------------------
 // ASVD_ORDER=rr: round-robin tournament instead of the XOR pair schedule (A/B measurements; single-level sweeps only)
@@ -1013,15 +1014,22 @@ static bool tall_wanted(const Plan& p) {
     return p.cols >= 128;
 }
 
+static bool nn_i8_wanted() {
+    const char* e = getenv("ASVD_NN_I8");   // read per call
+    return !(e && atoi(e) == 0);
+}
 static bool gram_i8_wanted() {
     const char* e = getenv("ASVD_GRAM_I8");   // read per call: tests and A/B runs toggle it inside one process
     return !(e && atoi(e) == 0);
 }
 
 // G (upper 32-blocks) = X^T X of the packed panels through the int8 digit planes (gram_i8.h).  scratch: >= 3 * n_pad * 64 * batch bytes; the
-// rows go in segments of what fits (and of at most 32768 rows: the int32 accumulators), each added to G in fp64.  ex: n_pad ints per problem.
+// rows go in segments of what fits (and of at most 32768 rows: the int32 accumulators), each added to G in fp64.  ex: n_pad column exponents per
+// problem (colmaxexp_kernel) IN PLANE ORDER.  perm / dp (both or neither): plane column i holds column perm[i] of X and G_ij / (dp_i dp_j) is
+// stored — the sorted, unit-scaled Gram matrix the Cholesky factorisation starts from, without a pass over an unsorted one.
 static int launch_gram_i8(const float* Xp, int64_t panel_stride, int64_t batch_stride, int nb, int m_pad, int n_pad, int batch, double* G,
-                          int64_t ldg, int64_t gbs, signed char* scratch, size_t scratch_bytes, int* ex, int seg_rows_max, hipStream_t st) {
+                          int64_t ldg, int64_t gbs, signed char* scratch, size_t scratch_bytes, const int* ex, const int* perm, const double* dp,
+                          int seg_rows_max, hipStream_t st) {
     int64_t cap_rows = (int64_t)(scratch_bytes / ((size_t)3 * n_pad * batch)) / 64 * 64;
     if (cap_rows > 32768) cap_rows = 32768;
     if (seg_rows_max >= 64 && cap_rows > seg_rows_max / 64 * 64) cap_rows = seg_rows_max / 64 * 64;
@@ -1030,7 +1038,6 @@ static int launch_gram_i8(const float* Xp, int64_t panel_stride, int64_t batch_s
     const int nseg = (int)ceil_div64(m64, cap_rows);
     const int seg = (int)round_up64(ceil_div64(m64, nseg), 64);
     ASVD_HIP_CHECK(hipFuncSetAttribute((const void*)gram_i8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GI_STAGE_BYTES));
-    colmaxexp_kernel<<<dim3(nb, batch), 256, 0, st>>>(Xp, panel_stride, batch_stride, m_pad, n_pad, ex);
     const int nt = (nb + 3) / 4, ntri = nt * (nt + 1) / 2;
     for (int s = 0; s < nseg; ++s) {
         const int r0 = s * seg;
@@ -1038,16 +1045,16 @@ static int launch_gram_i8(const float* Xp, int64_t panel_stride, int64_t batch_s
         if (rows <= 0) break;
         const int kgs = rows / 16;
         const int64_t plane_stride = (int64_t)nb * kgs * 512;
-        split_i8_kernel<<<dim3((unsigned)ceil_div64(kgs, 8), nb, batch), 256, 0, st>>>(Xp, panel_stride, batch_stride, nb, m_pad, n_pad, ex, r0, kgs,
-                                                                                       scratch, plane_stride);
-        gram_i8_kernel<<<dim3(ntri, batch), 512, 2 * GI_STAGE_BYTES, st>>>(scratch, plane_stride, nb, kgs, n_pad, ex, G, ldg, gbs, s > 0 ? 1 : 0, nt);
+        split_i8_kernel<<<dim3(nb, (unsigned)ceil_div64(kgs, 8), batch), 256, 0, st>>>(Xp, panel_stride, batch_stride, nb, m_pad, n_pad, ex, r0, kgs,
+                                                                                       scratch, plane_stride, perm);
+        gram_i8_kernel<<<dim3(ntri, batch), 512, 2 * GI_STAGE_BYTES, st>>>(scratch, plane_stride, nb, kgs, n_pad, ex, G, ldg, gbs, s > 0 ? 1 : 0, nt, dp);
     }
     ASVD_HIP_CHECK(hipGetLastError());
     return ASVD_OK;
 }
 
 struct TallLayout {
-    size_t off_xp, off_g, off_gs, off_dp, off_df, off_perm, off_dg, off_d, off_fail, off_r, off_vr, off_part, off_inv, off_inner, inner_bytes, total;
+    size_t off_xp, off_g, off_gs, off_dp, off_df, off_perm, off_dg, off_d, off_fail, off_r, off_vr, off_part, off_inv, off_bex, off_aex, off_vmax, off_gex, off_ex, off_exs, off_inner, inner_bytes, total;
     int n_pad64;
 };
 
@@ -1068,6 +1075,14 @@ static int tall_layout(int batch, const Plan& p, int want_vectors, int64_t k, Ta
     t.off_vr = take(want_vectors ? (size_t)2 * p.cols * k * batch * sizeof(float) : 0);  // permuted + un-permuted right vectors
     t.off_part = take(want_vectors ? (size_t)64 * k * batch * sizeof(double) : 0);  // per problem: the epilogues run on side streams
     t.off_inv = take(want_vectors ? (size_t)k * batch * sizeof(float) : 0);
+    // column exponents of the int8 Gram matrix (gram_i8.h), original and sorted order
+    t.off_ex = take((size_t)p.n_pad * batch * sizeof(int));
+    t.off_exs = take((size_t)p.n_pad * batch * sizeof(int));
+    // exponents of the int8 long-side product (nn_gemm_i8.h): columns of X, rows of X, columns of Vr (key of the maximum, then the exponent)
+    t.off_bex = take(want_vectors ? (size_t)p.n_pad * batch * sizeof(int) : 0);
+    t.off_aex = take(want_vectors ? (size_t)round_up64(p.m_pad, 128) * batch * sizeof(int) : 0);
+    t.off_vmax = take(want_vectors ? (size_t)round_up64(k, 32) * batch * sizeof(unsigned) : 0);
+    t.off_gex = take(want_vectors ? (size_t)round_up64(k, 32) * batch * sizeof(int) : 0);
     Plan pi;
     int rc = make_plan(batch, p.cols, p.cols, want_vectors, want_vectors, pi);
     if (rc) return rc;
@@ -1131,22 +1146,33 @@ static int svd_tall(int batch, const void* const* a_host, int a_dtype, int64_t m
             }
             if (prc) return prc;
         }
-        // G = X^T X: exact integer arithmetic on the int8 matrix pipe (gram_i8.h; the digit planes live in Gs and the exponents in cperm, both
-        // written only after the Gram matrix is complete), or the fp64 matrix instructions (ASVD_GRAM_I8=0)
+        // G = X^T X: exact integer arithmetic on the int8 matrix pipe (gram_i8.h), or the fp64 matrix instructions (ASVD_GRAM_I8=0), then
+        // sort columns by decreasing norm (stable, padding last; 14 -> 10 sweeps, unsorted saves nothing), permute + unit-scale the Gram matrix.
+        // The int8 path takes the norms from the data first (fp64, colmaxexp_kernel) and stores the sorted, scaled matrix directly: Gs = D^-1 P^T G~ P D^-1
+        // with G~ the exact Gram matrix of the digitised columns and D the norms of the original ones — diagonal 1 + O(1e-7) instead of exactly 1,
+        // which is a column scaling like any other (R is un-scaled with the same D).  Digit planes in the G region, which this path does not use.
         if (gram_i8_wanted()) {
-            rc = launch_gram_i8(Xp, p.panel_stride, p.batch_stride, p.nb, p.m_pad, p.n_pad, batch, G, ldg, gbs, (signed char*)Gs,
-                                (size_t)gbs * batch * sizeof(double), cperm, 0, st);
+            int* ex = (int*)(wb + t.off_ex);
+            int* exs = (int*)(wb + t.off_exs);
+            colmaxexp_kernel<<<dim3(p.nb, batch), 256, 0, st>>>(Xp, p.panel_stride, p.batch_stride, p.m_pad, p.n_pad, ex, d);
+            d_to_float_kernel<<<(unsigned)ceil_div64((int64_t)p.n_pad * batch, 256), 256, 0, st>>>(d, p.n_pad * batch, dF);
+            rank_kernel<<<dim3((unsigned)ceil_div64(p.n_pad, 256), batch), 256, 0, st>>>(dF, p.n_pad, cperm);
+            perm_gather_kernel<<<dim3((unsigned)ceil_div64(p.n_pad, 256), batch), 256, 0, st>>>(ex, d, cperm, p.n_pad, exs, dp);
+            rc = launch_gram_i8(Xp, p.panel_stride, p.batch_stride, p.nb, p.m_pad, p.n_pad, batch, Gs, ldg, gbs, (signed char*)G,
+                                (size_t)gbs * batch * sizeof(double), exs, cperm, dp, 0, st);
             if (rc) return rc;
         } else {
             gram64_kernel<<<dim3(p.nb, (unsigned)ceil_div64(p.nb, 4), batch), 256, 0, st>>>(Xp, p.panel_stride, p.batch_stride, p.nb, p.m_pad, G, ldg, gbs);
+            chol_diag_kernel<<<dim3((unsigned)ceil_div64(p.n_pad, 256), batch), 256, 0, st>>>(G, ldg, gbs, p.n_pad, d);
+            d_to_float_kernel<<<(unsigned)ceil_div64((int64_t)p.n_pad * batch, 256), 256, 0, st>>>(d, p.n_pad * batch, dF);
+            rank_kernel<<<dim3((unsigned)ceil_div64(p.n_pad, 256), batch), 256, 0, st>>>(dF, p.n_pad, cperm);
+            g_permute_scale_kernel<<<dim3((unsigned)ceil_div64(p.n_pad, 256), p.n_pad, batch), 256, 0, st>>>(G, ldg, gbs, d, cperm, p.n_pad, Gs, dp);
         }
-        chol_diag_kernel<<<dim3((unsigned)ceil_div64(p.n_pad, 256), batch), 256, 0, st>>>(G, ldg, gbs, p.n_pad, d);
-        // sort columns by decreasing norm (stable, padding last; 14 -> 10 sweeps, unsorted saves nothing), permute + unit-scale the Gram matrix
-        d_to_float_kernel<<<(unsigned)ceil_div64((int64_t)p.n_pad * batch, 256), 256, 0, st>>>(d, p.n_pad * batch, dF);
-        rank_kernel<<<dim3((unsigned)ceil_div64(p.n_pad, 256), batch), 256, 0, st>>>(dF, p.n_pad, cperm);
-        g_permute_scale_kernel<<<dim3((unsigned)ceil_div64(p.n_pad, 256), p.n_pad, batch), 256, 0, st>>>(G, ldg, gbs, d, cperm, p.n_pad, Gs, dp);
         // block rows in groups of four: inside a group each finished row updates the rest of the group's strip (K = 64), the matrix behind
         // the group is updated once per group (K = 256)
+        // (Round 6, measured and removed — profiles/r6_chol_lookahead.txt: the chain of group g + 1 on a second, equally CU-masked stream beside the bulk
+        // of group g's trailing update, the next group's strip updated first.  Reduction 48.1-48.5 -> 52.3 ms per 32 x 4096^2: the two extra launches and
+        // event hand-overs per group cost more than the 0.5 ms chain they hide, and the trailing update loses the CUs the chain occupies.)
         constexpr int cg = 4;
         for (int j0 = 0; j0 < nbk; j0 += cg) {
             const int j1 = std::min(nbk, j0 + cg);
@@ -1204,8 +1230,42 @@ static int svd_tall(int batch, const void* const* a_host, int a_dtype, int64_t m
             }
             row_unpermute_kernel<<<dim3((unsigned)ceil_div64(k, 256), p.cols, zb), 256, 0, st>>>(tb, cperm + (int64_t)b0 * p.n_pad, p.n_pad, p.cols, (int)k);
             if (!any_long) continue;
-            nn_gemm_split_kernel<<<dim3((unsigned)ceil_div64(k, 128), (unsigned)ceil_div64(p.rows, 128), zb), 256, 0, st>>>(
-                tb, Xp + (int64_t)b0 * p.batch_stride, p.panel_stride, p.batch_stride, p.nb, p.rows, p.cols, k, (int)k, k);
+            if (nn_i8_wanted() && p.cols <= 32768) {
+                // Y = X Vr on the int8 matrix pipe (nn_gemm_i8.h).  Digit planes: Vr in the G region, X^T (row segments of what fits) in the Gs region —
+                // both free since R left them; exponents in their own small arrays.
+                const float* Xz = Xp + (int64_t)b0 * p.batch_stride;
+                int* bex = (int*)(wb + t.off_bex) + (int64_t)b0 * p.n_pad;
+                const int rows_pad = (int)round_up64(p.m_pad, 128), kp = (int)round_up64(k, 32);
+                int* aex = (int*)(wb + t.off_aex) + (int64_t)b0 * rows_pad;
+                unsigned* vmax = (unsigned*)(wb + t.off_vmax) + (int64_t)b0 * kp;
+                int* gex = (int*)(wb + t.off_gex) + (int64_t)b0 * kp;
+                const int cgs = p.n_pad / 16, jps = kp / 32;
+                const int64_t strideB = (int64_t)jps * cgs * 512;
+                signed char* planesB = (signed char*)G;
+                signed char* planesA = (signed char*)Gs;
+                colexp_from_norm_kernel<<<(unsigned)ceil_div64((int64_t)p.n_pad * zb, 256), 256, 0, st>>>(d + (int64_t)b0 * p.n_pad, p.n_pad * zb, bex);
+                rowmaxexp_kernel<<<dim3((unsigned)(rows_pad / 8), zb), 256, 0, st>>>(Xz, p.panel_stride, p.batch_stride, p.nb, p.rows, rows_pad, bex, p.n_pad, aex);
+                ASVD_HIP_CHECK(hipMemsetAsync(vmax, 0, (size_t)kp * zb * sizeof(unsigned), st));
+                const int vchunks = (int)std::min<int64_t>(32, ceil_div64(p.cols, 64));
+                const int vrpc = (int)ceil_div64(p.cols, vchunks);
+                vcolmax_kernel<<<dim3((unsigned)ceil_div64(k, 256), vchunks, zb), 256, 0, st>>>(tb, p.cols, (int)k, k, bex, p.n_pad, vrpc, vmax, kp);
+                split_v_i8_kernel<<<dim3(jps, (unsigned)ceil_div64(cgs, 8), zb), 256, 0, st>>>(tb, p.cols, (int)k, k, bex, p.n_pad, vmax, kp, cgs, planesB, strideB, gex);
+                ASVD_HIP_CHECK(hipFuncSetAttribute((const void*)nn_gemm_i8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GI_STAGE_BYTES));
+                int64_t seg = ((int64_t)8 * p.n_pad / 3) / 128 * 128;   // rows of X^T planes per problem that fit the Gs region
+                if (seg > rows_pad) seg = rows_pad;
+                for (int64_t r0 = 0; r0 < rows_pad; r0 += seg) {
+                    const int rps = (int)(std::min<int64_t>(seg, rows_pad - r0) / 32);
+                    const int64_t strideA = (int64_t)rps * cgs * 512;
+                    split_xt_i8_kernel<<<dim3(rps, (unsigned)ceil_div64(cgs, 8), zb), 256, 0, st>>>(Xz, p.panel_stride, p.batch_stride, p.rows, rows_pad, bex, p.n_pad,
+                                                                                                  aex, (int)r0, cgs, planesA, strideA);
+                    const int gx = (int)ceil_div64(jps, 4), gy = (int)ceil_div64(rps, 4);
+                    nn_gemm_i8_kernel<<<dim3(gx * gy, zb), 256, 2 * GI_STAGE_BYTES, st>>>(tb, planesA, strideA, rps, planesB, strideB, jps, cgs, aex, rows_pad, gex, kp,
+                                                                                         (int)r0, p.rows, (int)k, k, gx, gy);
+                }
+            } else {
+                nn_gemm_split_kernel<<<dim3((unsigned)ceil_div64(k, 128), (unsigned)ceil_div64(p.rows, 128), zb), 256, 0, st>>>(
+                    tb, Xp + (int64_t)b0 * p.batch_stride, p.panel_stride, p.batch_stride, p.nb, p.rows, p.cols, k, (int)k, k);
+            }
             // sigma_j = |X v_j| and unit left vectors
             double* part = (double*)(wb + t.off_part) + (size_t)b0 * 64 * k;
             float* invs = (float*)(wb + t.off_inv) + (size_t)b0 * k;
@@ -1245,8 +1305,9 @@ int asvd_test_gram(const float* Xp, int64_t panel_stride, int64_t batch_stride, 
         return ASVD_OK;
     }
     if (!scratch || !ex) return ASVD_E_BADARG;
+    colmaxexp_kernel<<<dim3(nb, batch), 256, 0, st>>>(Xp, panel_stride, batch_stride, m_pad, n_pad, ex, nullptr);
     return launch_gram_i8(Xp, panel_stride, batch_stride, nb, m_pad, n_pad, batch, G, n_pad, (int64_t)n_pad * n_pad, (signed char*)scratch, scratch_bytes, ex,
-                          seg_rows, st);
+                          nullptr, nullptr, seg_rows, st);
 }
 
 // Test hook: the super-panel pair schedule itself.  out[step * npairs + k] = (S << 16) | T of slot k of super-step `step`, or -1 for an empty

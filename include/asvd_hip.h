@@ -148,7 +148,9 @@ int asvd_scale_cols(const void* w, int w_dtype, int64_t m, int64_t n, int64_t ld
  * ASVD_EVDQ=0/1 (force the throughput / latency form of the eigen-solver), ASVD_EVDW_TRACE (stage stamps of the solver),
  * ASVD_SPREAD_FROM=<sweep> (line-spread order of the XOR distances from that dense sweep on: a measurement knob),
  * ASVD_SPLIT=0 (never split a batch over the two halves of the chip), ASVD_RING=0/1/2 + ASVD_RING_FROM=<sweep> (cross-only ring visits of the
- * eigen-solves: off / both inner steps / inner step 1 only — the default for >= 2048 columns is 2).
+ * eigen-solves: off / both inner steps / inner step 1 only — the default for >= 2048 columns is 2), ASVD_GRAM_I8=0 (Gram matrix of the reduction
+ * with the fp64 matrix instructions instead of the exact int8 digit products, csrc/gram_i8.h), ASVD_NN_I8=0 (long-side product X V with six bf16
+ * products per fp32 product instead of the int8 fixed-point form, csrc/nn_gemm_i8.h).
  * Returns worst status over the batch.
  */
 int asvd_svd_worksize(int batch, int64_t m, int64_t n, int want_vectors, size_t* bytes);
@@ -286,7 +288,8 @@ int asvd_svd_get_split_profile(float* ms_host, int* launches_host, float* overla
  * asvd_svd_batched runs a batch of >= 4 problems with >= 3072 columns as two halves, each on an internal stream masked to one half of the CUs
  * (hipExtStreamCreateWithCUMask): the eigen-solve launches of one half (VALU-bound) then overlap the HBM-bound update launches of the other,
  * which two launches of one stream never do.
- * OWNERSHIP — the only entry point of this header that creates anything behind the caller's back.  Per CALLING HOST THREAD and device, at that
+ * OWNERSHIP — asvd_svd_batched (and asvd_svd, which calls it) is the only entry point of this header that creates anything behind the caller's
+ * back.  Per CALLING HOST THREAD and device, at that
  * thread's first split call, the library creates (a) two CU-masked streams (hipExtStreamCreateWithCUMask has no flags argument: they are
  * ordinary blocking streams, i.e. they also order against the legacy NULL stream) and (b) ONE worker thread (it runs the second half; the
  * first half runs on the calling thread); both are released when the calling thread ends.  Per thread, so that two host threads making split
