@@ -82,10 +82,11 @@ __global__ void perm_gather_kernel(const int* __restrict__ ex, const double* __r
 __global__ __launch_bounds__(256) void split_i8_kernel(const float* __restrict__ X, int64_t panel_stride, int64_t batch_stride, int nb, int m_pad,
                                                        int n_pad, const int* __restrict__ ex, int r0, int kgs, signed char* __restrict__ planes,
                                                        int64_t plane_stride /* bytes per digit and problem = nb kgs 512 */,
-                                                       const int* __restrict__ perm /* nullable: plane column i holds column perm[i] of X; ex is in plane order */) {
+                                                       const int* __restrict__ perm /* nullable: plane column i holds column perm[i] of X; ex is in plane order */,
+                                                       const int* __restrict__ done /* nullable: problems whose flag is set are skipped */) {
     const int P = blockIdx.x, b = blockIdx.z, c = threadIdx.x & 31;
     const int kg = blockIdx.y * 8 + (threadIdx.x >> 5);
-    if (kg >= kgs) return;
+    if (kg >= kgs || (done && ld_flag(done + b))) return;
     const int E = ex[(int64_t)b * n_pad + P * PB + c];
     const int q = perm ? perm[(int64_t)b * n_pad + P * PB + c] : P * PB + c;
     const float* __restrict__ xp = X + (int64_t)b * batch_stride + (int64_t)(q >> 5) * panel_stride + (q & 31);
@@ -120,15 +121,39 @@ constexpr int GI_STAGE_BYTES = 2 * 3 * 4 * 4 * 512;  // side, digit, panel, row 
 __global__ __launch_bounds__(512) void gram_i8_kernel(const signed char* __restrict__ planes, int64_t plane_stride, int nb, int kgs, int n_pad,
                                                       const int* __restrict__ ex, double* __restrict__ G, int64_t ldg, int64_t g_batch_stride,
                                                       int accumulate, int nt, const double* __restrict__ dp /* nullable: G_ij / (dp_i dp_j) is stored;
-                                                      a column with dp = 0 gets a unit diagonal and zeros */) {
+                                                      a column with dp = 0 gets a unit diagonal and zeros */, int order /* block order: 0 row runs per XCD, 1 4 x 8 groups per XCD, 2 plain */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char gi_lds[];  // 2 x GI_STAGE_BYTES
     // XCD-aware order: consecutive workgroup ids go round-robin over the 8 XCDs; give every XCD a contiguous run of blocks (they share I panels in its L2)
     // (a block count that is not a multiple of 8 keeps the plain order: correct, merely less local)
     const int total = gridDim.x;
-    const int lid = (total & 7) ? (int)blockIdx.x : (int)((blockIdx.x & 7) * (total >> 3) + (blockIdx.x >> 3));
-    int Ib = 0, rem = lid;
-    while (rem >= nt - Ib) { rem -= nt - Ib; ++Ib; }
-    const int Jb = Ib + rem;
+    const int lid = ((total & 7) || order == 2) ? (int)blockIdx.x : (int)((blockIdx.x & 7) * (total >> 3) + (blockIdx.x >> 3));
+    int Ib = 0, Jb = 0;
+    if (order == 1) {
+        // 4 x 8 groups of blocks (the 32 workgroups an XCD runs at a time share 4 I-side and 8 J-side column blocks in its L2), groups row by row
+        int rem = lid;
+        bool found = false;
+        for (int SI = 0; SI * 4 < nt && !found; ++SI)
+            for (int SJ = (SI * 4) >> 3; SJ * 8 < nt && !found; ++SJ) {
+                int cnt = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int ib = SI * 4 + i, lo = max(SJ * 8, ib), hi = min(SJ * 8 + 8, nt);
+                    if (ib < nt && hi > lo) cnt += hi - lo;
+                }
+                if (rem >= cnt) { rem -= cnt; continue; }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int ib = SI * 4 + i, lo = max(SJ * 8, ib), hi = min(SJ * 8 + 8, nt);
+                    const int wdt = (ib < nt && hi > lo) ? hi - lo : 0;
+                    if (!found && rem < wdt) { Ib = ib; Jb = lo + rem; found = true; }
+                    if (!found) rem -= wdt;
+                }
+            }
+    } else {
+        int rem = lid;
+        while (rem >= nt - Ib) { rem -= nt - Ib; ++Ib; }
+        Jb = Ib + rem;
+    }
     const int b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wi = w >> 2, wj = w & 3;

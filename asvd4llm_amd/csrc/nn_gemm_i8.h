@@ -7,12 +7,12 @@
 //   beta_c  : power of two just above the column norm of X (removes the activation scales from the row maxima; cancels in the product),
 //   alpha_r : power of two just above max_c |x[r][c]| 2^-beta_c,     gamma_j : just above max_c |v[c][j]| 2^beta_c,
 //   y[r][j] = 2^(alpha_r + gamma_j - 46) sum_c tx tv,   sum_c tx tv = sum_{a,b} 2^(8 (4 - a - b)) (Da^T Db)[r][j]
-// with the six digit products of weight s = a + b <= 2 kept (three int32 accumulators: exact, no accumulation rounding) and the three products of weight
-// 3 and 4 dropped, 2^-23 of the leading one.  v_mfma_i32_32x32x32_i8 covers twice the reduction length of v_mfma_f32_32x32x16_bf16 per issue slot, the
-// operands are half the bytes and need no VALU in the loop.  Reduction lengths (columns of X) above 32768 keep the bf16 kernel (int32 range).
-// Accuracy (tests/test_gpu_gram_i8.py, columns of U sigma against the fp64 product, worst column over sigma_1): 7.3e-7 here against 4.6e-7 for the bf16
-// form at 1024^2 — the fixed-point operands are rounded to 2^-24 of their ROW / COLUMN maximum (the three bf16 parts represent every entry exactly, that
-// form's error is its fp32 accumulation), both far inside what the fp16 factors the pipeline emits can show; ASVD_NN_I8=0 keeps the bf16 kernel.
+// with the eight digit products of weight s = a + b <= 3 kept (four int32 accumulators: exact, no accumulation rounding) and only the product of the two
+// lowest digits dropped, 2^-32 of the largest product.  v_mfma_i32_32x32x32_i8 covers twice the reduction length of v_mfma_f32_32x32x16_bf16 per issue
+// slot, the operands are half the bytes and need no VALU in the loop.  Reduction lengths (columns of X) above 32768 keep the bf16 kernel (int32 range).
+// What is left is the rounding of the fixed-point operands themselves, 2^-25 of their ROW (X) / COLUMN (V) maximum per entry — the three bf16 parts of the
+// other form represent every entry exactly, that form's error is its fp32 accumulation over the reduction; measured side by side in
+// tests/test_gpu_gram_i8.py (columns of U sigma against the fp64 product).  ASVD_NN_I8=0 keeps the bf16 kernel.
 #pragma once
 
 // bex[b][c] = beta_c from the column norms d of the reduction (any power of two above the column's largest entry does; |x| <= |x_c|_2 < 2^beta)
@@ -156,13 +156,16 @@ __global__ __launch_bounds__(256) void split_v_i8_kernel(TallBatch tb, int cols,
     *(uint4*)(pb + 2 * plane_stride) = make_uint4(w2[0], w2[1], w2[2], w2[3]);
 }
 
-// out[z][r0 + ..][..] = Y.  Workgroup = 256 threads = one 128 (rows) x 128 (columns) block; wave w: row panels 4 Ib + 2 (w >> 1) + {0, 1}, column panels
-// 4 Jb + 2 (w & 1) + {0, 1}: 4 tiles x 3 weights x 16 = 192 accumulators, one wave per SIMD.  Stages of 64 reduction indices through LDS exactly as in
-// gram_i8_kernel (same piece order).  grid: (column blocks x row blocks of this segment, zb); blocks are walked in 4 x 8 groups per XCD when the counts allow.
-__global__ __launch_bounds__(256) void nn_gemm_i8_kernel(TallBatch tb, const signed char* __restrict__ planesA, int64_t strideA, int rps,
+// out[z][r0 + ..][..] = Y.  Workgroup = 512 threads = one 128 (rows) x 128 (columns) block on the tiling of gram_i8_kernel: wave w owns row panels
+// 4 Ib + 2 (w >> 2) + {0, 1} against column panel 4 Jb + (w & 3) — 2 tiles x 4 weights x 16 = 128 accumulators, two waves per SIMD; stages of 64 reduction
+// indices through LDS in the planes' own order.  grid: (column blocks x row blocks of this segment, zb); `order` 1 walks the blocks in 4 x 8 groups per XCD,
+// 0 in row runs per XCD, 2 plainly (measured: no difference, tools/bench_i8_gemm.py).
+// (First version, measured: four waves of 64 x 64 with SIX products, weight <= 2 — 17 ms per 32 x 4096^2, but on rows with a spike over a floor 1e-3
+// below it the floor's values sit in the low digits and the dropped weight-3 products were 2.4e-5 of sigma_1 in U sigma, fifty times the bf16 form.)
+__global__ __launch_bounds__(512) void nn_gemm_i8_kernel(TallBatch tb, const signed char* __restrict__ planesA, int64_t strideA, int rps,
                                                          const signed char* __restrict__ planesB, int64_t strideB, int jps, int cgs,
                                                          const int* __restrict__ aex, int rows_pad, const int* __restrict__ gex, int kp, int r0, int rows, int k,
-                                                         int64_t ldo, int gx, int gy) {
+                                                         int64_t ldo, int gx, int gy, int order) {
     extern __shared__ __attribute__((aligned(16))) unsigned char gi_lds[];  // 2 x GI_STAGE_BYTES
     const int z = blockIdx.y;
     float* __restrict__ out = tb.lng[z];
@@ -170,23 +173,27 @@ __global__ __launch_bounds__(256) void nn_gemm_i8_kernel(TallBatch tb, const sig
     int Ib, Jb;
     {
         const int total = gx * gy, id = blockIdx.x;
-        if ((total & 7) == 0 && (gx & 7) == 0 && (gy & 3) == 0) {
+        if (order == 1 && (total & 7) == 0 && (gx & 7) == 0 && (gy & 3) == 0) {
             const int lid = (id & 7) * (total >> 3) + (id >> 3);   // consecutive ids of one XCD
-            const int g = lid >> 5, wi = lid & 31, ggx = gx >> 3;
-            Ib = (g / ggx) * 4 + (wi >> 3);
-            Jb = (g % ggx) * 8 + (wi & 7);
+            const int g = lid >> 5, wi_ = lid & 31, ggx = gx >> 3;
+            Ib = (g / ggx) * 4 + (wi_ >> 3);
+            Jb = (g % ggx) * 8 + (wi_ & 7);
+        } else if (order == 0 && (total & 7) == 0) {
+            const int lid = (id & 7) * (total >> 3) + (id >> 3);   // row runs per XCD
+            Ib = lid / gx;
+            Jb = lid % gx;
         } else {
             Ib = id / gx;
             Jb = id % gx;
         }
     }
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int wi = w >> 1, wj = w & 1;
-    const unsigned char* gsrc[12];
-    bool gok[12];
+    const int wi = w >> 2, wj = w & 3;
+    const unsigned char* gsrc[6];
+    bool gok[6];
 #pragma unroll
-    for (int r = 0; r < 12; ++r) {
-        const int q = r * 256 + tid;
+    for (int r = 0; r < 6; ++r) {
+        const int q = r * 512 + tid;
         const int side = q / 1536, qq = q % 1536;
         const int a = (qq >> 7) >> 2, p4 = (qq >> 7) & 3, within = qq & 127;
         if (side == 0) {
@@ -199,75 +206,69 @@ __global__ __launch_bounds__(256) void nn_gemm_i8_kernel(TallBatch tb, const sig
             gsrc[r] = (const unsigned char*)planesB + (int64_t)z * 3 * strideB + (int64_t)a * strideB + (int64_t)(gok[r] ? P : 0) * cgs * 512 + within * 16;
         }
     }
-    i32x16 acc[2][2][3];
+    i32x16 acc[2][4];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int s = 0; s < 3; ++s)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[t][u][s][i] = 0;
+            for (int i = 0; i < 16; ++i) acc[t][s][i] = 0;
     const int nstage = cgs >> 2;  // cgs is a multiple of 4
-    uint4 stg[12];
+    uint4 stg[6];
 #pragma unroll
-    for (int r = 0; r < 12; ++r) stg[r] = gok[r] ? *(const uint4*)(gsrc[r]) : make_uint4(0, 0, 0, 0);
+    for (int r = 0; r < 6; ++r) stg[r] = gok[r] ? *(const uint4*)(gsrc[r]) : make_uint4(0, 0, 0, 0);
 #pragma unroll
-    for (int r = 0; r < 12; ++r) *(uint4*)(gi_lds + (r * 256 + tid) * 16) = stg[r];
+    for (int r = 0; r < 6; ++r) *(uint4*)(gi_lds + (r * 512 + tid) * 16) = stg[r];
     __syncthreads();
     for (int st = 0; st < nstage; ++st) {
         const unsigned char* cur = gi_lds + (st & 1) * GI_STAGE_BYTES;
         if (st + 1 < nstage) {
 #pragma unroll
-            for (int r = 0; r < 12; ++r) stg[r] = gok[r] ? *(const uint4*)(gsrc[r] + (int64_t)(st + 1) * 2048) : make_uint4(0, 0, 0, 0);
+            for (int r = 0; r < 6; ++r) stg[r] = gok[r] ? *(const uint4*)(gsrc[r] + (int64_t)(st + 1) * 2048) : make_uint4(0, 0, 0, 0);
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            i32x4 fa[2][3], fb[2][3];
+            i32x4 fa[2][3], fb[3];
 #pragma unroll
-            for (int a = 0; a < 3; ++a)
+            for (int a = 0; a < 3; ++a) {
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
+                for (int t = 0; t < 2; ++t)
                     fa[t][a] = *(const i32x4*)(cur + (((0 * 3 + a) * 4 + 2 * wi + t) * 4 + 2 * ks) * 512 + lane * 16);
-                    fb[t][a] = *(const i32x4*)(cur + (((1 * 3 + a) * 4 + 2 * wj + t) * 4 + 2 * ks) * 512 + lane * 16);
-                }
+                fb[a] = *(const i32x4*)(cur + (((1 * 3 + a) * 4 + wj) * 4 + 2 * ks) * 512 + lane * 16);
+            }
 #pragma unroll
             for (int a = 0; a < 3; ++a)
 #pragma unroll
-                for (int c = 0; c + a < 3; ++c)
+                for (int c = 0; c < 3; ++c)
 #pragma unroll
                     for (int t = 0; t < 2; ++t)
-#pragma unroll
-                        for (int u = 0; u < 2; ++u)
-                            acc[t][u][a + c] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[t][a], fb[u][c], acc[t][u][a + c], 0, 0, 0);
+                        if (a + c < 4) acc[t][a + c] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[t][a], fb[c], acc[t][a + c], 0, 0, 0);
         }
         if (st + 1 < nstage) {
             unsigned char* nxt = gi_lds + ((st + 1) & 1) * GI_STAGE_BYTES;
 #pragma unroll
-            for (int r = 0; r < 12; ++r) *(uint4*)(nxt + (r * 256 + tid) * 16) = stg[r];
+            for (int r = 0; r < 6; ++r) *(uint4*)(nxt + (r * 512 + tid) * 16) = stg[r];
         }
         __syncthreads();
     }
     // D[i][j]: j = lane & 31 (B operand = column panel), i = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (A operand = row panel)
+    const int j = (4 * Jb + wj) * 32 + (lane & 31);
+    if (j >= k) return;
+    const int ge = gex[(int64_t)z * kp + j];
+    const double sj = ge == GI_BAD ? __builtin_nan("") : (ge == GI_ZERO ? 0.0 : ldexp(1.0, ge - 23));
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int j = (4 * Jb + 2 * wj + u) * 32 + (lane & 31);
-        if (j >= k) continue;
-        const int ge = gex[(int64_t)z * kp + j];
-        const double sj = ge == GI_BAD ? __builtin_nan("") : (ge == GI_ZERO ? 0.0 : ldexp(1.0, ge - 23));
+    for (int t = 0; t < 2; ++t) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int r = r0 + (4 * Ib + 2 * wi + t) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-                if (r >= rows) continue;
-                const int ae = aex[(int64_t)z * rows_pad + r];
-                const double si = ae == GI_BAD ? __builtin_nan("") : (ae == GI_ZERO ? 0.0 : ldexp(1.0, ae - 23));
-                double v = (double)acc[t][u][2][reg] * 65536.0;
-                v += (double)acc[t][u][1][reg] * 16777216.0;
-                v += (double)acc[t][u][0][reg] * 4294967296.0;
-                out[(int64_t)r * ldo + j] = (float)(v * si * sj);
-            }
+        for (int reg = 0; reg < 16; ++reg) {
+            const int r = r0 + (4 * Ib + 2 * wi + t) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+            if (r >= rows) continue;
+            const int ae = aex[(int64_t)z * rows_pad + r];
+            const double si = ae == GI_BAD ? __builtin_nan("") : (ae == GI_ZERO ? 0.0 : ldexp(1.0, ae - 23));
+            double v = (double)acc[t][3][reg] * 256.0;
+            v += (double)acc[t][2][reg] * 65536.0;
+            v += (double)acc[t][1][reg] * 16777216.0;
+            v += (double)acc[t][0][reg] * 4294967296.0;
+            out[(int64_t)r * ldo + j] = (float)(v * si * sj);
         }
     }
 }

@@ -58,6 +58,7 @@ using namespace asvdk;
 #include "tall_kernels.h"
 #include "gram_i8.h"
 #include "nn_gemm_i8.h"
+#include "snapshot_i8.h"
 
 // --------------------------------------------------------------------------------------------------
 // ASVD_ORDER=rr: round-robin tournament instead of the XOR pair schedule (A/B measurements; single-level sweeps only)
@@ -78,7 +79,7 @@ struct Plan {
     size_t off_gd32, off_gx6, off_q0, off_d0, off_qfin, off_subact, off_din;
     int64_t panel_stride, batch_stride;
     // workspace offsets in bytes
-    size_t off_x, off_xorig, off_gpart, off_q, off_active, off_sig, off_ina, off_inv, off_perm, off_flags, off_pflag, off_plist, total;
+    size_t off_x, off_xorig, off_gpart, off_q, off_active, off_sig, off_ina, off_inv, off_perm, off_flags, off_pflag, off_plist, off_snap, off_snapex, total;
 };
 
 // CUs the launches of the current call may use: those of the device (256 on the MI355X), or those of one half when asvd_svd_batched runs a batch
@@ -199,6 +200,10 @@ int make_plan(int batch, int64_t m, int64_t n, int want_u, int want_vv, Plan& p)
     p.off_flags = take((size_t)batch * 4 * sizeof(int));  // [maxoff bits | nrot | done | super-pair updates] x batch (SoA)
     p.off_pflag = take((size_t)batch * p.nb * p.nb);      // sparse-sweep pair marks
     p.off_plist = take((size_t)batch * p.nb * p.nb * sizeof(int));  // per-step lists of marked pairs (bound: steps x nb/2 slots per problem)
+    // int8 digit planes + column exponents of the coupling snapshot (snapshot_i8.h): problems that can reach a sparse sweep and fit the int32 range
+    const bool snap8 = p.nb >= 8 && p.m_pad <= 32768;
+    p.off_snap = take(snap8 ? (size_t)3 * p.n_pad * round_up64(p.m_pad, 64) * batch : 0);
+    p.off_snapex = take(snap8 ? (size_t)batch * p.n_pad * sizeof(int) : 0);
     const size_t t2 = p.two ? 1 : 0;
     p.off_gd32 = take(t2 * batch * p.nb * 1024 * sizeof(float));                          // carried 32x32 diagonal blocks, one per panel
     p.off_gx6 = take(t2 * batch * p.npairs_s * std::max(p.nsplit_s, p.nchunks_q) * 6 * 1024 * sizeof(float));  // sgram6 / supgram partial tiles
@@ -687,10 +692,26 @@ static int svd_direct_run(int batch, const void* const* a_host, int a_dtype, int
             {
                 ProfScope ps(5, st);
                 ASVD_HIP_CHECK(hipMemsetAsync(pflag, 0, (size_t)batch * p.nb * p.nb, st));
-                panel_sumsq_kernel<<<dim3(p.nb, batch), 256, 0, st>>>(sc, X, p.panel_stride, p.batch_stride, p.m_pad, p.n_pad, dnorm, done);
                 const unsigned nt = (unsigned)ceil_div64(p.nb, 4);
-                fullcheck_kernel<<<dim3(nt, nt, batch), 256, 0, st>>>(sc, X, p.panel_stride, p.batch_stride, p.nb, p.m_pad, p.n_pad, dnorm, tol, kb, pflag,
-                                                                      maxoff, done);
+                const char* es8 = getenv("ASVD_SNAP_I8");   // read per call
+                const bool snap8 = p.nb >= 8 && p.m_pad <= 32768 && !(es8 && atoi(es8) == 0);
+                if (snap8) panel_sumsq_max_kernel<<<dim3(p.nb, batch), 256, 0, st>>>(X, p.panel_stride, p.batch_stride, p.m_pad, p.n_pad, dnorm, (int*)(wb + p.off_snapex), done);
+                else panel_sumsq_kernel<<<dim3(p.nb, batch), 256, 0, st>>>(sc, X, p.panel_stride, p.batch_stride, p.m_pad, p.n_pad, dnorm, done);
+                if (snap8) {
+                    // X^T X from int8 digit planes (snapshot_i8.h): digitise once, eight exact digit products per fp32 product
+                    int* sex = (int*)(wb + p.off_snapex);
+                    signed char* spl = (signed char*)(wb + p.off_snap);
+                    const int kgs = (int)(round_up64(p.m_pad, 64) / 16);
+                    const int64_t plane_stride = (int64_t)p.nb * kgs * 512;
+                    split_i8_kernel<<<dim3(p.nb, (unsigned)ceil_div64(kgs, 8), batch), 256, 0, st>>>(X, p.panel_stride, p.batch_stride, p.nb, p.m_pad, p.n_pad, sex, 0,
+                                                                                                   kgs, spl, plane_stride, nullptr, done);
+                    ASVD_HIP_CHECK(hipFuncSetAttribute((const void*)fullcheck_i8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GI_STAGE_BYTES));
+                    fullcheck_i8_kernel<<<dim3(nt * (nt + 1) / 2, batch), 512, 2 * GI_STAGE_BYTES, st>>>(spl, plane_stride, p.nb, kgs, p.n_pad, sex, dnorm, tol, kb,
+                                                                                                      pflag, maxoff, done, (int)nt);
+                } else {
+                    fullcheck_kernel<<<dim3(nt, nt, batch), 256, 0, st>>>(sc, X, p.panel_stride, p.batch_stride, p.nb, p.m_pad, p.n_pad, dnorm, tol, kb, pflag,
+                                                                          maxoff, done);
+                }
             }
             hflag.resize((size_t)batch * p.nb * p.nb);
             ASVD_HIP_CHECK(hipMemcpyAsync(hflag.data(), pflag, hflag.size(), hipMemcpyDeviceToHost, st));
@@ -1039,6 +1060,7 @@ static int launch_gram_i8(const float* Xp, int64_t panel_stride, int64_t batch_s
     const int seg = (int)round_up64(ceil_div64(m64, nseg), 64);
     ASVD_HIP_CHECK(hipFuncSetAttribute((const void*)gram_i8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GI_STAGE_BYTES));
     const int nt = (nb + 3) / 4, ntri = nt * (nt + 1) / 2;
+    const int order = getenv("ASVD_GI_ORDER") ? atoi(getenv("ASVD_GI_ORDER")) : 0;   // measurement knob (block order of gram_i8_kernel)
     for (int s = 0; s < nseg; ++s) {
         const int r0 = s * seg;
         const int rows = (int)std::min<int64_t>(seg, m64 - r0);
@@ -1046,8 +1068,8 @@ static int launch_gram_i8(const float* Xp, int64_t panel_stride, int64_t batch_s
         const int kgs = rows / 16;
         const int64_t plane_stride = (int64_t)nb * kgs * 512;
         split_i8_kernel<<<dim3(nb, (unsigned)ceil_div64(kgs, 8), batch), 256, 0, st>>>(Xp, panel_stride, batch_stride, nb, m_pad, n_pad, ex, r0, kgs,
-                                                                                       scratch, plane_stride, perm);
-        gram_i8_kernel<<<dim3(ntri, batch), 512, 2 * GI_STAGE_BYTES, st>>>(scratch, plane_stride, nb, kgs, n_pad, ex, G, ldg, gbs, s > 0 ? 1 : 0, nt, dp);
+                                                                                       scratch, plane_stride, perm, nullptr);
+        gram_i8_kernel<<<dim3(ntri, batch), 512, 2 * GI_STAGE_BYTES, st>>>(scratch, plane_stride, nb, kgs, n_pad, ex, G, ldg, gbs, s > 0 ? 1 : 0, nt, dp, order);
     }
     ASVD_HIP_CHECK(hipGetLastError());
     return ASVD_OK;
@@ -1259,8 +1281,9 @@ static int svd_tall(int batch, const void* const* a_host, int a_dtype, int64_t m
                     split_xt_i8_kernel<<<dim3(rps, (unsigned)ceil_div64(cgs, 8), zb), 256, 0, st>>>(Xz, p.panel_stride, p.batch_stride, p.rows, rows_pad, bex, p.n_pad,
                                                                                                   aex, (int)r0, cgs, planesA, strideA);
                     const int gx = (int)ceil_div64(jps, 4), gy = (int)ceil_div64(rps, 4);
-                    nn_gemm_i8_kernel<<<dim3(gx * gy, zb), 256, 2 * GI_STAGE_BYTES, st>>>(tb, planesA, strideA, rps, planesB, strideB, jps, cgs, aex, rows_pad, gex, kp,
-                                                                                         (int)r0, p.rows, (int)k, k, gx, gy);
+                    nn_gemm_i8_kernel<<<dim3(gx * gy, zb), 512, 2 * GI_STAGE_BYTES, st>>>(tb, planesA, strideA, rps, planesB, strideB, jps, cgs, aex, rows_pad, gex, kp,
+                                                                                         (int)r0, p.rows, (int)k, k, gx, gy,
+                                                                                         getenv("ASVD_NI_ORDER") ? atoi(getenv("ASVD_NI_ORDER")) : 1);
                 }
             } else {
                 nn_gemm_split_kernel<<<dim3((unsigned)ceil_div64(k, 128), (unsigned)ceil_div64(p.rows, 128), zb), 256, 0, st>>>(

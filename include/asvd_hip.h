@@ -150,7 +150,9 @@ int asvd_scale_cols(const void* w, int w_dtype, int64_t m, int64_t n, int64_t ld
  * ASVD_SPLIT=0 (never split a batch over the two halves of the chip), ASVD_RING=0/1/2 + ASVD_RING_FROM=<sweep> (cross-only ring visits of the
  * eigen-solves: off / both inner steps / inner step 1 only — the default for >= 2048 columns is 2), ASVD_GRAM_I8=0 (Gram matrix of the reduction
  * with the fp64 matrix instructions instead of the exact int8 digit products, csrc/gram_i8.h), ASVD_NN_I8=0 (long-side product X V with six bf16
- * products per fp32 product instead of the int8 fixed-point form, csrc/nn_gemm_i8.h).
+ * products per fp32 product instead of the int8 fixed-point form, csrc/nn_gemm_i8.h), ASVD_SNAP_I8=0 (coupling snapshot of the sparse sweeps with
+ * three fp16 products per fp32 product instead of int8 digit planes, csrc/snapshot_i8.h); ASVD_GI_ORDER / ASVD_NI_ORDER=0/1/2 (block order of the two
+ * int8 GEMM kernels: measurement knobs, tools/bench_i8_gemm.py).
  * Returns worst status over the batch.
  */
 int asvd_svd_worksize(int batch, int64_t m, int64_t n, int want_vectors, size_t* bytes);
