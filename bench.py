@@ -527,7 +527,7 @@ def main():
         achieved = f_svd * (value / world) / 1e12  # algorithmic TFLOP/s per GPU of the whole SVD job, from the timed region's wall clock
         roofline["svd_level"] = {"bound": "mfma", "unit_of_work": "one economy SVD, F = 14 m n^2 + 8 n^3", "achieved": achieved, "peak": 157.3,
                                  "unit": "TFLOP/s", "frac": achieved / 157.3,
-                                 "note": "fp32-MFMA peak as the yardstick (SURVEY 8d); the streaming products run split-fp16 / split-bf16 on the 16-bit matrix pipes (3 / 6 products per fp32 product), so this fraction does not bound what executes"}
+                                 "note": "fp32-MFMA peak as the yardstick (SURVEY 8d); the streaming products run split-fp16 on the 16-bit matrix pipe (3 products per fp32 product) and as int8 digit products (8 / 9 per product), so this fraction does not bound what executes"}
         if two_level:
             roofline["streaming_kernels"] = {k: {"GBps": alg[k] / (classes[k]["avg_us"] * 1e-6) / 1e9, "frac_of_8TBps": alg[k] / (classes[k]["avg_us"] * 1e-6) / 8e12,
                                                  "avg_launch_us": classes[k]["avg_us"], "algorithmic_bytes_per_launch": alg[k]}
@@ -576,10 +576,12 @@ def main():
             "warmup": args.warmup, "prewarm_steps": prewarm_steps, "ms_per_step": 1e3 * dt / args.steps,
             "step_wall_ms": [1e3 * (b - a) for a, b in zip([t0] + step_marks[:-1], step_marks)], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "arithmetic": "fp32 in, fp32 U / S / V out (the rank-r factors are emitted in fp16); inside: fp64 MFMA for the Gram matrix and the Cholesky-QR, fp32 VALU for the "
-                          "64x64 eigen-solves, and the streaming products (dense-sweep update + Gram, coupling snapshot) as THREE fp16 MFMA products per fp32 product with "
-                          "power-of-two column scales (2^-22 relative per product), the long-side GEMM as six bf16 products (2^-24): fp32-equivalent by measurement, not by "
-                          "construction — per-column error against fp64 in tests/test_gpu_twolevel.py, whole-SVD parity on flat AND graded / clustered inputs in "
+            "arithmetic": "fp32 in, fp32 U / S / V out (the rank-r factors are emitted in fp16); inside: the Gram matrix of the Cholesky-QR EXACTLY from int8 digit products "
+                          "(24-bit fixed point per column, nine products, int32 accumulation, fp64 combine: csrc/gram_i8.h), the Cholesky factorisation in fp64 MFMA, fp32 VALU for the "
+                          "64x64 eigen-solves, the dense-sweep update + Gram as THREE fp16 MFMA products per fp32 product with power-of-two column scales (2^-22 relative per "
+                          "product), the coupling snapshot and the long-side GEMM as EIGHT int8 digit products with exact int32 accumulation (operands rounded to 2^-25 of "
+                          "their column / row maximum: csrc/snapshot_i8.h, csrc/nn_gemm_i8.h): fp32-equivalent by measurement, not by construction — per-column error against "
+                          "fp64 and int64 arithmetic in tests/test_gpu_twolevel.py / test_gpu_gram_i8.py, whole-SVD parity on flat AND graded / clustered inputs in "
                           "tests/test_gpu_svd.py / test_gpu_families.py",
             "config": {"workload": f"{B} synthetic {m}x{n} fp32 Linears per GPU per step, abs_mean scaling (alpha 0.5), full SVD + rank-{r} truncation, factors emitted in fp16 (SURVEY 8d; the reference would emit the Linear's own dtype, svd_linear.py:102 - the cast is <0.1% of a step)",
                        "batch_per_gpu": B, "m": m, "n": n, "rank": r, "parallelism": f"independent matrices x{world}",
