@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("ASVD_HIP_LIB") or os.path.join(_HERE, "libasvd_hip.so
 F32, F16, BF16 = 0, 1, 2
 FUSE = {"UV": 0, "U": 1, "V": 2}
 STAT_ABS_MEAN, STAT_ABS_MAX, STAT_SQ_MEAN = 0, 1, 2
-PATH_REDUCED, PATH_REDUCE_FALLBACK, PATH_PLAIN_RETRY, PATH_SPLIT, PATH_SPLIT_REFUSED = 1, 2, 4, 8, 16
+PATH_REDUCED, PATH_REDUCE_FALLBACK, PATH_PLAIN_RETRY, PATH_SPLIT, PATH_SPLIT_REFUSED, PATH_GRAM_RETRY = 1, 2, 4, 8, 16, 32
 OK, E_BADARG, E_WORKSPACE, E_HIP, E_NODEVICE, N_NOCONV, N_NAN = 0, -1, -2, -3, -4, 1, 2
 
 _c = ctypes

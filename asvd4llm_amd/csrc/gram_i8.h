@@ -63,33 +63,36 @@ __global__ __launch_bounds__(256) void colmaxexp_kernel(const float* __restrict_
     }
 }
 
-// exs[b][i] = ex[b][perm[b][i]], dp[b][i] = d[b][perm[b][i]]: exponents and norms in sorted-column order
+// exs[b][i] = ex[b][perm[b][i]], dp[b][i] = d[b][perm[b][i]]: exponents and norms in sorted-column order; inv[b][perm[b][i]] = i
 __global__ void perm_gather_kernel(const int* __restrict__ ex, const double* __restrict__ d, const int* __restrict__ perm, int n, int* __restrict__ exs,
-                                   double* __restrict__ dp) {
+                                   double* __restrict__ dp, int* __restrict__ inv) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int b = blockIdx.y;
     const int q = perm[(int64_t)b * n + i];
     exs[(int64_t)b * n + i] = ex[(int64_t)b * n + q];
     dp[(int64_t)b * n + i] = d[(int64_t)b * n + q];
+    inv[(int64_t)b * n + q] = i;
 }
 
 // Digit planes of the rows [r0, r0 + 16 kgs) of every problem:  planes[b][digit a][panel P][16-row group kg][column c][16 bytes = rows].
 // One (P, kg) piece of a digit is 512 contiguous bytes; two consecutive pieces are the A (or B) operand of one v_mfma_i32_32x32x32_i8 of a
 // wave: lane l = 32 (kg & 1) + c reads its 16 bytes at offset 16 l.  Rows >= m_pad are zero.
-// grid: (nb, ceil(kgs / 8), batch), 256 threads = 8 row groups x 32 columns — panels fastest: with a column permutation every lane of a load reads
-// another panel's 128-byte row, and the workgroups that want the other 31 columns of those rows are the other panels of the SAME row range.
+// grid: (nb, ceil(kgs / 8), batch), 256 threads = 8 row groups x 32 columns.  The workgroup READS panel P of X (coalesced) and writes column q = 32 P + c
+// to plane position inv[q] (nullable: q itself) — a scatter of 16-byte pieces.  (First version: plane panel P GATHERED its columns perm[32 P + c], every lane
+// of a load in another panel's 128-byte row: 5.6 ms per 32 x 4096^2 against 0.7 ms unpermuted.)
 __global__ __launch_bounds__(256) void split_i8_kernel(const float* __restrict__ X, int64_t panel_stride, int64_t batch_stride, int nb, int m_pad,
-                                                       int n_pad, const int* __restrict__ ex, int r0, int kgs, signed char* __restrict__ planes,
-                                                       int64_t plane_stride /* bytes per digit and problem = nb kgs 512 */,
-                                                       const int* __restrict__ perm /* nullable: plane column i holds column perm[i] of X; ex is in plane order */,
+                                                       int n_pad, const int* __restrict__ ex /* exponents of the columns of X, in X's order */, int r0, int kgs,
+                                                       signed char* __restrict__ planes, int64_t plane_stride /* bytes per digit and problem = nb kgs 512 */,
+                                                       const int* __restrict__ inv /* nullable: plane position of every column of X */,
                                                        const int* __restrict__ done /* nullable: problems whose flag is set are skipped */) {
     const int P = blockIdx.x, b = blockIdx.z, c = threadIdx.x & 31;
     const int kg = blockIdx.y * 8 + (threadIdx.x >> 5);
     if (kg >= kgs || (done && ld_flag(done + b))) return;
-    const int E = ex[(int64_t)b * n_pad + P * PB + c];
-    const int q = perm ? perm[(int64_t)b * n_pad + P * PB + c] : P * PB + c;
-    const float* __restrict__ xp = X + (int64_t)b * batch_stride + (int64_t)(q >> 5) * panel_stride + (q & 31);
+    const int q = P * PB + c;
+    const int E = ex[(int64_t)b * n_pad + q];
+    const int pos = inv ? inv[(int64_t)b * n_pad + q] : q;
+    const float* __restrict__ xp = X + (int64_t)b * batch_stride + (int64_t)P * panel_stride + c;
     unsigned w0[4] = {0, 0, 0, 0}, w1[4] = {0, 0, 0, 0}, w2[4] = {0, 0, 0, 0};
     if (E != GI_BAD && E != GI_ZERO) {
 #pragma unroll
@@ -106,7 +109,7 @@ __global__ __launch_bounds__(256) void split_i8_kernel(const float* __restrict__
             w2[i >> 2] |= (unsigned)(d2 & 0xff) << (8 * (i & 3));
         }
     }
-    signed char* pb = planes + (int64_t)b * 3 * plane_stride + ((int64_t)P * kgs + kg) * 512 + c * 16;
+    signed char* pb = planes + (int64_t)b * 3 * plane_stride + ((int64_t)(pos >> 5) * kgs + kg) * 512 + (pos & 31) * 16;
     *(uint4*)(pb) = make_uint4(w0[0], w0[1], w0[2], w0[3]);
     *(uint4*)(pb + plane_stride) = make_uint4(w1[0], w1[1], w1[2], w1[3]);
     *(uint4*)(pb + 2 * plane_stride) = make_uint4(w2[0], w2[1], w2[2], w2[3]);

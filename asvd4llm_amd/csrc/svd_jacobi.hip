@@ -1046,11 +1046,12 @@ static bool gram_i8_wanted() {
 
 // G (upper 32-blocks) = X^T X of the packed panels through the int8 digit planes (gram_i8.h).  scratch: >= 3 * n_pad * 64 * batch bytes; the
 // rows go in segments of what fits (and of at most 32768 rows: the int32 accumulators), each added to G in fp64.  ex: n_pad column exponents per
-// problem (colmaxexp_kernel) IN PLANE ORDER.  perm / dp (both or neither): plane column i holds column perm[i] of X and G_ij / (dp_i dp_j) is
-// stored — the sorted, unit-scaled Gram matrix the Cholesky factorisation starts from, without a pass over an unsorted one.
+// problem (colmaxexp_kernel) in the order of X.  inv / exs / dp (all or none): column q of X goes to plane position inv[q], exs / dp are the exponents and
+// norms in plane order, and G_ij / (dp_i dp_j) is stored — the sorted, unit-scaled Gram matrix the Cholesky factorisation starts from, without a pass
+// over an unsorted one.
 static int launch_gram_i8(const float* Xp, int64_t panel_stride, int64_t batch_stride, int nb, int m_pad, int n_pad, int batch, double* G,
-                          int64_t ldg, int64_t gbs, signed char* scratch, size_t scratch_bytes, const int* ex, const int* perm, const double* dp,
-                          int seg_rows_max, hipStream_t st) {
+                          int64_t ldg, int64_t gbs, signed char* scratch, size_t scratch_bytes, const int* ex, const int* inv, const int* exs,
+                          const double* dp, int seg_rows_max, hipStream_t st) {
     int64_t cap_rows = (int64_t)(scratch_bytes / ((size_t)3 * n_pad * batch)) / 64 * 64;
     if (cap_rows > 32768) cap_rows = 32768;
     if (seg_rows_max >= 64 && cap_rows > seg_rows_max / 64 * 64) cap_rows = seg_rows_max / 64 * 64;
@@ -1068,15 +1069,16 @@ static int launch_gram_i8(const float* Xp, int64_t panel_stride, int64_t batch_s
         const int kgs = rows / 16;
         const int64_t plane_stride = (int64_t)nb * kgs * 512;
         split_i8_kernel<<<dim3(nb, (unsigned)ceil_div64(kgs, 8), batch), 256, 0, st>>>(Xp, panel_stride, batch_stride, nb, m_pad, n_pad, ex, r0, kgs,
-                                                                                       scratch, plane_stride, perm, nullptr);
-        gram_i8_kernel<<<dim3(ntri, batch), 512, 2 * GI_STAGE_BYTES, st>>>(scratch, plane_stride, nb, kgs, n_pad, ex, G, ldg, gbs, s > 0 ? 1 : 0, nt, dp, order);
+                                                                                       scratch, plane_stride, inv, nullptr);
+        gram_i8_kernel<<<dim3(ntri, batch), 512, 2 * GI_STAGE_BYTES, st>>>(scratch, plane_stride, nb, kgs, n_pad, inv ? exs : ex, G, ldg, gbs, s > 0 ? 1 : 0, nt,
+                                                                           dp, order);
     }
     ASVD_HIP_CHECK(hipGetLastError());
     return ASVD_OK;
 }
 
 struct TallLayout {
-    size_t off_xp, off_g, off_gs, off_dp, off_df, off_perm, off_dg, off_d, off_fail, off_r, off_vr, off_part, off_inv, off_bex, off_aex, off_vmax, off_gex, off_ex, off_exs, off_inner, inner_bytes, total;
+    size_t off_xp, off_g, off_gs, off_dp, off_df, off_perm, off_dg, off_d, off_fail, off_r, off_vr, off_part, off_inv, off_bex, off_aex, off_vmax, off_gex, off_ex, off_exs, off_cinv, off_inner, inner_bytes, total;
     int n_pad64;
 };
 
@@ -1100,6 +1102,7 @@ static int tall_layout(int batch, const Plan& p, int want_vectors, int64_t k, Ta
     // column exponents of the int8 Gram matrix (gram_i8.h), original and sorted order
     t.off_ex = take((size_t)p.n_pad * batch * sizeof(int));
     t.off_exs = take((size_t)p.n_pad * batch * sizeof(int));
+    t.off_cinv = take((size_t)p.n_pad * batch * sizeof(int));   // plane position of every column (inverse of the norm sort)
     // exponents of the int8 long-side product (nn_gemm_i8.h): columns of X, rows of X, columns of Vr (key of the maximum, then the exponent)
     t.off_bex = take(want_vectors ? (size_t)p.n_pad * batch * sizeof(int) : 0);
     t.off_aex = take(want_vectors ? (size_t)round_up64(p.m_pad, 128) * batch * sizeof(int) : 0);
@@ -1173,15 +1176,26 @@ static int svd_tall(int batch, const void* const* a_host, int a_dtype, int64_t m
         // The int8 path takes the norms from the data first (fp64, colmaxexp_kernel) and stores the sorted, scaled matrix directly: Gs = D^-1 P^T G~ P D^-1
         // with G~ the exact Gram matrix of the digitised columns and D the norms of the original ones — diagonal 1 + O(1e-7) instead of exactly 1,
         // which is a column scaling like any other (R is un-scaled with the same D).  Digit planes in the G region, which this path does not use.
-        if (gram_i8_wanted()) {
+        // A Cholesky breakdown on the int8 path is retried ONCE with the fp64 Gram matrix before the call gives up on the reduction: the digitised columns
+        // differ from X by ~2^-25 of their largest entry, which decides the sign of a pivot only where singular values sit at the fp32 rounding level of
+        // X itself (rank n/4 + 1e-4 noise under abs_mean scaling: `profiles/r6_families.txt`) — there the exact Gram matrix of the exact X still factors.
+    }
+    std::vector<int> hfail(batch, 0);
+    bool use_i8 = gram_i8_wanted();
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        {
+        ProfScope ps(0, st);
+        if (attempt) ASVD_HIP_CHECK(hipMemsetAsync(fail, 0, (size_t)batch * sizeof(int), st));
+        if (use_i8) {
             int* ex = (int*)(wb + t.off_ex);
             int* exs = (int*)(wb + t.off_exs);
             colmaxexp_kernel<<<dim3(p.nb, batch), 256, 0, st>>>(Xp, p.panel_stride, p.batch_stride, p.m_pad, p.n_pad, ex, d);
             d_to_float_kernel<<<(unsigned)ceil_div64((int64_t)p.n_pad * batch, 256), 256, 0, st>>>(d, p.n_pad * batch, dF);
             rank_kernel<<<dim3((unsigned)ceil_div64(p.n_pad, 256), batch), 256, 0, st>>>(dF, p.n_pad, cperm);
-            perm_gather_kernel<<<dim3((unsigned)ceil_div64(p.n_pad, 256), batch), 256, 0, st>>>(ex, d, cperm, p.n_pad, exs, dp);
+            int* cinv = (int*)(wb + t.off_cinv);
+            perm_gather_kernel<<<dim3((unsigned)ceil_div64(p.n_pad, 256), batch), 256, 0, st>>>(ex, d, cperm, p.n_pad, exs, dp, cinv);
             rc = launch_gram_i8(Xp, p.panel_stride, p.batch_stride, p.nb, p.m_pad, p.n_pad, batch, Gs, ldg, gbs, (signed char*)G,
-                                (size_t)gbs * batch * sizeof(double), exs, cperm, dp, 0, st);
+                                (size_t)gbs * batch * sizeof(double), ex, cinv, exs, dp, 0, st);
             if (rc) return rc;
         } else {
             gram64_kernel<<<dim3(p.nb, (unsigned)ceil_div64(p.nb, 4), batch), 256, 0, st>>>(Xp, p.panel_stride, p.batch_stride, p.nb, p.m_pad, G, ldg, gbs);
@@ -1206,10 +1220,20 @@ static int svd_tall(int batch, const void* const* a_host, int a_dtype, int64_t m
             if (j1 < nbk) chol_syrk_multi_kernel<<<dim3(nbk - j1, nbk - j1, batch), 256, 0, st>>>(Gs, ldg, gbs, j0, j1 - j0, nbk);
         }
         r_to_f32_t_kernel<<<dim3((unsigned)(p.n_pad / 32), (unsigned)(p.n_pad / 32), batch), 256, 0, st>>>(Gs, ldg, gbs, Dg, dp, p.n_pad, R, gbs);  // n_pad is a multiple of 64
+        }
+        ASVD_HIP_CHECK(hipMemcpyAsync(hfail.data(), fail, (size_t)batch * sizeof(int), hipMemcpyDeviceToHost, st));
+        ASVD_HIP_CHECK(hipStreamSynchronize(st));
+        bool broke = false;
+        for (int b = 0; b < batch; ++b) broke = broke || hfail[b];
+        if (!broke) break;
+        if (use_i8 && attempt == 0) {
+            if (getenv("ASVD_DEBUG")) fprintf(stderr, "[asvd_svd] Cholesky breakdown on the int8 Gram matrix: once more with the fp64 Gram matrix\n");
+            use_i8 = false;
+            g_last_path |= ASVD_PATH_GRAM_RETRY;
+            continue;
+        }
+        break;
     }
-    std::vector<int> hfail(batch, 0);
-    ASVD_HIP_CHECK(hipMemcpyAsync(hfail.data(), fail, (size_t)batch * sizeof(int), hipMemcpyDeviceToHost, st));
-    ASVD_HIP_CHECK(hipStreamSynchronize(st));
     for (int b = 0; b < batch; ++b)
         if (hfail[b]) {
             if (getenv("ASVD_DEBUG")) fprintf(stderr, "[asvd_svd] Cholesky-QR breakdown for problem %d (code %d): falling back to the direct path\n", b, hfail[b]);
@@ -1330,7 +1354,7 @@ int asvd_test_gram(const float* Xp, int64_t panel_stride, int64_t batch_stride, 
     if (!scratch || !ex) return ASVD_E_BADARG;
     colmaxexp_kernel<<<dim3(nb, batch), 256, 0, st>>>(Xp, panel_stride, batch_stride, m_pad, n_pad, ex, nullptr);
     return launch_gram_i8(Xp, panel_stride, batch_stride, nb, m_pad, n_pad, batch, G, n_pad, (int64_t)n_pad * n_pad, (signed char*)scratch, scratch_bytes, ex,
-                          nullptr, nullptr, seg_rows, st);
+                          nullptr, nullptr, nullptr, seg_rows, st);
 }
 
 // Test hook: the super-panel pair schedule itself.  out[step * npairs + k] = (S << 16) | T of slot k of super-step `step`, or -1 for an empty

@@ -149,7 +149,7 @@ def scale_cols(w, s=None):
 
 class SvdInfo:
     """per-problem {status, sweeps, pairs rotated in the last sweep} + the path bits of the CALL the problem was part of
-    (asvd_svd_get_last_path: reduced / reduce_fallback / plain_retry / split)"""
+    (asvd_svd_get_last_path: reduced / reduce_fallback / plain_retry / split / split_refused / gram_retry)"""
 
     def __init__(self, status, sweeps, last_rot, path=0):
         self.status, self.sweeps, self.last_rotated_pairs, self.path = status, sweeps, last_rot, path
@@ -158,10 +158,11 @@ class SvdInfo:
         self.plain_retry = bool(path & L.PATH_PLAIN_RETRY)
         self.split = bool(path & L.PATH_SPLIT)
         self.split_refused = bool(path & L.PATH_SPLIT_REFUSED)
+        self.gram_retry = bool(path & L.PATH_GRAM_RETRY)
 
     def __repr__(self):
         return (f"SvdInfo(status={self.status}, sweeps={self.sweeps}, last_rotated_pairs={self.last_rotated_pairs}, reduced={self.reduced}, "
-                f"reduce_fallback={self.reduce_fallback}, plain_retry={self.plain_retry}, split={self.split})")
+                f"reduce_fallback={self.reduce_fallback}, plain_retry={self.plain_retry}, split={self.split}, gram_retry={self.gram_retry})")
 
 
 def svd_batched(mats, col_scales=None, k=None, want_vectors=True, max_sweeps=0, tol=0.0):

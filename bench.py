@@ -798,7 +798,7 @@ def main():
                              "recon_fro_err_rank512_vs_oracle": max(q["recon_fro_err_rank%d_vs_oracle" % r] for q in problems),
                              "recon_fro_err_scaled_norm": max(q["recon_fro_err_scaled_norm"] for q in problems),
                              "problems": problems, "problems_note": "worst of the first problem of the batch (first half of a split call) and the last (second half); outputs of the LAST TIMED step",
-                             "timed_call_path": {"split": timed_infos[0].split, "reduced": timed_infos[0].reduced, "reduce_fallback": timed_infos[0].reduce_fallback,
+                             "timed_call_path": {"split": timed_infos[0].split, "reduced": timed_infos[0].reduced, "reduce_fallback": timed_infos[0].reduce_fallback, "gram_retry": any(i.gram_retry for i in timed_infos),
                                                  "plain_retry": timed_infos[0].plain_retry},
                              "truncation_err_over_W_device_k9": k9["recon_err_over_W_device"], "truncation_err_over_W_oracle_fp64": oracle_err,
                              "vs_stock_svd_lowrank": {"criterion": "SURVEY 8c secondary: |Ws - (rank-r of the HIP path)|_F <= |Ws - torch.svd_lowrank(Ws, q=r)|_F (1 + 1e-5); the exact "

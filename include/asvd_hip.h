@@ -169,6 +169,8 @@ int asvd_svd_batched(int batch, const void* const* a_host, int a_dtype, int64_t 
 #define ASVD_PATH_SPLIT 8            /* the batch ran as two halves on two CU-masked streams */
 #define ASVD_PATH_SPLIT_REFUSED 16   /* the batch qualified for the split but ran as one call on the caller's stream: another process computes on the
                                         device or the caller's stream carries a CU mask of its own */
+#define ASVD_PATH_GRAM_RETRY 32      /* the Cholesky broke down on the int8 Gram matrix (columns rounded to 2^-25 of their largest entry) and the reduction was
+                                      * repeated with the fp64 Gram matrix of the exact columns (which either completes: REDUCED, or breaks down too: REDUCE_FALLBACK) */
 int asvd_svd_get_last_path(void);
 /* single-problem convenience wrapper (batch = 1) */
 int asvd_svd(const void* a, int a_dtype, int64_t m, int64_t n, int64_t lda, const void* col_scale, int cs_dtype,

@@ -83,7 +83,7 @@ def main():
         dt = time.time() - t0
         rec = {"family": kind, "stat": stat, "alpha": alpha, "svd_per_s": round(B / dt, 2), "ms_per_call": round(dt * 1e3, 1),
                "sweeps_min": min(i.sweeps for i in infos), "sweeps_max": max(i.sweeps for i in infos),
-               "status_max": max(i.status for i in infos), "reduced": infos[0].reduced, "reduce_fallback": infos[0].reduce_fallback,
+               "status_max": max(i.status for i in infos), "reduced": infos[0].reduced, "reduce_fallback": infos[0].reduce_fallback, "gram_retry": any(i.gram_retry for i in infos),
                "plain_retry": infos[0].plain_retry, "split": infos[0].split, "gen_s": round(gen_s, 1)}
         if not a.no_check:
             for b in (0, B - 1):
