@@ -1204,12 +1204,14 @@ static int svd_tall(int batch, const void* const* a_host, int a_dtype, int64_t m
             rank_kernel<<<dim3((unsigned)ceil_div64(p.n_pad, 256), batch), 256, 0, st>>>(dF, p.n_pad, cperm);
             g_permute_scale_kernel<<<dim3((unsigned)ceil_div64(p.n_pad, 256), p.n_pad, batch), 256, 0, st>>>(G, ldg, gbs, d, cperm, p.n_pad, Gs, dp);
         }
-        // block rows in groups of four: inside a group each finished row updates the rest of the group's strip (K = 64), the matrix behind
-        // the group is updated once per group (K = 256)
+        // block rows in groups of six (four until round 6): inside a group each finished row updates the rest of the group's strip (K = 64), the matrix
+        // behind the group is updated once per group (K = 384)
         // (Round 6, measured and removed — profiles/r6_chol_lookahead.txt: the chain of group g + 1 on a second, equally CU-masked stream beside the bulk
         // of group g's trailing update, the next group's strip updated first.  Reduction 48.1-48.5 -> 52.3 ms per 32 x 4096^2: the two extra launches and
         // event hand-overs per group cost more than the 0.5 ms chain they hide, and the trailing update loses the CUs the chain occupies.)
-        constexpr int cg = 4;
+        // (block rows per group, 32 x 4096^2, reduction ms: 2: 48.0 · 4: 44.4-44.6 · 5: 42.1 · 6: 42.2-42.6 · 7: 41.9 · 8: 44.9-45.2 — profiles/r6_chol_group.txt)
+        int cg = 6;
+        if (const char* ecg = getenv("ASVD_CHOL_GROUP")) cg = std::max(1, std::min(16, atoi(ecg)));   // measurement knob: block rows per grouped trailing update
         for (int j0 = 0; j0 < nbk; j0 += cg) {
             const int j1 = std::min(nbk, j0 + cg);
             for (int jb = j0; jb < j1; ++jb) {

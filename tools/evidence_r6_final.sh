@@ -26,3 +26,10 @@ python tools/full_model_bench.py --model llama-2-13b 2>/dev/null | tail -1 > $O/
 python tools/bench_i8_gemm.py > $O/i8_gemm_micro.jsonl 2>/dev/null
 python tools/bench_aux.py > $O/aux.jsonl 2> /dev/null
 ls -la $O gpurun_out/prof_r6 | tail -40
+# whole pipeline (asvd.py flags) on one GPU with the final library: BASELINE configs[2] (7B shapes, n_calib 32, ~13 min), configs[4]'s workload at n_calib 4, opt-125m-shaped
+if [ "${1:-all}" = all ]; then
+python tools/gpu_e2e_cli.py opt-125m 16 2>/dev/null | tail -1 > $O/e2e_opt125m.json
+python tools/gpu_e2e_cli.py llama-2-13b 4 --param_ratio_target 0.95 2>/dev/null | tail -1 > $O/e2e_llama2_13b_ratio095_ncalib4.json
+python tools/gpu_e2e_cli.py llama-2-7b 32 2>/dev/null | tail -1 > $O/e2e_llama2_7b_ncalib32.json
+ls -la $O | tail -5
+fi
