@@ -1,5 +1,5 @@
 #!/bin/bash
-# Reproduces the round's evidence on one MI355X.  Outputs under gpurun_out/; copy what should be kept to profiles/ (named r<round>_*).
+# Reproduces the evidence on one MI355X (round 6, final library: tools/evidence_r6_final.sh is the shorter script the committed profiles/r6_* came from).  Outputs under gpurun_out/; copy what should be kept to profiles/ (named r<round>_*).
 #   bash tools/reproduce_evidence.sh            # everything (about 60 minutes)
 #   bash tools/reproduce_evidence.sh quick      # tests + smoke + bench only (about 20 minutes)
 #   bash tools/reproduce_evidence.sh prof       # rocprofv3 kernel stats + PMC passes + power telemetry + bench (about 12 minutes): run this one
