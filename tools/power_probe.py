@@ -1,6 +1,6 @@
 """Socket power / shader clock / power cap telemetry next to a workload ("put telemetry in the evidence").
 
-  python tools/power_probe.py --workload {idle,supgram,supgram_ni,bench,mfma} [--seconds 6] [--out file.json]
+  python tools/power_probe.py --workload {idle,supgram,supgram_ni,bench,mfma,gram_i8,gram_fp64} [--seconds 6] [--out file.json]
 
 A sampler thread reads amdsmi (power, gfx clock, temperature, power cap) every ~50 ms while the main thread keeps the GPU busy with
 the chosen workload: back-to-back launches of the fused update + Gram kernel on random / near-identity Q (tools/bench_supgram.py's
@@ -121,6 +121,27 @@ def main():
             ops.truncate_split_batched(U, S, V, scales, 512, "UV", torch.float16)
             torch.cuda.synchronize()
             return 1
+    elif a.workload in ("gram_i8", "gram_fp64"):
+        # the Gram matrix of the reduction alone (asvd_test_gram): int8 digit path / fp64 matrix instructions, 32 x 4096^2, back to back
+        from asvd4llm_amd import _lib as L
+        lib = L.load(True)
+        vp = ctypes.c_void_p
+        gb, gn = 32, 4096   # (`n` is the loop counter of main)
+        gnb = gn // 32
+        P = torch.randn(gb, gnb, gn, 32, device=gpu) * 0.02
+        G = torch.empty(gb, gn, gn, dtype=torch.float64, device=gpu)
+        scratch = torch.empty(3 * gn * gn * gb, dtype=torch.int8, device=gpu)
+        ex = torch.zeros(gb, gn, dtype=torch.int32, device=gpu)
+        mode = 1 if a.workload == "gram_i8" else 0
+        unit = "Gram matrix of 32 x 4096^2 (" + ("int8 digit planes incl. digitising" if mode else "fp64 MFMA") + ")"
+        st = torch.cuda.current_stream().cuda_stream
+
+        def work():
+            for _ in range(10):
+                lib.asvd_test_gram(vp(P.data_ptr()), gn * 32, gnb * gn * 32, gnb, gn, gb, mode, 0, vp(G.data_ptr()), vp(scratch.data_ptr()), scratch.numel(),
+                                   vp(ex.data_ptr()), vp(st))
+            torch.cuda.synchronize()
+            return 10
     elif a.workload == "idle":
         def work():
             time.sleep(0.2)
