@@ -109,3 +109,14 @@ def test_environment_names_in_header_exist_in_the_sources():
     design = open(os.path.join(ROOT, "DESIGN.md")).read()
     undocumented = sorted(n for n in read_c if n not in src and n not in design)
     assert not undocumented, f"csrc/ reads environment names neither asvd_hip.h nor DESIGN.md mention: {undocumented}"
+
+
+def test_path_bits_of_the_header_match_the_python_binding():
+    """ASVD_PATH_* (include/asvd_hip.h) are what ops.SvdInfo decodes: the values in asvd4llm_amd/_lib.py must be the header's"""
+    from asvd4llm_amd import _lib as L
+    src = open(os.path.join(ROOT, "include", "asvd_hip.h")).read()
+    bits = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+ASVD_PATH_([A-Z_]+)\s+(\d+)", src)}
+    assert set(bits) == {"REDUCED", "REDUCE_FALLBACK", "PLAIN_RETRY", "SPLIT", "SPLIT_REFUSED", "GRAM_RETRY"}, bits
+    for name, val in bits.items():
+        assert getattr(L, "PATH_" + name) == val, name
+    assert len(set(bits.values())) == len(bits) and all(v & (v - 1) == 0 for v in bits.values())   # distinct single bits
