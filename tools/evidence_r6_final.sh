@@ -33,3 +33,9 @@ python tools/gpu_e2e_cli.py llama-2-13b 4 --param_ratio_target 0.95 2>/dev/null 
 python tools/gpu_e2e_cli.py llama-2-7b 32 2>/dev/null | tail -1 > $O/e2e_llama2_7b_ncalib32.json
 ls -la $O | tail -5
 fi
+# the remaining round-6 records (each was its own job):
+#   for w in idle gram_i8 gram_fp64 mfma supgram bench; do python tools/power_probe.py --workload $w --seconds 6 --out gpurun_out/ev/power.jsonl; done          -> profiles/r6_power.jsonl
+#   ASVD_DEBUG_WORKFILL=255 python -m pytest tests/test_gpu_svd.py tests/test_gpu_gram_i8.py tests/test_gpu_families.py tests/test_gpu_full_model.py -q   -> profiles/r6_poisoned_workspace_tests.txt
+#   ASVD_GRAM_I8=0 ASVD_SNAP_I8=0 ASVD_NN_I8=0 python -m pytest tests/test_gpu_svd.py tests/test_gpu_families.py -q                                      -> profiles/r6_legacy_kernels_tests.txt
+#   for v in 4 6 ...; do ASVD_CHOL_GROUP=$v python bench.py --no_cpu_baseline --no_latency --sharded_model none --steps 4 --warmup 1 --prewarm_s 3; done   -> profiles/r6_chol_group.txt
+#   python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 bench.py --gpus 2 --steps 3 --warmup 1 --dist_backend gloo --same_gpu -> profiles/r6_bench_2ranks_one_gpu_gloo.json
